@@ -1,0 +1,290 @@
+"""Pins the oracle (oracle/caro_oracle.c) against
+  (a) the reference's own known-answer tests, restated as data, and
+  (b) vectors recorded from the reference itself (tests/golden/make_golden.py).
+CPU only.  These tests are what allows the GPU parity tests to trust the oracle.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle, noise_row
+from tests.conftest import load_golden
+
+
+def make_oracle(d, n_stores=1):
+    if d["kind"] == "c4":
+        return Oracle(Oracle.C4, n_stores=n_stores)
+    return Oracle(Oracle.MNK, d["n"], d["k"], n_stores=n_stores)
+
+
+# --------------------------------------------------------------- (a) known answers
+class TestConnectFourKnownAnswers:
+    """Values from lib/game/connect_four/test_connect_four.py:28-191."""
+
+    EMPTY = 0b000000000000000000000000000000000000000000110110110110110110110
+    FULL1 = 0b111111111111111111111111111111111111111111000000000000000000000
+
+    def enc(self, o, cols):
+        cells = np.full(42, 2, np.uint8)
+        for c, col in enumerate(cols):
+            for r, v in enumerate(col):
+                cells[c * 6 + r] = v
+        return o.to_int(cells)
+
+    def dec(self, o, s):
+        cells = o.to_cells(s)
+        return [[int(cells[c * 6 + r]) for r in range(6) if cells[c * 6 + r] != 2] for c in range(7)]
+
+    def test_encode_decode(self):
+        o = Oracle(Oracle.C4)
+        assert o.initial_state == self.EMPTY == 1797558
+        assert self.enc(o, [[]] * 7) == self.EMPTY
+        assert self.enc(o, [[1] * 6] * 7) == self.FULL1
+        assert self.enc(o, [[0] * 6] * 7) == 0
+        assert self.dec(o, self.EMPTY) == [[]] * 7
+        assert self.dec(o, self.FULL1) == [[1] * 6] * 7
+        assert self.dec(o, 0) == [[0] * 6] * 7
+
+    def test_possible_moves(self):
+        o = Oracle(Oracle.C4)
+        assert o.possible_moves(0) == []
+        assert o.possible_moves(self.FULL1) == []
+        assert o.possible_moves(self.EMPTY) == [0, 1, 2, 3, 4, 5, 6]
+
+    def test_vertical_win(self):
+        o = Oracle(Oracle.C4)
+        f = self.EMPTY
+        for i, exp in enumerate([False, False, False, True]):
+            f, won = o.move(f, 0, 1)
+            assert won == exp
+            assert self.dec(o, f) == [[1] * (i + 1)] + [[]] * 6
+
+    def test_horizontal_win(self):
+        o = Oracle(Oracle.C4)
+        f = self.EMPTY
+        for col, exp in [(0, False), (1, False), (3, False), (2, True)]:
+            f, won = o.move(f, col, 1)
+            assert won == exp
+        assert self.dec(o, f) == [[1], [1], [1], [1], [], [], []]
+
+    def test_diags(self):
+        o = Oracle(Oracle.C4)
+        f = self.enc(o, [[0, 0, 0, 1], [0, 0, 1], [0], [1], [], [], []])
+        assert o.move(f, 2, 1)[1] is True
+        assert o.move(f, 2, 0)[1] is False
+        f = self.enc(o, [[], [0, 1], [0, 0, 1], [1, 0, 0, 1], [], [], []])
+        assert o.move(f, 0, 1)[1] is True
+        assert o.move(f, 0, 0)[1] is False
+
+    def test_tricky(self):
+        o = Oracle(Oracle.C4)
+        f = self.enc(o, [[0, 1, 1], [1, 0], [0, 1], [0, 0, 1], [0, 0], [1, 1, 1, 0], []])
+        s, won = o.move(f, 4, 0)
+        assert won is True
+        assert s == 3531389463375529686
+
+    def test_model_view(self):
+        o = Oracle(Oracle.C4)
+        s = self.enc(o, [[0, 1, 0], [0], [1, 1, 1], [], [1], [], []])
+        batch = o.states_to_training_batch([s, s], [1, 0])
+        black_me = np.zeros((6, 7)); black_me[3, 2] = black_me[4, 0] = black_me[4, 2] = black_me[5, 2] = black_me[5, 4] = 1
+        black_op = np.zeros((6, 7)); black_op[3, 0] = black_op[5, 0] = black_op[5, 1] = 1
+        np.testing.assert_equal(batch[0], [black_me, black_op])
+        np.testing.assert_equal(batch[1], [black_op, black_me])
+
+
+class TestTicTacToeKnownAnswers:
+    """Values from lib/game/tictactoe/test_tictactoe.py:12-144."""
+
+    def test_codec(self):
+        o = Oracle(Oracle.MNK, 3, 3)
+        assert o.to_int([1, 2, 0, 0, 2, 0, 1, 0, 0]) == int("120020100")
+        assert o.to_int([0, 0, 0, 1, 2, 0, 1, 0, 0]) == int("000120100")
+        assert o.to_cells(int("010220011")).tolist() == [0, 1, 0, 2, 2, 0, 0, 1, 1]
+        assert o.initial_state == 222222222
+
+    def test_possible_moves(self):
+        o = Oracle(Oracle.MNK, 3, 3)
+        assert o.possible_moves(int("010220011")) == [3, 4]
+        assert o.possible_moves(int("212220012")) == [0, 2, 3, 4, 8]
+
+    def test_planes(self):
+        o = Oracle(Oracle.MNK, 3, 3)
+        b = o.states_to_training_batch([int("001010221"), int("101222001")], [1, 0])
+        np.testing.assert_equal(b[0], [[[0, 0, 1], [0, 1, 0], [0, 0, 1]], [[1, 1, 0], [1, 0, 1], [0, 0, 0]]])
+        np.testing.assert_equal(b[1], [[[0, 1, 0], [0, 0, 0], [1, 1, 0]], [[1, 0, 1], [0, 0, 0], [0, 0, 1]]])
+
+    def test_moves(self):
+        o = Oracle(Oracle.MNK, 3, 3)
+        b = int("222222222")
+        for mv, pl, exp in [(1, 0, "202222222"), (5, 1, "202221222"), (8, 0, "202221220"), (7, 1, "202221210")]:
+            b, won = o.move(b, mv, pl)
+            assert won is False and b == int(exp)
+
+    @pytest.mark.parametrize("board,mv,pl,exp", [
+        ("002112122", 2, 0, "000112122"), ("021012212", 6, 0, "021012012"),
+        ("021102212", 8, 0, "021102210"), ("120122012", 4, 0, "120102012"),
+        ("120102222", 6, 1, "120102122")])
+    def test_winning_moves(self, board, mv, pl, exp):
+        o = Oracle(Oracle.MNK, 3, 3)
+        nb, won = o.move(int(board), mv, pl)
+        assert won is True and nb == int(exp)
+
+
+class TestBackupKnownAnswer:
+    """lib/test_mcts.py:25-38: a 2-action mock game, states 1 -> 2 -> 3."""
+
+    def test_back_up(self):
+        o = Oracle(Oracle.MNK, 3, 3)  # any game; only A matters, we use 2 of the 9 slots
+        A = o.A
+
+        def pad(x, fill=0):
+            return list(x) + [fill] * (A - len(x))
+
+        keys = {1: np.full(9, 2, np.uint8), 2: np.full(9, 2, np.uint8), 3: np.full(9, 2, np.uint8)}
+        keys[2][0] = 0
+        keys[3][0] = 0; keys[3][1] = 1
+        o.poke_node(keys[1], pad([0, 1]), pad([0.0, 0.5]), pad([0.0, 0.5]), pad([0.1, 0.9]))
+        o.poke_node(keys[2], pad([1, 0]), pad([0.6, 0.0]), pad([0.6, 0.0]), pad([0.8, 0.2]))
+        o.poke_node(keys[3], pad([0, 0]), pad([0.0, 0.0]), pad([0.0, 0.0]), pad([0.7, 0.3]))
+        o.backup(0.2, np.stack([keys[1], keys[2], keys[3]]), [1, 0, 0])
+        n1, n2, n3 = (o.get_node_cells(keys[i]) for i in (1, 2, 3))
+        assert n1["N"][:2].tolist() == [0, 2] and n2["N"][:2].tolist() == [2, 0] and n3["N"][:2].tolist() == [1, 0]
+        assert n1["W"][:2].tolist() == [0.0, 0.3] and n2["W"][:2].tolist() == [0.8, 0.0]
+        assert n3["W"][:2].tolist() == [-0.2, 0.0]
+        assert n1["Q"][:2].tolist() == [0.0, 0.15] and n2["Q"][:2].tolist() == [0.4, 0.0]
+        assert n3["Q"][:2].tolist() == [-0.2, 0.0]
+
+
+# --------------------------------------------------------------- (b) recorded from the reference
+@pytest.mark.parametrize("name", ["rules_c4.json.gz", "rules_ttt3.json.gz", "rules_mnk5.json.gz",
+                                  "rules_mnk15.json.gz"])
+def test_rules_vs_reference(name):
+    d = load_golden(name)
+    o = make_oracle(d)
+    assert len(d["recs"]) > 500
+    for r in d["recs"]:
+        s = int(r["s"])
+        assert o.possible_moves(s) == r["legal"]
+        s2, won = o.move(s, r["m"], r["p"])
+        assert s2 == int(r["s2"]) and won == r["won"]
+        planes = o.states_to_training_batch([s2], [1 - r["p"]])[0]
+        assert np.packbits(planes.astype(np.uint8).reshape(-1)).tobytes().hex() == r["planes"]
+
+
+def _check_game(o, g, net_setup):
+    o.set_stream(g["seed"], g["uid"])
+    if "noise_table" in g:  # explicit-table path
+        o.set_noise_table(np.array(g["noise_table"]))
+        o.set_uniform_table(np.array(g["uniform_table"]))
+    else:
+        o.set_noise_table(None)
+        o.set_uniform_table(None)
+    net_setup(o)
+    res = o.play_game(g["steps_before_tau_0"], g["searches"], g["batch"], g["first_player"])
+    assert res["result"] == g["result"]
+    assert res["steps"] == g["steps"]
+    assert res["plies"] == g["plies"]
+    assert [str(s) for s in res["states"]] == g["states"]
+    assert res["players"].tolist() == g["players"]
+    assert res["z"].tolist() == g["z"]
+    for ply in range(g["plies"]):
+        assert res["rootN"][ply].tolist() == g["trace"][ply]["N"], ply
+        assert res["nodes"][ply] == g["trace"][ply]["nodes"], ply
+        assert res["pi"][ply].tolist() == g["pi"][ply], ply  # float64, bit exact
+    return res
+
+
+@pytest.mark.parametrize("name", ["synth_c4.json.gz", "synth_ttt3.json.gz", "synth_mnk5.json.gz",
+                                  "synth_mnk15.json.gz"])
+def test_search_vs_reference_synth_net(name):
+    """G2: select / dedupe / expand / backup / policy / play_game with the
+    synthetic table net: every integer and every float64 pi bit exact."""
+    d = load_golden(name)
+    for g in d["games"]:
+        o = make_oracle(d, g["n_stores"])
+        _check_game(o, g, lambda oo: oo.use_synth_net())
+
+
+def test_noise_spec_matches_recorded_tables():
+    d = load_golden("synth_c4.json.gz")
+    g = d["games"][0]
+    tab = np.array(g["noise_table"])
+    assert hashlib.sha1(tab.tobytes()).hexdigest() == g["noise_sha1"]
+    # first row is (ply 0, sim 8): the root is expanded by the first minibatch (Q6)
+    np.testing.assert_array_equal(tab[0], noise_row(g["seed"], g["uid"], 0, 8, 7))
+    assert abs(tab.sum(axis=1) - 1).max() < 1e-12
+    assert tab.min() > 0
+
+
+def test_root_WQ_dtypes_vs_reference():
+    """W / Q values and their NEP-50 dtype (python float vs float32) at the
+    root after every ply's search."""
+    d = load_golden("synth_c4.json.gz")
+    g = d["games"][1]
+    o = make_oracle(d, g["n_stores"])
+    o.use_synth_net()
+    o.set_stream(g["seed"], g["uid"])
+    # replay the game ply by ply with search_batch so the tree can be inspected
+    state = o.initial_state
+    player = g["first_player"]
+    for ply in range(g["plies"]):
+        assert str(state) == g["states"][ply]
+        o.search_batch(g["searches"], g["batch"], state, player, ply=ply)
+        nd = o.get_node(state)
+        tr = g["trace"][ply]
+        assert nd["N"].tolist() == tr["N"]
+        assert nd["W"].tolist() == tr["W"]
+        assert nd["Q"].tolist() == tr["Q"]
+        assert nd["W_is_f32"].tolist() == tr["W_f32"]
+        pi = np.array(g["pi"][ply])
+        nxt = [i for i in range(o.A)]
+        # the move actually played: recover from the next recorded state
+        if ply + 1 < g["plies"]:
+            for a in o.possible_moves(state):
+                s2, _ = o.move(state, a, player)
+                if str(s2) == g["states"][ply + 1]:
+                    state = s2
+                    break
+            else:
+                raise AssertionError("no move leads to the recorded next state")
+            player = 1 - player
+        del pi, nxt
+
+
+# --------------------------------------------------------------- real weights (G3 / G5)
+def _torch_net(path, shape, A):
+    import os
+    import torch
+    from caro_ai_amd.lib.model import Net
+    from tests.conftest import GOLDEN
+    torch.set_num_threads(1)
+    net = Net(shape, A)
+    net.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", path), map_location="cpu"))
+    net.eval()
+
+    def fn(planes, states, players):
+        with torch.no_grad():
+            logits, values = net(torch.from_numpy(np.ascontiguousarray(planes)))
+            return torch.softmax(logits, dim=1).numpy(), values.numpy()[:, 0]
+
+    return fn
+
+
+@pytest.mark.parametrize("name", ["real_c4.json.gz", "real_ttt3.json.gz", "arena_c4.json.gz"])
+def test_play_game_vs_reference_real_weights(name):
+    """G3 / G5: the oracle driving the SAME torch CPU float32 forward on the
+    same leaf batches reproduces the reference's games exactly (the net is
+    third-party arithmetic; identical batches give identical bits)."""
+    d = load_golden(name)
+    w = d["weights"] if isinstance(d["weights"], list) else [d["weights"], d["weights"]]
+    for g in d["games"]:
+        o = make_oracle(d, g["n_stores"])
+        shape = (2, o.rows, o.cols)
+
+        def setup(oo):
+            oo.set_net(0, _torch_net(w[0], shape, oo.A))
+            oo.set_net(1, _torch_net(w[1], shape, oo.A))
+
+        _check_game(o, g, setup)
