@@ -1,0 +1,1402 @@
+// caro_engine.hip -- MI355X (gfx950) self-play engine: kernels + C-ABI.
+//
+// What runs where (reference file:line in brackets):
+//   k_select         B find_leaf descents per game on the frozen tree
+//                    [lib/mcts.py:97-148,64-95,48-62] + leaf de-duplication
+//                    [lib/mcts.py:265-278].  One workgroup per game, one group
+//                    of LPD lanes per descent, lanes = actions; PUCT argmax is
+//                    a xor-butterfly over (score, action) inside the group.
+//   k_scan/k_encode  deterministic compaction of the unique leaves into dense
+//                    net rows + NN planes [game.states_to_training_batch].
+//   k_expand_backup  _create_node + ordered _backup [lib/mcts.py:178-190,225-246,281-287].
+//   k_step           get_policy_value + one ply of play_game
+//                    [lib/mcts.py:289-313, lib/utils.py:80-99].
+//   k_drain_*        replay emission [lib/utils.py:101-106] + slot recycling.
+//
+// Data layout in HBM (T = G * n_stores trees, AP = padded action count):
+//   slots    i32 [T][hcap]          open-addressing table, -1 = empty
+//   node_key u64 [T][cap][KW]       board of each node (the transposition key)
+//   edges    u32 [T][cap][4][AP]    per node four action rows N | W | Q | P,
+//                                   adjacent in memory (connect four: one
+//                                   128-byte line per node); N carries the
+//                                   "strong" flag in bit 30 (W has absorbed a
+//                                   float32 value).
+// Arithmetic: non-root PUCT in float32, root PUCT in float64, no FMA
+// contraction (compiled with -ffp-contract=off), exactly the order of
+// lib/mcts.py:79-84 under numpy>=2 scalar promotion.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/caro_hip.h"
+#include "../../include/caro_noise.h"
+#include "caro_rules.h"
+
+namespace caro {
+
+constexpr uint32_t NSTRONG = 1u << 30;
+constexpr uint32_t NMASK = NSTRONG - 1u;
+constexpr int ST_DROPPED = 0, ST_TERMINAL = 1, ST_LEAF = 2;
+constexpr int MAXB = 64;
+
+enum Counter { C_SIMS, C_LEVELS, C_EXPANSIONS, C_TERMINALS, C_DROPPED, C_OVERFLOW, C_PLIES, C_FINISHED, C_N };
+
+struct View {
+  GameParams gp;
+  int G, n_stores, n_nets, cap, hcap, A, HW, maxply, maxd, maxB, sbt0, first_mode;
+  float c_puct;
+  double alpha, explore;
+  uint64_t seed, uid_base, uid_stride;
+  // trees
+  int32_t* slots;
+  uint64_t* node_key;
+  uint32_t* edges;
+  int32_t* n_nodes;
+  int32_t* n_created;
+  // games
+  uint64_t* root;
+  int32_t* player;
+  int32_t* ply;
+  int32_t* step;
+  uint64_t* uid;
+  int32_t* done;    // 0 live, 1 finished (awaiting drain)
+  int32_t* result;  // net1_result
+  int32_t* final_r; // 1 win of the last mover, 0 draw
+  int32_t* first;
+  // history
+  uint64_t* h_key;
+  int32_t* h_player;
+  double* h_pi;
+  // minibatch scratch
+  int32_t* path_node;
+  int32_t* path_act;
+  int32_t* path_len;
+  int32_t* d_status;
+  float* d_value;
+  int32_t* d_local;
+  uint64_t* d_key;
+  int32_t* d_player;
+  int32_t* g_nleaf;
+  int32_t* g_off;
+  int32_t* g_tree;
+  int32_t* g_class;
+  int32_t* leaf_count;  // [4]: L0, L1, batch of the pending minibatch, -
+  unsigned long long* counters;
+  // drain scratch
+  int32_t* dr_off;
+  int32_t* dr_gidx;
+  int32_t* dr_sel;
+  int64_t* dr_tot;  // [2] tuples, games
+};
+
+template <class R_, int LPD_, int APL_>
+struct Geo {
+  using R = R_;
+  static constexpr int LPD = LPD_, APL = APL_, AP = LPD_ * APL_, KW = R_::KW;
+};
+using GeoC4 = Geo<C4Rules, 8, 1>;
+using GeoM16 = Geo<MnkRules<1>, 16, 1>;
+using GeoM32 = Geo<MnkRules<1>, 32, 1>;
+using GeoM64 = Geo<MnkRules<1>, 64, 1>;
+using GeoM128 = Geo<MnkRules<2>, 64, 2>;
+using GeoM256 = Geo<MnkRules<4>, 64, 4>;
+
+// ------------------------------------------------------------------ device helpers
+template <class R>
+__device__ __forceinline__ typename R::Board load_board(const uint64_t* p) {
+  typename R::Board b;
+#pragma unroll
+  for (int i = 0; i < R::KW; ++i) b.w[i] = p[i];
+  return b;
+}
+template <class R>
+__device__ __forceinline__ void store_board(uint64_t* p, const typename R::Board& b) {
+#pragma unroll
+  for (int i = 0; i < R::KW; ++i) p[i] = b.w[i];
+}
+
+// `state in self.probs` (lib/mcts.py:160): open-addressing probe of tree t
+template <class R>
+__device__ __forceinline__ int probe(const View& v, int t, const typename R::Board& b) {
+  const uint32_t mask = (uint32_t)v.hcap - 1u;
+  uint32_t i = (uint32_t)R::hash(b) & mask;
+  const int32_t* sl = v.slots + (size_t)t * v.hcap;
+  for (int it = 0; it < v.hcap; ++it) {
+    const int s = sl[i];
+    if (s < 0) return -1;
+    const uint64_t* k = v.node_key + ((size_t)t * v.cap + s) * R::KW;
+    bool eq = true;
+#pragma unroll
+    for (int w = 0; w < R::KW; ++w) eq = eq && (k[w] == b.w[w]);
+    if (eq) return s;
+    i = (i + 1u) & mask;
+  }
+  return -1;
+}
+
+template <class R>
+__device__ __forceinline__ void insert_slot(const View& v, int t, const typename R::Board& b, int node) {
+  const uint32_t mask = (uint32_t)v.hcap - 1u;
+  uint32_t i = (uint32_t)R::hash(b) & mask;
+  int32_t* sl = v.slots + (size_t)t * v.hcap;
+  for (int it = 0; it < v.hcap; ++it) {
+    if (sl[i] < 0) {
+      sl[i] = node;
+      return;
+    }
+    i = (i + 1u) & mask;
+  }
+}
+
+template <int LPD>
+__device__ __forceinline__ double group_sum_f64(double x) {
+#pragma unroll
+  for (int m = 1; m < LPD; m <<= 1) x = x + __shfl_xor(x, m, LPD);
+  return x;
+}
+template <int LPD>
+__device__ __forceinline__ int group_sum_i32(int x) {
+#pragma unroll
+  for (int m = 1; m < LPD; m <<= 1) x = x + __shfl_xor(x, m, LPD);
+  return x;
+}
+
+// One Dirichlet row of caro_noise.h for the LPD lanes of a descent group:
+// lane l holds actions l*APL .. l*APL+APL-1.  Per-lane adjacent tree, then the
+// xor butterfly: the balanced adjacent-pair tree sum of the spec.
+template <int LPD, int APL>
+__device__ __forceinline__ void noise_group(uint64_t key, int l, int A, double alpha, double* out) {
+  double g[APL];
+#pragma unroll
+  for (int j = 0; j < APL; ++j) {
+    const int a = l * APL + j;
+    g[j] = a < A ? caro_gamma_small(key, (uint32_t)a, alpha) : 0.0;
+  }
+  double s;
+  if (APL == 1) s = g[0];
+  else if (APL == 2) s = g[0] + g[1];
+  else s = (g[0] + g[1]) + (g[2 % APL] + g[3 % APL]);
+  s = group_sum_f64<LPD>(s);
+#pragma unroll
+  for (int j = 0; j < APL; ++j) out[j] = g[j] / s;
+}
+
+// ------------------------------------------------------------------ select
+template <class GEO>
+__global__ void k_select(View v, int B, int mb_index, const double* __restrict__ noise) {
+  using R = typename GEO::R;
+  using Board = typename R::Board;
+  constexpr int LPD = GEO::LPD, APL = GEO::APL, AP = GEO::AP, KW = GEO::KW;
+  const int g = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int b = tid / LPD, l = tid % LPD;
+
+  __shared__ uint64_t s_key[MAXB][KW];
+  __shared__ int s_status[MAXB];
+  __shared__ int s_first[MAXB];
+  __shared__ int s_depth[MAXB];
+
+  if (v.done[g]) {
+    if (tid == 0) {
+      v.g_nleaf[g] = 0;
+      v.g_class[g] = 0;
+    }
+    return;
+  }
+  const Board root = load_board<R>(v.root + (size_t)g * KW);
+  const int player0 = v.player[g];
+  const int t = g * v.n_stores + (v.n_stores == 2 ? player0 : 0);
+  const uint32_t ply = (uint32_t)v.ply[g];
+  const uint64_t uid = v.uid[g];
+  const int A = v.A;
+
+  Board cur = root;
+  int player = player0;
+  int depth = 0;
+  int status = ST_LEAF;
+  float value = 0.0f;
+  int32_t* pn = v.path_node + ((size_t)g * v.maxB + b) * v.maxd;
+  int32_t* pa = v.path_act + ((size_t)g * v.maxB + b) * v.maxd;
+  const float c32 = v.c_puct;
+  const double c64 = (double)v.c_puct;
+
+  int node = probe<R>(v, t, cur);
+  while (node >= 0 && depth < v.maxd) {
+    const uint32_t* row = v.edges + ((size_t)t * v.cap + node) * 4 * AP;
+    uint32_t nraw[APL];
+    float q[APL], p[APL];
+    int nsum = 0;
+#pragma unroll
+    for (int j = 0; j < APL; ++j) {
+      const int a = l * APL + j;
+      nraw[j] = row[a];
+      q[j] = __uint_as_float(row[2 * AP + a]);
+      p[j] = __uint_as_float(row[3 * AP + a]);
+      nsum += (int)(nraw[j] & NMASK);
+    }
+    nsum = group_sum_i32<LPD>(nsum);
+    const double sq = caro_sqrt((double)nsum);  // m.sqrt(sum(counts)), mcts.py:79
+    double best = -__builtin_huge_val();
+    int besta = 0x7fffffff;
+    if (depth == 0) {
+      // root: _add_noise (mcts.py:48-62) -> float64 probs, float64 scores
+      double nz[APL];
+      if (noise) {
+#pragma unroll
+        for (int j = 0; j < APL; ++j) {
+          const int a = l * APL + j;
+          nz[j] = a < A ? noise[((size_t)g * B + b) * A + a] : 0.0;
+        }
+      } else {
+        const uint64_t key = caro_noise_key(v.seed, uid, ply, (uint32_t)(mb_index * B + b));
+        noise_group<LPD, APL>(key, l, A, v.alpha, nz);
+      }
+      const float keepf = (float)(1.0 - v.explore);
+#pragma unroll
+      for (int j = 0; j < APL; ++j) {
+        const int a = l * APL + j;
+        const int n = (int)(nraw[j] & NMASK);
+        const float keep = keepf * p[j];                            // py float * float32 -> float32
+        const double prob = (double)keep + v.explore * nz[j];       // float32 + float64 -> float64
+        const double u = ((c64 * prob) * sq) / (double)(1 + n);
+        double qd;
+        if (nraw[j] & NSTRONG) qd = (double)q[j];                   // np.float32 Q
+        else if (n > 0) qd = (double)__uint_as_float(row[AP + a]) / (double)n;  // python-float W / int
+        else qd = 0.0;
+        double sc = qd + u;
+        if (!R::legal(v.gp, cur, a)) sc = -__builtin_huge_val();
+        if (sc > best || (sc == best && a < besta)) {
+          best = sc;
+          besta = a;
+        }
+      }
+    } else {
+      const float sqf = (float)sq;
+#pragma unroll
+      for (int j = 0; j < APL; ++j) {
+        const int a = l * APL + j;
+        const int n = (int)(nraw[j] & NMASK);
+        float tt = c32 * p[j];
+        tt = tt * sqf;
+        tt = tt / (float)(1 + n);
+        double sc = (double)(q[j] + tt);
+        if (!R::legal(v.gp, cur, a)) sc = -__builtin_huge_val();
+        if (sc > best || (sc == best && a < besta)) {
+          best = sc;
+          besta = a;
+        }
+      }
+    }
+    // np.argmax: first maximum (mcts.py:136)
+#pragma unroll
+    for (int m = 1; m < LPD; m <<= 1) {
+      const double ob = __shfl_xor(best, m, LPD);
+      const int oa = __shfl_xor(besta, m, LPD);
+      if (ob > best || (ob == best && oa < besta)) {
+        best = ob;
+        besta = oa;
+      }
+    }
+    if (l == 0) {
+      pn[depth] = node;
+      pa[depth] = besta;
+    }
+    const bool won = R::move(v.gp, cur, besta, player);  // game.move, mcts.py:138
+    player ^= 1;
+    ++depth;
+    if (won) {  // mcts.py:140-142
+      status = ST_TERMINAL;
+      value = -1.0f;
+      break;
+    }
+    if (R::full(v.gp, cur)) {  // mcts.py:145-146
+      status = ST_TERMINAL;
+      value = 0.0f;
+      break;
+    }
+    node = probe<R>(v, t, cur);
+  }
+
+  if (l == 0) {
+#pragma unroll
+    for (int w = 0; w < KW; ++w) s_key[b][w] = cur.w[w];
+    s_status[b] = status;
+    s_depth[b] = depth;
+  }
+  __syncthreads();
+  // planned-set de-duplication (mcts.py:272-278): first occurrence of a new leaf is kept
+  if (l == 0) {
+    int first = 0;
+    if (status == ST_LEAF) {
+      first = 1;
+      for (int bb = 0; bb < b; ++bb) {
+        if (s_status[bb] != ST_LEAF) continue;
+        bool eq = true;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) eq = eq && (s_key[bb][w] == cur.w[w]);
+        if (eq) first = 0;
+      }
+    }
+    s_first[b] = first;
+  }
+  __syncthreads();
+  if (l == 0) {
+    int local = 0;
+    for (int bb = 0; bb < b; ++bb) local += s_first[bb];
+    const size_t di = (size_t)g * v.maxB + b;
+    int st = status;
+    if (status == ST_LEAF && !s_first[b]) st = ST_DROPPED;
+    v.d_status[di] = st;
+    v.d_value[di] = value;
+    v.d_local[di] = local;
+    v.d_player[di] = player;
+    v.path_len[di] = depth;
+    store_board<R>(v.d_key + di * KW, cur);
+  }
+  if (tid == 0) {
+    int nleaf = 0, levels = 0, term = 0, drop = 0;
+    for (int bb = 0; bb < B; ++bb) {
+      nleaf += s_first[bb];
+      levels += s_depth[bb];
+      term += s_status[bb] == ST_TERMINAL;
+      drop += (s_status[bb] == ST_LEAF && !s_first[bb]);
+    }
+    v.g_nleaf[g] = nleaf;
+    v.g_tree[g] = t;
+    v.g_class[g] = v.n_nets == 2 ? player0 : 0;
+    atomicAdd(&v.counters[C_SIMS], (unsigned long long)B);
+    atomicAdd(&v.counters[C_LEVELS], (unsigned long long)levels);
+    if (term) atomicAdd(&v.counters[C_TERMINALS], (unsigned long long)term);
+    if (drop) atomicAdd(&v.counters[C_DROPPED], (unsigned long long)drop);
+  }
+}
+
+// exclusive scan of the per-game unique-leaf counts, class 0 rows first, then class 1
+__global__ void k_scan(View v, int B) {
+  __shared__ int s0[1024], s1[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (v.G + 1023) / 1024;
+  const int lo = tid * chunk, hi = min(v.G, lo + chunk);
+  int c0 = 0, c1 = 0;
+  for (int g = lo; g < hi; ++g) {
+    const int n = v.g_nleaf[g];
+    if (v.g_class[g]) c1 += n; else c0 += n;
+  }
+  s0[tid] = c0;
+  s1[tid] = c1;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int a0 = tid >= d ? s0[tid - d] : 0, a1 = tid >= d ? s1[tid - d] : 0;
+    __syncthreads();
+    s0[tid] += a0;
+    s1[tid] += a1;
+    __syncthreads();
+  }
+  const int tot0 = s0[1023], tot1 = s1[1023];
+  int o0 = s0[tid] - c0, o1 = tot0 + s1[tid] - c1;
+  for (int g = lo; g < hi; ++g) {
+    const int n = v.g_nleaf[g];
+    if (v.g_class[g]) { v.g_off[g] = o1; o1 += n; } else { v.g_off[g] = o0; o0 += n; }
+  }
+  if (tid == 0) {
+    v.leaf_count[0] = tot0;
+    v.leaf_count[1] = tot1;
+    v.leaf_count[2] = B;
+    atomicAdd(&v.counters[C_EXPANSIONS], (unsigned long long)(tot0 + tot1));
+  }
+}
+
+template <class GEO>
+__global__ void k_encode(View v, int B, float* __restrict__ planes, uint64_t* __restrict__ leaf_keys) {
+  using R = typename GEO::R;
+  constexpr int KW = GEO::KW;
+  const int g = blockIdx.x;
+  if (v.g_nleaf[g] == 0) return;
+  const int off = v.g_off[g];
+  const int HW = v.HW;
+  for (int b = 0; b < B; ++b) {
+    const size_t di = (size_t)g * v.maxB + b;
+    if (v.d_status[di] != ST_LEAF) continue;
+    const int rowi = off + v.d_local[di];
+    const typename R::Board brd = load_board<R>(v.d_key + di * KW);
+    const int who = v.d_player[di];
+    float* dst = planes + (size_t)rowi * 2 * HW;
+    for (int i = threadIdx.x; i < 2 * HW; i += blockDim.x)
+      dst[i] = R::plane(v.gp, brd, who, i / HW, i % HW);
+    if (leaf_keys && threadIdx.x < KW) leaf_keys[(size_t)rowi * KW + threadIdx.x] = brd.w[threadIdx.x];
+  }
+}
+
+// _backup of one path by one lane (mcts.py:225-246), float32 running sums in queue order
+template <int AP>
+__device__ __forceinline__ void backup_path(const View& v, int t, float value, bool strong_val, const int32_t* pn,
+                                            const int32_t* pa, int len) {
+  float cur = -value;
+  for (int i = len - 1; i >= 0; --i) {
+    uint32_t* row = v.edges + ((size_t)t * v.cap + pn[i]) * 4 * AP;
+    const int a = pa[i];
+    const uint32_t nraw = row[a];
+    const int n = (int)(nraw & NMASK) + 1;
+    const uint32_t strong = (nraw & NSTRONG) | (strong_val ? NSTRONG : 0u);
+    const float w = __uint_as_float(row[AP + a]) + cur;
+    const float q = w / (float)n;
+    row[a] = (uint32_t)n | strong;
+    row[AP + a] = __float_as_uint(w);
+    row[2 * AP + a] = __float_as_uint(q);
+    cur = -cur;
+  }
+}
+
+template <class GEO>
+__global__ void k_expand_backup(View v, const float* __restrict__ probs, const float* __restrict__ values) {
+  using R = typename GEO::R;
+  constexpr int AP = GEO::AP, KW = GEO::KW;
+  const int g = blockIdx.x;
+  if (v.done[g]) return;
+  const int B = v.leaf_count[2];
+  const int lane = threadIdx.x;
+  const int t = v.g_tree[g];
+  const int nleaf = v.g_nleaf[g];
+  const int off = v.g_off[g];
+  const int base = v.n_nodes[t];
+  const bool overflow = base + nleaf > v.cap;
+  const int A = v.A;
+  if (!overflow) {
+    for (int b = 0; b < B; ++b) {
+      const size_t di = (size_t)g * v.maxB + b;
+      if (v.d_status[di] != ST_LEAF) continue;
+      const int local = v.d_local[di];
+      const int rowi = off + local, node = base + local;
+      uint32_t* row = v.edges + ((size_t)t * v.cap + node) * 4 * AP;
+      for (int a = lane; a < AP; a += blockDim.x) {  // _create_node, mcts.py:178-190
+        row[a] = 0u;
+        row[AP + a] = 0u;
+        row[2 * AP + a] = 0u;
+        row[3 * AP + a] = a < A ? __float_as_uint(probs[(size_t)rowi * A + a]) : 0u;
+      }
+      if (lane == 0) {
+        const typename R::Board brd = load_board<R>(v.d_key + di * KW);
+        store_board<R>(v.node_key + ((size_t)t * v.cap + node) * KW, brd);
+        insert_slot<R>(v, t, brd, node);
+      }
+    }
+  }
+  if (lane == 0) {
+    if (overflow) {
+      atomicAdd(&v.counters[C_OVERFLOW], 1ull);
+    } else {
+      v.n_nodes[t] = base + nleaf;
+      v.n_created[t] += nleaf;
+    }
+    // backup queue order (mcts.py:269-271,221-223,286-287): terminals in sim order, then new leaves
+    for (int b = 0; b < B; ++b) {
+      const size_t di = (size_t)g * v.maxB + b;
+      if (v.d_status[di] == ST_TERMINAL)
+        backup_path<AP>(v, t, v.d_value[di], false, v.path_node + di * v.maxd, v.path_act + di * v.maxd,
+                        v.path_len[di]);
+    }
+    if (!overflow)
+      for (int b = 0; b < B; ++b) {
+        const size_t di = (size_t)g * v.maxB + b;
+        if (v.d_status[di] == ST_LEAF)
+          backup_path<AP>(v, t, values[off + v.d_local[di]], true, v.path_node + di * v.maxd,
+                          v.path_act + di * v.maxd, v.path_len[di]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------ policy / step
+template <class GEO>
+__device__ __forceinline__ void root_policy(const View& v, int g, int t, const typename GEO::R::Board& root,
+                                            double* s_pi, int* s_n) {
+  using R = typename GEO::R;
+  constexpr int AP = GEO::AP;
+  const int node = probe<R>(v, t, root);
+  for (int a = threadIdx.x; a < AP; a += blockDim.x)
+    s_n[a] = (node >= 0 && a < v.A) ? (int)(v.edges[((size_t)t * v.cap + node) * 4 * AP + a] & NMASK) : 0;
+  __syncthreads();
+  __shared__ int s_best;
+  __shared__ double s_total;
+  if (threadIdx.x == 0) {
+    const int tau = (v.sbt0 > 0 && v.step[g] < v.sbt0) ? 1 : 0;  // utils.py:70,97-99
+    int best = 0;
+    long long tot = 0;
+    for (int a = 0; a < v.A; ++a) {
+      if (s_n[a] > s_n[best]) best = a;
+      tot += s_n[a];
+    }
+    s_best = tau == 0 ? best : -1;
+    s_total = (double)tot;
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < AP; a += blockDim.x) {
+    double p = 0.0;
+    if (a < v.A) p = s_best >= 0 ? (a == s_best ? 1.0 : 0.0) : (double)s_n[a] / s_total;  // mcts.py:305-311
+    s_pi[a] = p;
+  }
+  __syncthreads();
+}
+
+template <class GEO>
+__global__ void k_policy(View v, double* __restrict__ pi_out, int32_t* __restrict__ counts_out) {
+  using R = typename GEO::R;
+  constexpr int AP = GEO::AP, KW = GEO::KW;
+  __shared__ double s_pi[AP];
+  __shared__ int s_n[AP];
+  const int g = blockIdx.x;
+  const typename R::Board root = load_board<R>(v.root + (size_t)g * KW);
+  const int t = g * v.n_stores + (v.n_stores == 2 ? v.player[g] : 0);
+  root_policy<GEO>(v, g, t, root, s_pi, s_n);
+  for (int a = threadIdx.x; a < v.A; a += blockDim.x) {
+    if (pi_out) pi_out[(size_t)g * v.A + a] = s_pi[a];
+    if (counts_out) counts_out[(size_t)g * v.A + a] = s_n[a];
+  }
+}
+
+template <class GEO>
+__global__ void k_step(View v, const double* __restrict__ uniforms, int32_t* __restrict__ actions,
+                       int32_t* __restrict__ done_out, int32_t* __restrict__ result_out) {
+  using R = typename GEO::R;
+  using Board = typename R::Board;
+  constexpr int AP = GEO::AP, KW = GEO::KW;
+  __shared__ double s_pi[AP];
+  __shared__ int s_n[AP];
+  const int g = blockIdx.x;
+  if (v.done[g]) {
+    if (threadIdx.x == 0) {
+      if (actions) actions[g] = -1;
+      if (done_out) done_out[g] = 1;
+      if (result_out) result_out[g] = v.result[g];
+    }
+    return;
+  }
+  Board root = load_board<R>(v.root + (size_t)g * KW);
+  const int player = v.player[g];
+  const int t = g * v.n_stores + (v.n_stores == 2 ? player : 0);
+  root_policy<GEO>(v, g, t, root, s_pi, s_n);
+  const int ply = v.ply[g];
+  // game_history.append((state, cur_player, probs)), utils.py:82
+  const size_t hi = (size_t)g * v.maxply + ply;
+  for (int a = threadIdx.x; a < v.A; a += blockDim.x) v.h_pi[hi * v.A + a] = s_pi[a];
+  if (threadIdx.x == 0) {
+    store_board<R>(v.h_key + hi * KW, root);
+    v.h_player[hi] = player;
+    const double u = uniforms ? uniforms[g] : caro_move_uniform(v.seed, v.uid[g], (uint32_t)ply);
+    const int action = caro_sample_index(s_pi, v.A, u);  // np.random.choice(A, p=probs), utils.py:83
+    const bool won = R::move(v.gp, root, action, player);  // utils.py:86
+    store_board<R>(v.root + (size_t)g * KW, root);
+    v.ply[g] = ply + 1;
+    int done = 0, res = 0;
+    if (won) {  // utils.py:87-90
+      done = 1;
+      v.final_r[g] = 1;
+      res = player == 0 ? 1 : -1;
+    } else {
+      v.player[g] = 1 - player;
+      if (R::full(v.gp, root)) {  // utils.py:93-96
+        done = 1;
+        v.final_r[g] = 0;
+        res = 0;
+      } else {
+        v.step[g] = v.step[g] + 1;  // utils.py:97
+      }
+    }
+    if (done) {
+      v.done[g] = 1;
+      v.result[g] = res;
+      atomicAdd(&v.counters[C_FINISHED], 1ull);
+    }
+    atomicAdd(&v.counters[C_PLIES], 1ull);
+    if (actions) actions[g] = action;
+    if (done_out) done_out[g] = done;
+    if (result_out) result_out[g] = res;
+  }
+}
+
+// ------------------------------------------------------------------ reset / drain
+template <class GEO>
+__device__ __forceinline__ void reset_game(const View& v, int g, uint64_t uid, int first) {
+  using R = typename GEO::R;
+  constexpr int KW = GEO::KW;
+  for (int s = 0; s < v.n_stores; ++s) {
+    const int t = g * v.n_stores + s;
+    int32_t* sl = v.slots + (size_t)t * v.hcap;
+    for (int i = threadIdx.x; i < v.hcap; i += blockDim.x) sl[i] = -1;
+    if (threadIdx.x == 0) {
+      v.n_nodes[t] = 0;
+      v.n_created[t] = 0;
+    }
+  }
+  if (threadIdx.x == 0) {
+    const typename R::Board b0 = R::initial(v.gp);
+    store_board<R>(v.root + (size_t)g * KW, b0);
+    int fp = first;
+    if (fp < 0) fp = v.first_mode == 2 ? (int)(uid & 1ull) : v.first_mode;
+    v.player[g] = fp;
+    v.first[g] = fp;
+    v.ply[g] = 0;
+    v.step[g] = 0;
+    v.uid[g] = uid;
+    v.done[g] = 0;
+    v.result[g] = 0;
+    v.final_r[g] = 0;
+  }
+}
+
+template <class GEO>
+__global__ void k_reset(View v, const int32_t* __restrict__ first_player) {
+  const int g = blockIdx.x;
+  reset_game<GEO>(v, g, v.uid_base + (uint64_t)g, first_player ? first_player[g] : -1);
+}
+
+template <class GEO>
+__global__ void k_set_roots(View v, const uint64_t* __restrict__ keys, const int32_t* __restrict__ players) {
+  constexpr int KW = GEO::KW;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= v.G) return;
+  for (int w = 0; w < KW; ++w) v.root[(size_t)g * KW + w] = keys[(size_t)g * KW + w];
+  v.player[g] = players[g];
+  v.done[g] = 0;
+}
+
+// which finished games fit into `cap` tuples: exclusive scan of their ply counts (single block)
+__global__ void k_drain_scan(View v, long long cap) {
+  __shared__ long long s_t[1024];
+  __shared__ int s_g[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (v.G + 1023) / 1024;
+  const int lo = tid * chunk, hi = min(v.G, lo + chunk);
+  long long ct = 0;
+  int cg = 0;
+  for (int g = lo; g < hi; ++g)
+    if (v.done[g] == 1) { ct += v.ply[g]; cg += 1; }
+  s_t[tid] = ct;
+  s_g[tid] = cg;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const long long a = tid >= d ? s_t[tid - d] : 0;
+    const int b = tid >= d ? s_g[tid - d] : 0;
+    __syncthreads();
+    s_t[tid] += a;
+    s_g[tid] += b;
+    __syncthreads();
+  }
+  long long ot = s_t[tid] - ct;
+  int og = s_g[tid] - cg;
+  __shared__ long long s_tot;
+  __shared__ int s_totg;
+  if (tid == 0) { s_tot = 0; s_totg = 0; }
+  __syncthreads();
+  for (int g = lo; g < hi; ++g) {
+    int sel = 0;
+    if (v.done[g] == 1) {
+      if (ot + v.ply[g] <= cap) {
+        sel = 1;
+        v.dr_off[g] = (int)ot;
+        v.dr_gidx[g] = og;
+        atomicMax((unsigned long long*)&s_tot, (unsigned long long)(ot + v.ply[g]));
+        atomicMax(&s_totg, og + 1);
+      }
+      ot += v.ply[g];
+      og += 1;
+    }
+    v.dr_sel[g] = sel;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    v.dr_tot[0] = s_tot;
+    v.dr_tot[1] = s_totg;
+  }
+}
+
+template <class GEO>
+__global__ void k_drain_copy(View v, uint64_t* __restrict__ states, int32_t* __restrict__ players,
+                             double* __restrict__ pi, int32_t* __restrict__ z, int64_t* __restrict__ games,
+                             int recycle) {
+  constexpr int KW = GEO::KW;
+  const int g = blockIdx.x;
+  if (!v.dr_sel[g]) return;
+  const int n = v.ply[g];
+  const int off = v.dr_off[g];
+  const int r = v.final_r[g];
+  // reversed(game_history), result alternating from the last mover (utils.py:101-106)
+  for (int idx = threadIdx.x; idx < n * v.A; idx += blockDim.x) {
+    const int j = idx / v.A, a = idx % v.A;
+    const int plyi = n - 1 - j;
+    pi[((size_t)off + j) * v.A + a] = v.h_pi[((size_t)g * v.maxply + plyi) * v.A + a];
+  }
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const int plyi = n - 1 - j;
+    const size_t hi = (size_t)g * v.maxply + plyi;
+    for (int w = 0; w < KW; ++w) states[((size_t)off + j) * KW + w] = v.h_key[hi * KW + w];
+    players[off + j] = v.h_player[hi];
+    z[off + j] = (j & 1) ? -r : r;
+  }
+  if (threadIdx.x == 0 && games) {
+    int64_t* rec = games + (size_t)v.dr_gidx[g] * 4;
+    rec[0] = (int64_t)v.uid[g];
+    rec[1] = v.first[g];
+    rec[2] = v.result[g];
+    rec[3] = v.step[g];
+  }
+  __syncthreads();
+  if (recycle) {
+    reset_game<GEO>(v, g, v.uid[g] + v.uid_stride, -1);
+  } else if (threadIdx.x == 0) {
+    v.done[g] = 2;  // drained, stays finished
+  }
+}
+
+__global__ void k_count_live(View v, int32_t* out) {
+  int c = 0;
+  for (int g = threadIdx.x; g < v.G; g += blockDim.x) c += v.done[g] == 0;
+  atomicAdd(out, c);
+}
+
+// ------------------------------------------------------------------ inspection
+template <class GEO>
+__global__ void k_lookup(View v, long long M, const int32_t* __restrict__ game, const int32_t* __restrict__ store,
+                         const uint64_t* __restrict__ keys, int32_t* found, int32_t* N, float* W, float* Q, float* P,
+                         int32_t* strong) {
+  using R = typename GEO::R;
+  constexpr int AP = GEO::AP, KW = GEO::KW;
+  const long long m = blockIdx.x;
+  if (m >= M) return;
+  const int t = game[m] * v.n_stores + store[m];
+  const typename R::Board b = load_board<R>(keys + (size_t)m * KW);
+  const int node = probe<R>(v, t, b);
+  if (threadIdx.x == 0) found[m] = node >= 0;
+  if (node < 0) return;
+  const uint32_t* row = v.edges + ((size_t)t * v.cap + node) * 4 * AP;
+  for (int a = threadIdx.x; a < v.A; a += blockDim.x) {
+    const size_t o = (size_t)m * v.A + a;
+    N[o] = (int)(row[a] & NMASK);
+    strong[o] = (row[a] & NSTRONG) ? 1 : 0;
+    W[o] = __uint_as_float(row[AP + a]);
+    Q[o] = __uint_as_float(row[2 * AP + a]);
+    P[o] = __uint_as_float(row[3 * AP + a]);
+  }
+}
+
+template <class GEO>
+__global__ void k_poke(View v, long long M, const int32_t* __restrict__ game, const int32_t* __restrict__ store,
+                       const uint64_t* __restrict__ keys, const int32_t* N, const float* W, const float* Q,
+                       const float* P, const int32_t* strong) {
+  using R = typename GEO::R;
+  constexpr int AP = GEO::AP, KW = GEO::KW;
+  // single block, sequential over m: insertion order is deterministic
+  for (long long m = 0; m < M; ++m) {
+    const int t = game[m] * v.n_stores + store[m];
+    const typename R::Board b = load_board<R>(keys + (size_t)m * KW);
+    __shared__ int s_node;
+    if (threadIdx.x == 0) {
+      int node = probe<R>(v, t, b);
+      if (node < 0 && v.n_nodes[t] < v.cap) {
+        node = v.n_nodes[t]++;
+        v.n_created[t]++;
+        store_board<R>(v.node_key + ((size_t)t * v.cap + node) * KW, b);
+        insert_slot<R>(v, t, b, node);
+      }
+      s_node = node;
+    }
+    __syncthreads();
+    const int node = s_node;
+    if (node >= 0) {
+      uint32_t* row = v.edges + ((size_t)t * v.cap + node) * 4 * AP;
+      for (int a = threadIdx.x; a < AP; a += blockDim.x) {
+        const size_t o = (size_t)m * v.A + a;
+        const bool in = a < v.A;
+        row[a] = in ? ((uint32_t)N[o] | (strong[o] ? NSTRONG : 0u)) : 0u;
+        row[AP + a] = in ? __float_as_uint(W[o]) : 0u;
+        row[2 * AP + a] = in ? __float_as_uint(Q[o]) : 0u;
+        row[3 * AP + a] = in ? __float_as_uint(P[o]) : 0u;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <class GEO>
+__global__ void k_backup_one(View v, int game, int store, float value, int strong, int len,
+                             const uint64_t* __restrict__ keys, const int32_t* __restrict__ actions, int32_t* scratch) {
+  using R = typename GEO::R;
+  constexpr int AP = GEO::AP, KW = GEO::KW;
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int t = game * v.n_stores + store;
+  for (int i = 0; i < len; ++i) scratch[i] = probe<R>(v, t, load_board<R>(keys + (size_t)i * KW));
+  for (int i = 0; i < len; ++i)
+    if (scratch[i] < 0) return;  // KeyError in the reference
+  backup_path<AP>(v, t, value, strong != 0, scratch, actions, len);
+}
+
+template <class GEO>
+__global__ void k_dump(View v, int game, int store, long long cap, uint64_t* keys, int32_t* N, float* W, float* Q,
+                       float* P, int32_t* strong) {
+  constexpr int AP = GEO::AP, KW = GEO::KW;
+  const int t = game * v.n_stores + store;
+  const int nn = v.n_nodes[t];
+  const long long node = blockIdx.x;
+  if (node >= nn || node >= cap) return;
+  const uint32_t* row = v.edges + ((size_t)t * v.cap + node) * 4 * AP;
+  for (int a = threadIdx.x; a < v.A; a += blockDim.x) {
+    const size_t o = (size_t)node * v.A + a;
+    N[o] = (int)(row[a] & NMASK);
+    strong[o] = (row[a] & NSTRONG) ? 1 : 0;
+    W[o] = __uint_as_float(row[AP + a]);
+    Q[o] = __uint_as_float(row[2 * AP + a]);
+    P[o] = __uint_as_float(row[3 * AP + a]);
+  }
+  if (threadIdx.x < KW) keys[(size_t)node * KW + threadIdx.x] = v.node_key[((size_t)t * v.cap + node) * KW + threadIdx.x];
+}
+
+__global__ void k_tree_sizes(View v, int32_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < v.G * v.n_stores) out[i] = v.n_created[i];
+}
+
+template <class GEO>
+__global__ void k_get_roots(View v, uint64_t* keys, int32_t* players, int32_t* ply, uint64_t* uid) {
+  constexpr int KW = GEO::KW;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= v.G) return;
+  if (keys)
+    for (int w = 0; w < KW; ++w) keys[(size_t)g * KW + w] = v.root[(size_t)g * KW + w];
+  if (players) players[g] = v.player[g];
+  if (ply) ply[g] = v.ply[g];
+  if (uid) uid[g] = v.uid[g];
+}
+
+// ------------------------------------------------------------------ batched rules
+template <class GEO>
+__global__ void k_rules_move(GameParams gp, long long M, uint64_t* keys, const int32_t* moves, const int32_t* players,
+                             int32_t* won, int32_t* full) {
+  using R = typename GEO::R;
+  constexpr int KW = GEO::KW;
+  const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  typename R::Board b = load_board<R>(keys + (size_t)m * KW);
+  const bool w = R::move(gp, b, moves[m], players[m]);
+  store_board<R>(keys + (size_t)m * KW, b);
+  won[m] = w;
+  full[m] = R::full(gp, b);
+}
+template <class GEO>
+__global__ void k_rules_legal(GameParams gp, long long M, const uint64_t* keys, uint8_t* legal) {
+  using R = typename GEO::R;
+  constexpr int KW = GEO::KW;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * gp.A) return;
+  const long long m = idx / gp.A;
+  const int a = (int)(idx % gp.A);
+  const typename R::Board b = load_board<R>(keys + (size_t)m * KW);
+  legal[idx] = R::legal(gp, b, a);
+}
+template <class GEO>
+__global__ void k_rules_encode(GameParams gp, long long M, const uint64_t* keys, const int32_t* who, float* planes) {
+  using R = typename GEO::R;
+  constexpr int KW = GEO::KW;
+  const int HW = gp.rows * gp.cols;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * 2 * HW) return;
+  const long long m = idx / (2 * HW);
+  const int i = (int)(idx % (2 * HW));
+  const typename R::Board b = load_board<R>(keys + (size_t)m * KW);
+  planes[idx] = R::plane(gp, b, who[m], i / HW, i % HW);
+}
+template <class GEO>
+__global__ void k_noise(uint64_t seed, long long M, int A, double alpha, const uint64_t* uid, const uint32_t* ply,
+                        const uint32_t* sim, double* out) {
+  constexpr int LPD = GEO::LPD, APL = GEO::APL;
+  const int grp = threadIdx.x / LPD, l = threadIdx.x % LPD;
+  const long long m = (long long)blockIdx.x * (blockDim.x / LPD) + grp;
+  const long long mm = m < M ? m : M - 1;  // keep whole groups active for the shuffles
+  const uint64_t key = caro_noise_key(seed, uid[mm], ply[mm], sim[mm]);
+  double nz[APL];
+  noise_group<LPD, APL>(key, l, A, alpha, nz);
+  if (m < M)
+    for (int j = 0; j < APL; ++j) {
+      const int a = l * APL + j;
+      if (a < A) out[(size_t)m * A + a] = nz[j];
+    }
+}
+
+}  // namespace caro
+
+// =================================================================== host side
+using namespace caro;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(x)                                                                                  \
+  do {                                                                                             \
+    hipError_t e_ = (x);                                                                           \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(CARO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                     \
+  } while (0)
+
+enum Variant { V_C4, V_M16, V_M32, V_M64, V_M128, V_M256, V_BAD };
+
+static Variant pick_variant(int kind, int n) {
+  if (kind == CARO_GAME_CONNECT4) return V_C4;
+  if (kind != CARO_GAME_MNK || n < 2 || n > 15) return V_BAD;
+  const int A = n * n;
+  if (A <= 16) return V_M16;
+  if (A <= 32) return V_M32;
+  if (A <= 64) return V_M64;
+  if (A <= 128) return V_M128;
+  return V_M256;
+}
+static int variant_kw(Variant v) {
+  switch (v) {
+    case V_C4: return 1;
+    case V_M16: case V_M32: case V_M64: return 2;
+    case V_M128: return 4;
+    case V_M256: return 8;
+    default: return 0;
+  }
+}
+static int variant_lpd(Variant v) {
+  switch (v) {
+    case V_C4: return 8;
+    case V_M16: return 16;
+    case V_M32: return 32;
+    default: return 64;
+  }
+}
+static int variant_ap(Variant v) {
+  switch (v) {
+    case V_C4: return 8;
+    case V_M16: return 16;
+    case V_M32: return 32;
+    case V_M64: return 64;
+    case V_M128: return 128;
+    case V_M256: return 256;
+    default: return 0;
+  }
+}
+static GameParams make_gp(int kind, int n, int k) {
+  GameParams gp;
+  gp.kind = kind;
+  if (kind == CARO_GAME_CONNECT4) {
+    gp.n = 0; gp.k = 4; gp.A = 7; gp.rows = 6; gp.cols = 7;
+  } else {
+    gp.n = n; gp.k = k; gp.A = n * n; gp.rows = n; gp.cols = n;
+  }
+  return gp;
+}
+
+#define DISPATCH(var, EXPR)                                          \
+  switch (var) {                                                     \
+    case V_C4: { using GEO = GeoC4; EXPR; } break;                   \
+    case V_M16: { using GEO = GeoM16; EXPR; } break;                 \
+    case V_M32: { using GEO = GeoM32; EXPR; } break;                 \
+    case V_M64: { using GEO = GeoM64; EXPR; } break;                 \
+    case V_M128: { using GEO = GeoM128; EXPR; } break;               \
+    case V_M256: { using GEO = GeoM256; EXPR; } break;               \
+    default: return fail(CARO_E_INVAL, "unsupported game geometry"); \
+  }
+
+struct caro_engine {
+  caro_config cfg;
+  Variant var;
+  View v;
+  std::vector<void*> allocs;
+  int32_t* pinned;   // host pinned [8]
+  int64_t* pinned64; // host pinned [8]
+  int32_t* scratch;  // device i32 [maxply]
+  int32_t* live;     // device i32
+  int select_pending;
+};
+
+template <class T>
+static int dalloc(caro_engine* h, T** p, size_t n) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, n * sizeof(T) + 256);
+  if (e != hipSuccess) return fail(CARO_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+extern "C" {
+
+const char* caro_last_error(void) { return g_err.c_str(); }
+int caro_version(void) { return 100; }
+
+int caro_key_words(int kind, int n) { return variant_kw(pick_variant(kind, n)); }
+int caro_action_space(int kind, int n) { return kind == CARO_GAME_CONNECT4 ? 7 : n * n; }
+int caro_obs_cells(int kind, int n) { return kind == CARO_GAME_CONNECT4 ? 42 : n * n; }
+
+// ---- host helpers (same rules header, host instantiation)
+#define HOST_DISPATCH(var, EXPR) DISPATCH(var, EXPR)
+
+int caro_host_initial(int kind, int n, int k, uint64_t* key) {
+  const Variant var = pick_variant(kind, n);
+  const GameParams gp = make_gp(kind, n, k);
+  HOST_DISPATCH(var, { auto b = GEO::R::initial(gp); for (int i = 0; i < GEO::KW; ++i) key[i] = b.w[i]; });
+  return 0;
+}
+int caro_host_move(int kind, int n, int k, uint64_t* key, int move, int player, int* won) {
+  const Variant var = pick_variant(kind, n);
+  const GameParams gp = make_gp(kind, n, k);
+  if (player != 0 && player != 1) return fail(CARO_E_INVAL, "player must be 0 or 1");
+  if (move < 0 || move >= gp.A) return fail(CARO_E_INVAL, "move out of range");
+  HOST_DISPATCH(var, {
+    typename GEO::R::Board b;
+    for (int i = 0; i < GEO::KW; ++i) b.w[i] = key[i];
+    if (kind == CARO_GAME_CONNECT4 && !GEO::R::legal(gp, b, move)) return fail(CARO_E_INVAL, "column is full");
+    *won = GEO::R::move(gp, b, move, player) ? 1 : 0;
+    for (int i = 0; i < GEO::KW; ++i) key[i] = b.w[i];
+  });
+  return 0;
+}
+int caro_host_legal(int kind, int n, int k, const uint64_t* key, uint8_t* legal) {
+  const Variant var = pick_variant(kind, n);
+  const GameParams gp = make_gp(kind, n, k);
+  HOST_DISPATCH(var, {
+    typename GEO::R::Board b;
+    for (int i = 0; i < GEO::KW; ++i) b.w[i] = key[i];
+    for (int a = 0; a < gp.A; ++a) legal[a] = GEO::R::legal(gp, b, a) ? 1 : 0;
+  });
+  return 0;
+}
+int caro_host_encode(int kind, int n, int k, const uint64_t* key, int who, float* planes) {
+  const Variant var = pick_variant(kind, n);
+  const GameParams gp = make_gp(kind, n, k);
+  const int HW = gp.rows * gp.cols;
+  HOST_DISPATCH(var, {
+    typename GEO::R::Board b;
+    for (int i = 0; i < GEO::KW; ++i) b.w[i] = key[i];
+    for (int i = 0; i < 2 * HW; ++i) planes[i] = GEO::R::plane(gp, b, who, i / HW, i % HW);
+  });
+  return 0;
+}
+int caro_host_noise_row(uint64_t seed, uint64_t uid, uint32_t ply, uint32_t sim, int A, double alpha, double* out) {
+  if (A < 1 || A > 256) return fail(CARO_E_INVAL, "A out of range");
+  double tmp[256];
+  caro_noise_row(seed, uid, ply, sim, A, alpha, out, tmp);
+  return 0;
+}
+double caro_host_move_uniform(uint64_t seed, uint64_t uid, uint32_t ply) { return caro_move_uniform(seed, uid, ply); }
+
+// ---- batched rules
+int caro_rules_move_batch(int kind, int n, int k, int64_t M, uint64_t* keys, const int32_t* moves,
+                          const int32_t* players, int32_t* won, int32_t* full, void* stream) {
+  const Variant var = pick_variant(kind, n);
+  const GameParams gp = make_gp(kind, n, k);
+  if (M <= 0) return 0;
+  const unsigned grid = (unsigned)((M + 255) / 256);
+  DISPATCH(var, hipLaunchKernelGGL(k_rules_move<GEO>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gp,
+                                   (long long)M, keys, moves, players, won, full));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int caro_rules_legal_batch(int kind, int n, int k, int64_t M, const uint64_t* keys, uint8_t* legal, void* stream) {
+  const Variant var = pick_variant(kind, n);
+  const GameParams gp = make_gp(kind, n, k);
+  if (M <= 0) return 0;
+  const unsigned grid = (unsigned)((M * gp.A + 255) / 256);
+  DISPATCH(var, hipLaunchKernelGGL(k_rules_legal<GEO>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gp,
+                                   (long long)M, keys, legal));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int caro_rules_encode_batch(int kind, int n, int k, int64_t M, const uint64_t* keys, const int32_t* who,
+                            float* planes, void* stream) {
+  const Variant var = pick_variant(kind, n);
+  const GameParams gp = make_gp(kind, n, k);
+  if (M <= 0) return 0;
+  const unsigned grid = (unsigned)((M * 2 * gp.rows * gp.cols + 255) / 256);
+  DISPATCH(var, hipLaunchKernelGGL(k_rules_encode<GEO>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gp,
+                                   (long long)M, keys, who, planes));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int caro_noise_batch(uint64_t seed, int64_t M, int A, double alpha, const uint64_t* uid, const uint32_t* ply,
+                     const uint32_t* sim, double* out, void* stream) {
+  if (M <= 0) return 0;
+  // same lane geometry the select kernel uses for this action count
+  Variant var = A == 7 ? V_C4 : A <= 16 ? V_M16 : A <= 32 ? V_M32 : A <= 64 ? V_M64 : A <= 128 ? V_M128 : V_M256;
+  if (A > 256) return fail(CARO_E_INVAL, "A out of range");
+  const int lpd = variant_lpd(var);
+  const int per_block = 64 / lpd;
+  const unsigned grid = (unsigned)((M + per_block - 1) / per_block);
+  DISPATCH(var, hipLaunchKernelGGL(k_noise<GEO>, dim3(grid), dim3(64), 0, (hipStream_t)stream, seed, (long long)M, A,
+                                   alpha, uid, ply, sim, out));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- engine
+int caro_engine_create(const caro_config* cfg, caro_engine** out) {
+  if (!cfg || !out) return fail(CARO_E_INVAL, "null argument");
+  const Variant var = pick_variant(cfg->game_kind, cfg->n);
+  if (var == V_BAD) return fail(CARO_E_INVAL, "unsupported game (connect four, or m,n,k with 2 <= n <= 15)");
+  if (cfg->n_games < 1) return fail(CARO_E_INVAL, "n_games must be >= 1");
+  if (cfg->n_stores != 1 && cfg->n_stores != 2) return fail(CARO_E_INVAL, "n_stores must be 1 or 2");
+  if (cfg->n_nets != 1 && cfg->n_nets != 2) return fail(CARO_E_INVAL, "n_nets must be 1 or 2");
+  const int lpd = variant_lpd(var);
+  if (cfg->max_batch < 1 || cfg->max_batch > MAXB || cfg->max_batch * lpd > 1024)
+    return fail(CARO_E_INVAL, "max_batch out of range for this game (batch * lanes-per-descent <= 1024, batch <= 64)");
+  if (cfg->game_kind == CARO_GAME_MNK && (cfg->k < 2 || cfg->k > cfg->n))
+    return fail(CARO_E_INVAL, "k must satisfy 2 <= k <= n");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(CARO_E_NODEV, "no HIP device: libcaro_hip needs a GPU (there is no CPU fallback)");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(CARO_E_INVAL, "device_id out of range");
+  HIPCHK(hipSetDevice(cfg->device_id));
+
+  caro_engine* h = new caro_engine();
+  h->cfg = *cfg;
+  h->var = var;
+  h->select_pending = 0;
+  View& v = h->v;
+  memset(&v, 0, sizeof v);
+  v.gp = make_gp(cfg->game_kind, cfg->n, cfg->k);
+  v.G = cfg->n_games;
+  v.n_stores = cfg->n_stores;
+  v.n_nets = cfg->n_nets;
+  v.A = v.gp.A;
+  v.HW = v.gp.rows * v.gp.cols;
+  v.maxply = v.HW;
+  v.maxd = v.HW;
+  v.maxB = cfg->max_batch;
+  v.sbt0 = cfg->steps_before_tau_0;
+  v.first_mode = cfg->first_player_mode;
+  v.c_puct = cfg->c_puct;
+  v.alpha = cfg->alpha;
+  v.explore = cfg->explore;
+  v.seed = cfg->seed;
+  v.uid_base = cfg->uid_base;
+  v.uid_stride = cfg->uid_stride ? cfg->uid_stride : (uint64_t)cfg->n_games;
+  v.cap = cfg->node_cap > 0 ? cfg->node_cap : 4096;
+  int hc = 64;
+  while (hc < 2 * v.cap) hc <<= 1;
+  v.hcap = hc;
+  const int KW = variant_kw(var), AP = variant_ap(var);
+  const size_t T = (size_t)v.G * v.n_stores, G = (size_t)v.G;
+  int rc = 0;
+#define DA(p, n) if ((rc = dalloc(h, &p, (n))) != 0) { caro_engine_destroy(h); return rc; }
+  DA(v.slots, T * v.hcap);
+  DA(v.node_key, T * v.cap * KW);
+  DA(v.edges, T * v.cap * 4 * AP);
+  DA(v.n_nodes, T);
+  DA(v.n_created, T);
+  DA(v.root, G * KW);
+  DA(v.player, G); DA(v.ply, G); DA(v.step, G); DA(v.uid, G); DA(v.done, G); DA(v.result, G); DA(v.final_r, G);
+  DA(v.first, G);
+  DA(v.h_key, G * v.maxply * KW);
+  DA(v.h_player, G * v.maxply);
+  DA(v.h_pi, G * v.maxply * v.A);
+  DA(v.path_node, G * v.maxB * v.maxd);
+  DA(v.path_act, G * v.maxB * v.maxd);
+  DA(v.path_len, G * v.maxB);
+  DA(v.d_status, G * v.maxB); DA(v.d_value, G * v.maxB); DA(v.d_local, G * v.maxB); DA(v.d_player, G * v.maxB);
+  DA(v.d_key, G * v.maxB * KW);
+  DA(v.g_nleaf, G); DA(v.g_off, G); DA(v.g_tree, G); DA(v.g_class, G);
+  DA(v.leaf_count, 4);
+  DA(v.counters, C_N);
+  DA(v.dr_off, G); DA(v.dr_gidx, G); DA(v.dr_sel, G); DA(v.dr_tot, 2);
+  DA(h->scratch, (size_t)v.maxd + 8);
+  DA(h->live, 1);
+#undef DA
+  HIPCHK(hipMemset(v.counters, 0, sizeof(unsigned long long) * C_N));
+  HIPCHK(hipMemset(v.leaf_count, 0, sizeof(int32_t) * 4));
+  HIPCHK(hipMemset(v.g_nleaf, 0, sizeof(int32_t) * G));
+  HIPCHK(hipHostMalloc((void**)&h->pinned, 64, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&h->pinned64, 128, hipHostMallocDefault));
+  *out = h;
+  rc = caro_reset_games(h, nullptr, nullptr);
+  if (rc) { caro_engine_destroy(h); *out = nullptr; return rc; }
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+
+void caro_engine_destroy(caro_engine* h) {
+  if (!h) return;
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->pinned64) (void)hipHostFree(h->pinned64);
+  delete h;
+}
+
+int caro_reset_games(caro_engine* h, const int32_t* first_player_dev, void* stream) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  DISPATCH(h->var, hipLaunchKernelGGL(k_reset<GEO>, dim3(h->v.G), dim3(256), 0, (hipStream_t)stream, h->v,
+                                      first_player_dev));
+  HIPCHK(hipGetLastError());
+  h->select_pending = 0;
+  return 0;
+}
+
+int caro_set_roots(caro_engine* h, const uint64_t* keys, const int32_t* players, void* stream) {
+  if (!h || !keys || !players) return fail(CARO_E_INVAL, "null argument");
+  DISPATCH(h->var, hipLaunchKernelGGL(k_set_roots<GEO>, dim3((h->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                                      h->v, keys, players));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int caro_select(caro_engine* h, int batch, int mb_index, const double* noise, float* planes, uint64_t* leaf_keys,
+                void* stream) {
+  if (!h || !planes) return fail(CARO_E_INVAL, "null argument");
+  if (batch < 1 || batch > h->v.maxB) return fail(CARO_E_INVAL, "batch exceeds max_batch of the engine");
+  if (h->select_pending) return fail(CARO_E_STATE, "caro_select called twice without caro_expand_backup");
+  const int lpd = variant_lpd(h->var);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(h->var, {
+    hipLaunchKernelGGL(k_select<GEO>, dim3(h->v.G), dim3(batch * lpd), 0, st, h->v, batch, mb_index, noise);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, h->v, batch);
+    hipLaunchKernelGGL(k_encode<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, planes, leaf_keys);
+  });
+  HIPCHK(hipGetLastError());
+  h->select_pending = 1;
+  return 0;
+}
+
+int caro_leaf_counts(caro_engine* h, int32_t counts[2], void* stream) {
+  if (!h || !counts) return fail(CARO_E_INVAL, "null argument");
+  HIPCHK(hipMemcpyAsync(h->pinned, h->v.leaf_count, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  counts[0] = h->pinned[0];
+  counts[1] = h->pinned[1];
+  return 0;
+}
+
+int caro_expand_backup(caro_engine* h, const float* probs, const float* values, void* stream) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  if (!h->select_pending) return fail(CARO_E_STATE, "caro_expand_backup without a pending caro_select");
+  DISPATCH(h->var, hipLaunchKernelGGL(k_expand_backup<GEO>, dim3(h->v.G), dim3(64), 0, (hipStream_t)stream, h->v,
+                                      probs, values));
+  HIPCHK(hipGetLastError());
+  h->select_pending = 0;
+  return 0;
+}
+
+int caro_policy(caro_engine* h, double* pi, int32_t* counts, void* stream) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  DISPATCH(h->var, hipLaunchKernelGGL(k_policy<GEO>, dim3(h->v.G), dim3(64), 0, (hipStream_t)stream, h->v, pi, counts));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int caro_step(caro_engine* h, const double* uniforms, int32_t* actions, int32_t* done, int32_t* result, void* stream) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  if (h->select_pending) return fail(CARO_E_STATE, "caro_step with a pending caro_select");
+  DISPATCH(h->var, hipLaunchKernelGGL(k_step<GEO>, dim3(h->v.G), dim3(64), 0, (hipStream_t)stream, h->v, uniforms,
+                                      actions, done, result));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int caro_drain_tuples(caro_engine* h, int64_t cap, uint64_t* states, int32_t* players, double* pi, int32_t* z,
+                      int64_t* games, int recycle, int64_t* n_tuples, int64_t* n_games, void* stream) {
+  if (!h || !states || !players || !pi || !z || !n_tuples || !n_games) return fail(CARO_E_INVAL, "null argument");
+  if (h->select_pending) return fail(CARO_E_STATE, "caro_drain_tuples with a pending caro_select");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_drain_scan, dim3(1), dim3(1024), 0, st, h->v, (long long)cap);
+  DISPATCH(h->var, hipLaunchKernelGGL(k_drain_copy<GEO>, dim3(h->v.G), dim3(256), 0, st, h->v, states, players, pi, z,
+                                      games, recycle));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h->pinned64, h->v.dr_tot, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *n_tuples = h->pinned64[0];
+  *n_games = h->pinned64[1];
+  return 0;
+}
+
+int caro_counters(caro_engine* h, int64_t counters[8], void* stream) {
+  if (!h || !counters) return fail(CARO_E_INVAL, "null argument");
+  HIPCHK(hipMemcpyAsync(h->pinned64, h->v.counters, C_N * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  for (int i = 0; i < 8; ++i) counters[i] = i < C_N ? h->pinned64[i] : 0;
+  return 0;
+}
+
+int caro_live_games(caro_engine* h, int32_t* live, void* stream) {
+  if (!h || !live) return fail(CARO_E_INVAL, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(h->live, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_count_live, dim3(1), dim3(256), 0, st, h->v, h->live);
+  HIPCHK(hipMemcpyAsync(h->pinned + 4, h->live, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *live = h->pinned[4];
+  return 0;
+}
+
+int caro_tree_sizes(caro_engine* h, int32_t* out, void* stream) {
+  if (!h || !out) return fail(CARO_E_INVAL, "null argument");
+  const int T = h->v.G * h->v.n_stores;
+  hipLaunchKernelGGL(k_tree_sizes, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->v, out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int caro_lookup_nodes(caro_engine* h, int64_t M, const int32_t* game, const int32_t* store, const uint64_t* keys,
+                      int32_t* found, int32_t* N, float* W, float* Q, float* P, int32_t* strong, void* stream) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  if (M <= 0) return 0;
+  DISPATCH(h->var, hipLaunchKernelGGL(k_lookup<GEO>, dim3((unsigned)M), dim3(64), 0, (hipStream_t)stream, h->v,
+                                      (long long)M, game, store, keys, found, N, W, Q, P, strong));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int caro_get_roots(caro_engine* h, uint64_t* keys, int32_t* players, int32_t* ply, uint64_t* uid, void* stream) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  DISPATCH(h->var, hipLaunchKernelGGL(k_get_roots<GEO>, dim3((h->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                                      h->v, keys, players, ply, uid));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int caro_poke_nodes(caro_engine* h, int64_t M, const int32_t* game, const int32_t* store, const uint64_t* keys,
+                    const int32_t* N, const float* W, const float* Q, const float* P, const int32_t* strong,
+                    void* stream) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  if (M <= 0) return 0;
+  DISPATCH(h->var, hipLaunchKernelGGL(k_poke<GEO>, dim3(1), dim3(64), 0, (hipStream_t)stream, h->v, (long long)M, game,
+                                      store, keys, N, W, Q, P, strong));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int caro_backup_path(caro_engine* h, int game, int store, float value, int value_is_f32, int len,
+                     const uint64_t* keys, const int32_t* actions, void* stream) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  if (len < 0 || len > h->v.maxd) return fail(CARO_E_INVAL, "path too long");
+  if (game < 0 || game >= h->v.G || store < 0 || store >= h->v.n_stores) return fail(CARO_E_INVAL, "bad tree index");
+  if (len == 0) return 0;
+  DISPATCH(h->var, hipLaunchKernelGGL(k_backup_one<GEO>, dim3(1), dim3(64), 0, (hipStream_t)stream, h->v, game, store,
+                                      value, value_is_f32, len, keys, actions, h->scratch));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int caro_dump_tree(caro_engine* h, int game, int store, int64_t cap, uint64_t* keys, int32_t* N, float* W, float* Q,
+                   float* P, int32_t* strong, int64_t* n_nodes, void* stream) {
+  if (!h || !n_nodes) return fail(CARO_E_INVAL, "null argument");
+  if (game < 0 || game >= h->v.G || store < 0 || store >= h->v.n_stores) return fail(CARO_E_INVAL, "bad tree index");
+  hipStream_t st = (hipStream_t)stream;
+  const int t = game * h->v.n_stores + store;
+  HIPCHK(hipMemcpyAsync(h->pinned + 5, h->v.n_nodes + t, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int nn = h->pinned[5];
+  *n_nodes = nn;
+  if (nn == 0 || cap <= 0 || !keys) return 0;
+  const unsigned grid = (unsigned)(nn < cap ? nn : cap);
+  DISPATCH(h->var, hipLaunchKernelGGL(k_dump<GEO>, dim3(grid), dim3(64), 0, st, h->v, game, store, (long long)cap, keys,
+                                      N, W, Q, P, strong));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,255 @@
+"""Host driver of the HIP self-play engine: G concurrent `play_game`s on one GPU.
+
+The loop below is the reference's lib/utils.py:76-99 + lib/mcts.py:162-176,
+248-287 turned inside out: instead of one game calling the net with <= 8 rows,
+every phase runs for all G games at once,
+
+    for each move:
+        for mb in range(mcts_searches):           # search_batch
+            select       (HIP)   G x batch descents, unique leaves -> dense planes
+            net forward  (torch) one batch of L0 (+ L1) rows      [lib/model.py]
+            expand+backup(HIP)
+        step             (HIP)   pi, sample, game.move, win/draw, history
+        drain            (HIP)   finished games -> (s, player, pi, z) tuples, slots recycled
+
+PyTorch is used for device memory, streams and the conv net only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from caro_ai_amd import _lib
+from caro_ai_amd import config as cfg
+
+COUNTER_NAMES = ["sims", "levels", "expansions", "terminals", "dropped", "overflows", "plies", "finished"]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def torch_evaluator(net):
+    """leaf planes -> (P float32[L,A] softmaxed, v float32[L]); mcts.py:212-218 on the device."""
+    net.eval()
+
+    @torch.no_grad()
+    def fn(planes):
+        logits, values = net(planes)
+        return torch.softmax(logits.float(), dim=1).contiguous(), values.float().reshape(-1).contiguous()
+
+    return fn
+
+
+class SelfPlayEngine:
+    def __init__(self, game, n_games, net1=None, net2=None, evaluators=None, n_stores=1, max_batch=None,
+                 node_cap=None, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, first_player_mode=2,
+                 c_puct=cfg.C_PUCT, alpha=cfg.ALPHA, explore=cfg.EXPLORE, seed=0, uid_base=0, uid_stride=None,
+                 device="cuda:0", searches_hint=cfg.MCTS_SEARCHES):
+        if not torch.cuda.is_available():
+            raise _lib.CaroError("SelfPlayEngine needs a GPU (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+        self.L = _lib.load()
+        self.game = game
+        self.device = torch.device(device)
+        self.G = int(n_games)
+        self.A = game.action_space
+        self.KW = game.key_words
+        self.obs_shape = tuple(game.obs_shape)
+        self.HW = self.obs_shape[1] * self.obs_shape[2]
+        self.max_batch = int(max_batch or cfg.MCTS_BATCH_SIZE)
+        if evaluators is None:
+            nets = [net1] if net2 is None or net2 is net1 else [net1, net2]
+            evaluators = [torch_evaluator(n.to(self.device)) for n in nets]
+        self.evaluators = list(evaluators)
+        self.n_nets = len(self.evaluators)
+        assert self.n_nets in (1, 2)
+        if node_cap is None:
+            node_cap = min(int(searches_hint) * self.max_batch * self.HW + 64, 1 << 16)
+        c = _lib.CaroConfig()
+        c.game_kind, c.n, c.k = game.kind, game.n, game.k
+        c.n_games, c.n_stores, c.n_nets = self.G, n_stores, self.n_nets
+        c.max_batch, c.node_cap = self.max_batch, int(node_cap)
+        c.steps_before_tau_0, c.first_player_mode = steps_before_tau_0, first_player_mode
+        c.c_puct, c.alpha, c.explore = c_puct, alpha, explore
+        c.seed, c.uid_base = seed, uid_base
+        c.uid_stride = uid_stride if uid_stride is not None else self.G
+        c.device_id = self.device.index or 0
+        self.cfg = c
+        self.n_stores = n_stores
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        _lib.check(self.L.caro_engine_create(C.byref(c), C.byref(h)))
+        self.h = h
+        rows = self.G * self.max_batch
+        self.planes = torch.zeros((rows,) + self.obs_shape, dtype=torch.float32, device=self.device)
+        self.leaf_keys = torch.zeros((rows, self.KW), dtype=torch.int64, device=self.device)
+        self._probs = torch.zeros((rows, self.A), dtype=torch.float32, device=self.device)
+        self._values = torch.zeros(rows, dtype=torch.float32, device=self.device)
+        self._counts = (C.c_int32 * 2)()
+        self.maxply = self.HW
+        self.net_rows = 0
+        self.net_calls = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.caro_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------ phases
+    def reset(self, first_players=None):
+        fp = None
+        if first_players is not None:
+            fp = torch.as_tensor(first_players, dtype=torch.int32).to(self.device).contiguous()
+        _lib.check(self.L.caro_reset_games(self.h, _ptr(fp), self._stream()))
+        if fp is not None:
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def set_roots(self, states, players):
+        keys = torch.from_numpy(self.game.to_keys(states).view(np.int64)).to(self.device)
+        pl = torch.as_tensor(players, dtype=torch.int32).to(self.device)
+        _lib.check(self.L.caro_set_roots(self.h, _ptr(keys), _ptr(pl), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def minibatch(self, batch, mb_index, noise=None):
+        """one search_minibatch for all games; returns (L0, L1)"""
+        st = self._stream()
+        nz = None
+        if noise is not None:
+            nz = noise if torch.is_tensor(noise) else torch.as_tensor(np.asarray(noise, dtype=np.float64))
+            nz = nz.to(self.device, dtype=torch.float64).contiguous()
+            assert nz.numel() == self.G * batch * self.A
+        _lib.check(self.L.caro_select(self.h, batch, mb_index, _ptr(nz), _ptr(self.planes), _ptr(self.leaf_keys), st))
+        _lib.check(self.L.caro_leaf_counts(self.h, self._counts, st))
+        l0, l1 = self._counts[0], self._counts[1]
+        if l0:
+            p, v = self.evaluators[0](self.planes[:l0])
+            self._probs[:l0].copy_(p)
+            self._values[:l0].copy_(v)
+        if l1:
+            p, v = self.evaluators[1](self.planes[l0:l0 + l1])
+            self._probs[l0:l0 + l1].copy_(p)
+            self._values[l0:l0 + l1].copy_(v)
+        self.net_rows += l0 + l1
+        self.net_calls += (l0 > 0) + (l1 > 0)
+        _lib.check(self.L.caro_expand_backup(self.h, _ptr(self._probs), _ptr(self._values), st))
+        return l0, l1
+
+    def search(self, searches, batch, noise=None):
+        """search_batch (mcts.py:162-176) for all games. noise: optional [searches, G, batch, A] rows."""
+        for mb in range(searches):
+            self.minibatch(batch, mb, None if noise is None else noise[mb])
+
+    def policy(self):
+        pi = torch.empty((self.G, self.A), dtype=torch.float64, device=self.device)
+        counts = torch.empty((self.G, self.A), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.caro_policy(self.h, _ptr(pi), _ptr(counts), self._stream()))
+        return pi, counts
+
+    def step(self, uniforms=None):
+        u = None
+        if uniforms is not None:
+            u = torch.as_tensor(np.asarray(uniforms, dtype=np.float64)).to(self.device).contiguous()
+        actions = torch.empty(self.G, dtype=torch.int32, device=self.device)
+        done = torch.empty(self.G, dtype=torch.int32, device=self.device)
+        result = torch.empty(self.G, dtype=torch.int32, device=self.device)
+        _lib.check(self.L.caro_step(self.h, _ptr(u), _ptr(actions), _ptr(done), _ptr(result), self._stream()))
+        return actions, done, result
+
+    def drain(self, recycle=True, cap=None):
+        """Finished games -> tuples (device tensors), in the reference's append order."""
+        cap = int(cap or self.G * self.maxply)
+        if not hasattr(self, "_dr") or self._dr[0].shape[0] < cap:
+            dev = self.device
+            self._dr = (torch.empty((cap, self.KW), dtype=torch.int64, device=dev),
+                        torch.empty(cap, dtype=torch.int32, device=dev),
+                        torch.empty((cap, self.A), dtype=torch.float64, device=dev),
+                        torch.empty(cap, dtype=torch.int32, device=dev),
+                        torch.empty((self.G, 4), dtype=torch.int64, device=dev))
+        s, p, pi, z, games = self._dr
+        nt, ng = C.c_int64(0), C.c_int64(0)
+        _lib.check(self.L.caro_drain_tuples(self.h, cap, _ptr(s), _ptr(p), _ptr(pi), _ptr(z), _ptr(games),
+                                            1 if recycle else 0, C.addressof(nt), C.addressof(ng), self._stream()))
+        nt, ng = nt.value, ng.value
+        return {"states": s[:nt], "players": p[:nt], "pi": pi[:nt], "z": z[:nt], "games": games[:ng]}
+
+    # ------------------------------------------------------------ inspection
+    def counters(self):
+        out = (C.c_int64 * 8)()
+        _lib.check(self.L.caro_counters(self.h, out, self._stream()))
+        return dict(zip(COUNTER_NAMES, list(out)))
+
+    def live_games(self):
+        out = C.c_int32(0)
+        _lib.check(self.L.caro_live_games(self.h, C.addressof(out), self._stream()))
+        return out.value
+
+    def tree_sizes(self):
+        out = torch.empty(self.G * self.n_stores, dtype=torch.int32, device=self.device)
+        _lib.check(self.L.caro_tree_sizes(self.h, _ptr(out), self._stream()))
+        return out.cpu().numpy().reshape(self.G, self.n_stores)
+
+    def roots(self):
+        keys = torch.empty((self.G, self.KW), dtype=torch.int64, device=self.device)
+        pl = torch.empty(self.G, dtype=torch.int32, device=self.device)
+        ply = torch.empty(self.G, dtype=torch.int32, device=self.device)
+        uid = torch.empty(self.G, dtype=torch.int64, device=self.device)
+        _lib.check(self.L.caro_get_roots(self.h, _ptr(keys), _ptr(pl), _ptr(ply), _ptr(uid), self._stream()))
+        return (keys.cpu().numpy().view(np.uint64), pl.cpu().numpy(), ply.cpu().numpy(),
+                uid.cpu().numpy().view(np.uint64))
+
+    def lookup(self, games, stores, states):
+        """node rows of (game, store, state) triples -> dict of numpy arrays"""
+        M = len(states)
+        dev = self.device
+        g = torch.as_tensor(games, dtype=torch.int32).to(dev)
+        s = torch.as_tensor(stores, dtype=torch.int32).to(dev)
+        keys = torch.from_numpy(self.game.to_keys(states).view(np.int64)).to(dev)
+        found = torch.zeros(M, dtype=torch.int32, device=dev)
+        N = torch.zeros((M, self.A), dtype=torch.int32, device=dev)
+        strong = torch.zeros((M, self.A), dtype=torch.int32, device=dev)
+        W = torch.zeros((M, self.A), dtype=torch.float32, device=dev)
+        Q = torch.zeros_like(W)
+        P = torch.zeros_like(W)
+        _lib.check(self.L.caro_lookup_nodes(self.h, M, _ptr(g), _ptr(s), _ptr(keys), _ptr(found), _ptr(N), _ptr(W),
+                                            _ptr(Q), _ptr(P), _ptr(strong), self._stream()))
+        return {"found": found.cpu().numpy(), "N": N.cpu().numpy(), "W": W.cpu().numpy(), "Q": Q.cpu().numpy(),
+                "P": P.cpu().numpy(), "strong": strong.cpu().numpy()}
+
+    # ------------------------------------------------------------ whole games
+    def play_until(self, searches, batch, n_finished=None, max_moves=None, recycle=True, on_tuples=None):
+        """Run move steps until `n_finished` games have been drained (or `max_moves`).
+        Returns (list of tuple dicts on the host unless on_tuples consumes them, game records int64[n,4])."""
+        out, games = [], []
+        finished = 0
+        moves = 0
+        while True:
+            self.search(searches, batch)
+            self.step()
+            moves += 1
+            d = self.drain(recycle=recycle)
+            ng = d["games"].shape[0]
+            if ng:
+                finished += ng
+                games.append(d["games"].cpu().numpy().copy())
+                if on_tuples is not None:
+                    on_tuples(d)
+                else:
+                    out.append({k: v.cpu().numpy().copy() for k, v in d.items() if k != "games"})
+            if n_finished is not None and finished >= n_finished:
+                break
+            if max_moves is not None and moves >= max_moves:
+                break
+            if not recycle and self.live_games() == 0:
+                break
+        games = np.concatenate(games) if games else np.zeros((0, 4), np.int64)
+        return out, games

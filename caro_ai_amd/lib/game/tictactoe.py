@@ -1,0 +1,69 @@
+"""n x n, k-in-a-row game behind the reference's `TicTacToe` interface
+(lib/game/tictactoe/tictactoe.py:10-259).
+
+MCTS state int = the reference's base-10 digit string (0/1 tokens, 2 empty,
+row-major from the top left, :14-24), arbitrary precision for n > 4.  The
+engine's packed form is two bit-planes (token 0, token 1) of n*n bits."""
+import numpy as np
+
+from caro_ai_amd import _lib
+from caro_ai_amd.lib.game._packed import PackedGame
+
+
+class TicTacToe(PackedGame):
+    kind = _lib.GAME_MNK
+
+    def __init__(self, n: int = 3, k_to_win: int = 3):
+        super().__init__()
+        self.board_len = n
+        self.k_to_win = k_to_win
+        self.n, self.k = n, k_to_win
+        self.player_black = 1
+        self.player_white = 0
+        self.empty = 2
+        self._setup()
+        self._w64 = self.key_words // 2
+
+    @property
+    def obs_shape(self):
+        return (2, self.board_len, self.board_len)
+
+    def _digits(self, state_int):
+        s = str(int(state_int)).rjust(self._cells, "0")  # leading zeros are tokens of player 0 (:88-100)
+        return np.frombuffer(s.encode(), dtype=np.uint8) - ord("0")
+
+    def to_key(self, state_int):
+        d = self._digits(state_int)
+        key = np.zeros(self.key_words, dtype=np.uint64)
+        for plane in (0, 1):
+            for i in np.flatnonzero(d == plane):
+                key[plane * self._w64 + (int(i) >> 6)] |= np.uint64(1 << (int(i) & 63))
+        return key
+
+    def from_key(self, key):
+        key = [int(x) for x in np.asarray(key, dtype=np.uint64).reshape(-1)]
+        digits = []
+        for i in range(self._cells):
+            w, b = i >> 6, i & 63
+            if (key[w] >> b) & 1:
+                digits.append("0")
+            elif (key[self._w64 + w] >> b) & 1:
+                digits.append("1")
+            else:
+                digits.append("2")
+        return int("".join(digits))
+
+    def move(self, mcts_state, move, player):
+        assert player == self.player_white or player == self.player_black
+        assert 0 <= move < self.action_space
+        return self._move_key(mcts_state, move, player)
+
+    def render(self, mcts_state):
+        d = self._digits(mcts_state)
+        sym = {0: "X", 1: "O"}
+        rows = []
+        for r in range(self.board_len):
+            cells = [sym.get(int(d[r * self.board_len + c]), str(r * self.board_len + c))
+                     for c in range(self.board_len)]
+            rows.append("|" + "|".join(cells) + "|")
+        return "\n".join(rows)

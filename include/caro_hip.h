@@ -1,0 +1,185 @@
+/*
+ * caro_hip.h -- C-ABI of libcaro_hip.so, the MI355X (gfx950) self-play engine.
+ *
+ * The reference (nh273/caro-ai) is pure Python: the path this library replaces
+ * sits behind a Python plugin API, not an FFI.  Each entry point below names
+ * the reference interface it stands in for (paths relative to the reference
+ * tree).  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add (it is what caro_ai_amd/_lib.py does).
+ *
+ * Conventions
+ *   - plain C types only; every `*_dev` pointer is DEVICE memory owned by the
+ *     caller (e.g. a torch tensor's data_ptr()) on the engine's device;
+ *     `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     Calls enqueue work on `stream` and return without synchronising unless
+ *     the comment says otherwise.
+ *   - return value: 0 on success, negative CARO_E_* code on failure;
+ *     caro_last_error() returns a message for the calling thread.
+ *   - no internal threads; one engine per (process, GPU).
+ *
+ * Board states ("keys"), KW = caro_key_words() 64-bit words per board:
+ *   connect four: KW = 1, the reference's own 63-bit state int
+ *                 (lib/game/connect_four/connect_four.py:36-56).
+ *   m,n,k       : KW = 2*W64, W64 = 1 (n<=8), 2 (n<=11), 4 (n<=15);
+ *                 words [0,W64) = bit-plane of token 0, [W64,2*W64) = token 1,
+ *                 bit i = square i of lib/game/tictactoe/tictactoe.py:14-24.
+ */
+#ifndef CARO_HIP_H
+#define CARO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CARO_GAME_CONNECT4 0
+#define CARO_GAME_MNK 1
+
+#define CARO_E_INVAL (-22)   /* bad argument */
+#define CARO_E_NOMEM (-12)   /* allocation failed */
+#define CARO_E_HIP (-5)      /* HIP runtime error */
+#define CARO_E_NODEV (-19)   /* no usable GPU */
+#define CARO_E_STATE (-71)   /* call sequence violated */
+
+typedef struct caro_engine caro_engine;
+
+typedef struct caro_config {
+  int32_t game_kind;          /* CARO_GAME_* */
+  int32_t n, k;               /* m,n,k board side and run length (TicTacToe(n, k_to_win), tictactoe.py:27) */
+  int32_t n_games;            /* G concurrent games on this GPU */
+  int32_t n_stores;           /* 1: one tree per game shared by both players (utils.py:60-61);
+                                 2: one tree per player (utils.py:58-59, play.py:47) */
+  int32_t n_nets;             /* 1: self-play; 2: player p's leaves go to net p (utils.py:64,77-79) */
+  int32_t max_batch;          /* largest mcts_batch_size that will be used */
+  int32_t node_cap;           /* nodes per tree; 0 = searches_hint * max_batch * max plies bound */
+  int32_t steps_before_tau_0; /* utils.py:70,97-99 */
+  int32_t first_player_mode;  /* 0: all games start with player 0; 1: player 1; 2: game uid & 1 */
+  float c_puct;               /* config.C_PUCT */
+  double alpha, explore;      /* config.ALPHA, config.EXPLORE */
+  uint64_t seed;              /* key of the generated noise / move uniforms (caro_noise.h) */
+  uint64_t uid_base;          /* uid of this engine's game 0 (rank offset in multi-GPU runs) */
+  uint64_t uid_stride;        /* uid += uid_stride each time a game slot is recycled (total games in flight) */
+  int32_t device_id;
+  int32_t reserved;
+} caro_config;
+
+const char* caro_last_error(void);
+int caro_version(void);
+
+/* ---- geometry of a game kind (host only, no GPU needed) ---- */
+int caro_key_words(int game_kind, int n);                    /* KW */
+int caro_action_space(int game_kind, int n);                 /* BaseGame.action_space */
+int caro_obs_cells(int game_kind, int n);                    /* H*W of BaseGame.obs_shape */
+
+/* ---- host-side single-state rule helpers (API-edge use by the BaseGame shim;
+ *      compiled from the same caro_rules.h as the kernels; no GPU needed) ---- */
+/* BaseGame.initial_state (connect_four.py:67-74, tictactoe.py:56-63) */
+int caro_host_initial(int game_kind, int n, int k, uint64_t* key);
+/* BaseGame.move (connect_four.py:241-265, tictactoe.py:210-235): key updated in place, *won set */
+int caro_host_move(int game_kind, int n, int k, uint64_t* key, int move, int player, int* won);
+/* BaseGame.possible_moves as a byte mask legal[A] (connect_four.py:157-165, tictactoe.py:137-150) */
+int caro_host_legal(int game_kind, int n, int k, const uint64_t* key, uint8_t* legal);
+/* BaseGame.states_to_training_batch for one state -> float32[2*H*W] */
+int caro_host_encode(int game_kind, int n, int k, const uint64_t* key, int who_move, float* planes);
+/* one Dirichlet row / one move uniform of the caro_noise.h spec */
+int caro_host_noise_row(uint64_t seed, uint64_t uid, uint32_t ply, uint32_t sim, int A, double alpha, double* out);
+double caro_host_move_uniform(uint64_t seed, uint64_t uid, uint32_t ply);
+
+/* ---- batched rule kernels (device) : lib/game rules over M independent boards ---- */
+/* keys_dev u64[M,KW] in/out, moves_dev i32[M], players_dev i32[M] -> won_dev i32[M], full_dev i32[M] */
+int caro_rules_move_batch(int game_kind, int n, int k, int64_t M, uint64_t* keys_dev, const int32_t* moves_dev,
+                          const int32_t* players_dev, int32_t* won_dev, int32_t* full_dev, void* stream);
+/* legal_dev u8[M,A] */
+int caro_rules_legal_batch(int game_kind, int n, int k, int64_t M, const uint64_t* keys_dev, uint8_t* legal_dev,
+                           void* stream);
+/* planes_dev f32[M,2,H,W] */
+int caro_rules_encode_batch(int game_kind, int n, int k, int64_t M, const uint64_t* keys_dev,
+                            const int32_t* who_dev, float* planes_dev, void* stream);
+/* device form of the noise spec: out_dev f64[M,A] rows keyed (seed, uid[m], ply[m], sim[m]) */
+int caro_noise_batch(uint64_t seed, int64_t M, int A, double alpha, const uint64_t* uid_dev, const uint32_t* ply_dev,
+                     const uint32_t* sim_dev, double* out_dev, void* stream);
+
+/* ---- engine: G concurrent games = G x play_game (lib/utils.py:25-108) ---- */
+/* replaces MCTS.__init__ (lib/mcts.py:27-37) for every tree of every game */
+int caro_engine_create(const caro_config* cfg, caro_engine** out);
+void caro_engine_destroy(caro_engine* h);
+/* (re)start every game from the initial position with an empty tree: utils.py:58-73 / MCTS.clear (mcts.py:39-43).
+ * first_player_dev: i32[G] or NULL (use first_player_mode). */
+int caro_reset_games(caro_engine* h, const int32_t* first_player_dev, void* stream);
+/* force game positions (tests, MCTS shim): root keys u64[G,KW], players i32[G]; trees are kept */
+int caro_set_roots(caro_engine* h, const uint64_t* keys_dev, const int32_t* players_dev, void* stream);
+
+/* One search_minibatch (lib/mcts.py:248-287), first half, for every live game:
+ * `batch` find_leaf descents per game on the frozen tree (mcts.py:97-148: root
+ * noise :48-62, PUCT :64-84, mask :86-95, first-max argmax :136, game.move :138,
+ * terminal values :140-146), de-duplication of new leaves (:272-278), and the
+ * NN planes of the unique leaves (game.states_to_training_batch) written as
+ * dense rows into planes_dev f32[>= G*batch, 2, H, W]: rows [0,L0) feed net 0,
+ * rows [L0, L0+L1) feed net 1.
+ * noise_dev: f64[G, batch, A] explicit Dirichlet rows for this minibatch, or
+ * NULL to generate them on device from (seed, uid, ply, sim = mb_index*batch + b).
+ * leaf_keys_dev (optional, may be NULL): u64[>= G*batch, KW] keys of the rows. */
+int caro_select(caro_engine* h, int batch, int mb_index, const double* noise_dev, float* planes_dev,
+                uint64_t* leaf_keys_dev, void* stream);
+/* Blocks until the select on `stream` has finished; counts[0..1] = L0, L1. */
+int caro_leaf_counts(caro_engine* h, int32_t counts[2], void* stream);
+/* Second half (mcts.py:281-287): _create_node (:178-190) for every unique leaf
+ * with prior row probs_dev f32[L, A] (softmax ALREADY applied, mcts.py:216) and
+ * _backup (:225-246) of terminals (sim order) then new leaves (first-seen
+ * order) with values_dev f32[L] (mcts.py:217). Rows are those of caro_select. */
+int caro_expand_backup(caro_engine* h, const float* probs_dev, const float* values_dev, void* stream);
+
+/* get_policy_value (lib/mcts.py:289-313) of every game's root with the tau the
+ * game is in: pi_dev f64[G, A]; counts_dev i32[G, A] (root N) optional. */
+int caro_policy(caro_engine* h, double* pi_dev, int32_t* counts_dev, void* stream);
+/* One ply of play_game for every live game (utils.py:80-99): pi, history row,
+ * np.random.choice via inverse CDF of a uniform (uniforms_dev f64[G], or NULL =
+ * generated), game.move, win / draw detection, tau switch.
+ * Optional outputs (may be NULL): actions_dev i32[G] (-1 for finished games),
+ * done_dev i32[G] (1 once the game is over), result_dev i32[G] (net1_result). */
+int caro_step(caro_engine* h, const double* uniforms_dev, int32_t* actions_dev, int32_t* done_dev,
+              int32_t* result_dev, void* stream);
+/* Replay emission (utils.py:101-106) for finished games, in game order, each
+ * game's plies last-to-first exactly as the reference appends them:
+ *   states_dev u64[cap,KW], players_dev i32[cap], pi_dev f64[cap,A], z_dev i32[cap]
+ * and one record per drained game: games_dev i64[G,4] = (uid, first_player, net1_result, steps).
+ * Drained slots restart as new games (uid += uid_stride) when `recycle` != 0,
+ * otherwise they stay finished.  Synchronises; *n_tuples / *n_games set on return. */
+int caro_drain_tuples(caro_engine* h, int64_t cap, uint64_t* states_dev, int32_t* players_dev, double* pi_dev,
+                      int32_t* z_dev, int64_t* games_dev, int recycle, int64_t* n_tuples, int64_t* n_games,
+                      void* stream);
+
+/* counters[8] (host array): sims, levels, expansions, terminals, dropped
+ * duplicates, node-pool overflows, plies, finished games.  Synchronises. */
+int caro_counters(caro_engine* h, int64_t counters[8], void* stream);
+/* number of live (unfinished) games; synchronises */
+int caro_live_games(caro_engine* h, int32_t* live, void* stream);
+
+/* ---- inspection (tests, MCTS shim: the four public dicts of lib/mcts.py:29-36) ---- */
+/* len(MCTS) per tree: out_dev i32[G*n_stores] */
+int caro_tree_sizes(caro_engine* h, int32_t* out_dev, void* stream);
+/* look up M (game, store, key) triples: found_dev i32[M]; N i32[M,A]; W,Q,P f32[M,A]; strong i32[M,A]
+ * (strong = W has absorbed a float32 net value; 0 = still an exact Python float) */
+int caro_lookup_nodes(caro_engine* h, int64_t M, const int32_t* game_dev, const int32_t* store_dev,
+                      const uint64_t* keys_dev, int32_t* found_dev, int32_t* N_dev, float* W_dev, float* Q_dev,
+                      float* P_dev, int32_t* strong_dev, void* stream);
+/* current root key / player / ply / uid of every game: keys u64[G,KW], players i32[G], ply i32[G], uid u64[G] */
+int caro_get_roots(caro_engine* h, uint64_t* keys_dev, int32_t* players_dev, int32_t* ply_dev, uint64_t* uid_dev,
+                   void* stream);
+/* insert / overwrite nodes (MCTS shim attribute setters, lib/test_mcts.py:15-21): same layout as lookup */
+int caro_poke_nodes(caro_engine* h, int64_t M, const int32_t* game_dev, const int32_t* store_dev,
+                    const uint64_t* keys_dev, const int32_t* N_dev, const float* W_dev, const float* Q_dev,
+                    const float* P_dev, const int32_t* strong_dev, void* stream);
+/* MCTS._backup (lib/mcts.py:225-246) of ONE path on one tree: keys u64[len,KW], actions i32[len] */
+int caro_backup_path(caro_engine* h, int game, int store, float value, int value_is_f32, int len,
+                     const uint64_t* keys_dev, const int32_t* actions_dev, void* stream);
+/* dump a whole tree (MCTS shim dict views): keys u64[cap,KW], N i32[cap,A], W/Q/P f32[cap,A], strong i32[cap,A];
+ * *n_nodes set on return (synchronises). */
+int caro_dump_tree(caro_engine* h, int game, int store, int64_t cap, uint64_t* keys_dev, int32_t* N_dev,
+                   float* W_dev, float* Q_dev, float* P_dev, int32_t* strong_dev, int64_t* n_nodes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARO_HIP_H */

@@ -1,0 +1,140 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every
+symbol include/caro_hip.h declares, host-side rule helpers and game shims agree
+with the reference's vectors, the torch twin of the synthetic net equals the C
+one, and the engine refuses to run without a GPU (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from caro_ai_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "caro_hip.h")).read()
+    declared = set(re.findall(r"\b(caro_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"caro_engine", "caro_config"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libcaro_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lib.caro_version() >= 100
+
+
+def test_config_struct_layout_matches_header():
+    from caro_ai_amd import _lib
+    assert C.sizeof(_lib.CaroConfig) == 96
+    assert _lib.CaroConfig.alpha.offset == 48 and _lib.CaroConfig.seed.offset == 64
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_engine_fails_loudly_without_gpu():
+    from caro_ai_amd import _lib
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    with pytest.raises(_lib.CaroError):
+        SelfPlayEngine(ConnectFour(), 4, evaluators=[lambda x: x])
+    cfg = _lib.CaroConfig()
+    cfg.game_kind, cfg.n_games, cfg.n_stores, cfg.n_nets, cfg.max_batch = 0, 4, 1, 1, 8
+    h = C.c_void_p()
+    rc = _lib.load().caro_engine_create(C.byref(cfg), C.byref(h))
+    assert rc == -19 and not h.value  # CARO_E_NODEV
+    assert b"no CPU fallback" in _lib.load().caro_last_error()
+
+
+def _game_of(d):
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    return ConnectFour() if d["kind"] == "c4" else TicTacToe(d["n"], d["k"])
+
+
+@pytest.mark.parametrize("name", ["rules_c4.json.gz", "rules_ttt3.json.gz", "rules_mnk5.json.gz",
+                                  "rules_mnk15.json.gz"])
+def test_game_shims_vs_reference_vectors(name):
+    d = load_golden(name)
+    game = _game_of(d)
+    for r in d["recs"]:
+        s = int(r["s"])
+        assert game.possible_moves(s) == r["legal"]
+        assert sorted(game.invalid_moves(s) + r["legal"]) == list(range(game.action_space))
+        s2, won = game.move(s, r["m"], r["p"])
+        assert s2 == int(r["s2"]) and won == r["won"]
+        assert game.from_key(game.to_key(s2)) == s2
+        planes = game.states_to_training_batch([s2], [1 - r["p"]])[0]
+        assert planes.dtype == np.float32 and planes.shape == tuple(game.obs_shape)
+        assert np.packbits(planes.astype(np.uint8).reshape(-1)).tobytes().hex() == r["planes"]
+
+
+def test_connect_four_known_answers_through_the_shim():
+    """lib/game/connect_four/test_connect_four.py:28-141 restated against the shim."""
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    g = ConnectFour()
+    empty = 0b000000000000000000000000000000000000000000110110110110110110110
+    full1 = 0b111111111111111111111111111111111111111111000000000000000000000
+    assert g.initial_state == empty
+    assert g.encode_lists([[]] * 7) == empty and g.encode_lists([[1] * 6] * 7) == full1
+    assert g.encode_lists([[0] * 6] * 7) == 0
+    assert g.decode_binary(empty) == [[]] * 7 and g.decode_binary(full1) == [[1] * 6] * 7
+    assert g.decode_binary(0) == [[0] * 6] * 7
+    assert g.possible_moves(0) == [] and g.possible_moves(full1) == []
+    assert g.possible_moves(empty) == [0, 1, 2, 3, 4, 5, 6]
+    f = g.encode_lists([[0, 1, 1], [1, 0], [0, 1], [0, 0, 1], [0, 0], [1, 1, 1, 0], []])
+    s, won = g.move(f, 4, 0)
+    assert won is True and s == 3531389463375529686
+    f = g.encode_lists([[0, 0, 0, 1], [0, 0, 1], [0], [1], [], [], []])
+    assert g.move(f, 2, 1)[1] is True and g.move(f, 2, 0)[1] is False
+    with pytest.raises(AssertionError):
+        g.move(full1, 0, 1)
+    with pytest.raises(AssertionError):
+        g.move(empty, 7, 1)
+    assert g.obs_shape == (2, 6, 7) and g.action_space == 7
+
+
+def test_tictactoe_known_answers_through_the_shim():
+    """lib/game/tictactoe/test_tictactoe.py:41-144 restated against the shim."""
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    g = TicTacToe(3, 3)
+    assert g.initial_state == 222222222
+    assert g.possible_moves(int("010220011")) == [3, 4]
+    assert g.invalid_moves(int("010220011")) == [0, 1, 2, 5, 6, 7, 8]
+    assert g.possible_moves(int("212220012")) == [0, 2, 3, 4, 8]
+    for board, mv, pl, exp in [("002112122", 2, 0, "000112122"), ("021012212", 6, 0, "021012012"),
+                               ("021102212", 8, 0, "021102210"), ("120122012", 4, 0, "120102012"),
+                               ("120102222", 6, 1, "120102122")]:
+        nb, won = g.move(int(board), mv, pl)
+        assert won is True and nb == int(exp)
+    b = g.states_to_training_batch([int("001010221"), int("101222001")], [1, 0])
+    np.testing.assert_equal(b[0], [[[0, 0, 1], [0, 1, 0], [0, 0, 1]], [[1, 1, 0], [1, 0, 1], [0, 0, 0]]])
+
+
+def test_host_noise_equals_oracle_noise():
+    from caro_ai_amd import _lib
+    from oracle.oracle import move_uniform, noise_row
+    L = _lib.load()
+    for A in (7, 9, 225):
+        out = np.zeros(A)
+        _lib.check(L.caro_host_noise_row(5, 77, 3, 41, A, 0.3, out.ctypes.data))
+        assert np.array_equal(out, noise_row(5, 77, 3, 41, A))
+    assert L.caro_host_move_uniform(5, 77, 3) == move_uniform(5, 77, 3)
+
+
+def test_synth_net_twins_agree():
+    """torch int64 twin (tests/synth_net.py) == C twin (oracle_synth_net) == the
+    numpy twin used when the goldens were recorded."""
+    from oracle.oracle import Oracle
+    from tests.synth_net import synth_numpy
+    rng = np.random.default_rng(0)
+    for o in (Oracle(Oracle.C4), Oracle(Oracle.MNK, 15, 5)):
+        planes = (rng.random((17, 2, o.rows, o.cols)) < 0.3).astype(np.float32)
+        P, v = synth_numpy(planes, o.A)
+        Pc = np.zeros((17, o.A), np.float32)
+        vc = np.zeros(17, np.float32)
+        o.L.oracle_synth_net.argtypes = [C.c_void_p] + [C.c_int] + [C.c_void_p] * 5
+        o.L.oracle_synth_net(o.h, 17, planes.ctypes.data, None, None, Pc.ctypes.data, vc.ctypes.data)
+        assert np.array_equal(P, Pc) and np.array_equal(v, vc)
+        assert P.min() > 0 and abs(v).max() <= 1000 / 1024

@@ -1,0 +1,293 @@
+"""GPU parity tests: the HIP engine, called through the C-ABI (libcaro_hip.so),
+against the pinned oracle and the vectors recorded from the reference.
+
+Bar: every integer (boards, actions, visit counts, z, results, counters) and
+every float64 pi bit exact with the synthetic table net; W/Q float32 bit exact.
+Run on the GPU box:  python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _game_of(d):
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    return ConnectFour() if d["kind"] == "c4" else TicTacToe(d["n"], d["k"])
+
+
+def _oracle_of(d, n_stores=1):
+    from oracle.oracle import Oracle
+    return Oracle(Oracle.C4, n_stores=n_stores) if d["kind"] == "c4" else Oracle(Oracle.MNK, d["n"], d["k"],
+                                                                                 n_stores=n_stores)
+
+
+def _synth(game):
+    from tests.synth_net import SynthNet
+    return SynthNet(2 * game.obs_shape[1] * game.obs_shape[2], game.action_space, DEV)
+
+
+def _engine(game, G, evaluators, **kw):
+    from caro_ai_amd.engine import SelfPlayEngine
+    return SelfPlayEngine(game, G, evaluators=evaluators, device=DEV, **kw)
+
+
+# ------------------------------------------------------------------ noise spec
+@pytest.mark.parametrize("A", [7, 9, 25, 64, 100, 225])
+def test_noise_device_equals_host_bits(A):
+    from caro_ai_amd import _lib
+    from oracle.oracle import noise_row
+    L = _lib.load()
+    M = 512
+    rng = np.random.default_rng(A)
+    uid = rng.integers(0, 2**62, M, dtype=np.uint64)
+    ply = rng.integers(0, 225, M).astype(np.uint32)
+    sim = rng.integers(0, 800, M).astype(np.uint32)
+    d_uid = torch.from_numpy(uid.view(np.int64)).to(DEV)
+    d_ply = torch.from_numpy(ply.view(np.int32)).to(DEV)
+    d_sim = torch.from_numpy(sim.view(np.int32)).to(DEV)
+    out = torch.zeros((M, A), dtype=torch.float64, device=DEV)
+    _lib.check(L.caro_noise_batch(12345, M, A, 0.3, d_uid.data_ptr(), d_ply.data_ptr(), d_sim.data_ptr(),
+                                  out.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    exp = np.stack([noise_row(12345, int(uid[i]), int(ply[i]), int(sim[i]), A) for i in range(M)])
+    assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
+    assert np.all(got > 0) and np.allclose(got.sum(1), 1.0, atol=1e-12)
+
+
+# ------------------------------------------------------------------ batched rules vs the reference's vectors
+@pytest.mark.parametrize("name", ["rules_c4.json.gz", "rules_ttt3.json.gz", "rules_mnk5.json.gz",
+                                  "rules_mnk15.json.gz"])
+def test_rules_kernels_vs_reference(name):
+    from caro_ai_amd import _lib
+    L = _lib.load()
+    d = load_golden(name)
+    game = _game_of(d)
+    recs = d["recs"]
+    M, A, KW = len(recs), game.action_space, game.key_words
+    HW = game.obs_shape[1] * game.obs_shape[2]
+    keys = torch.from_numpy(game.to_keys([int(r["s"]) for r in recs]).view(np.int64)).to(DEV)
+    moves = torch.tensor([r["m"] for r in recs], dtype=torch.int32, device=DEV)
+    players = torch.tensor([r["p"] for r in recs], dtype=torch.int32, device=DEV)
+    legal = torch.zeros((M, A), dtype=torch.uint8, device=DEV)
+    _lib.check(L.caro_rules_legal_batch(game.kind, game.n, game.k, M, keys.data_ptr(), legal.data_ptr(), None))
+    won = torch.zeros(M, dtype=torch.int32, device=DEV)
+    full = torch.zeros(M, dtype=torch.int32, device=DEV)
+    _lib.check(L.caro_rules_move_batch(game.kind, game.n, game.k, M, keys.data_ptr(), moves.data_ptr(),
+                                       players.data_ptr(), won.data_ptr(), full.data_ptr(), None))
+    who = (1 - players).contiguous()
+    planes = torch.zeros((M, 2 * HW), dtype=torch.float32, device=DEV)
+    _lib.check(L.caro_rules_encode_batch(game.kind, game.n, game.k, M, keys.data_ptr(), who.data_ptr(),
+                                         planes.data_ptr(), None))
+    torch.cuda.synchronize()
+    legal, won, keys2, planes = legal.cpu().numpy(), won.cpu().numpy(), keys.cpu().numpy().view(np.uint64), planes.cpu().numpy()
+    new_states = game.from_keys(keys2)
+    for i, r in enumerate(recs):
+        assert np.flatnonzero(legal[i]).tolist() == r["legal"]
+        assert new_states[i] == int(r["s2"])
+        assert bool(won[i]) == r["won"]
+        assert np.packbits(planes[i].astype(np.uint8)).tobytes().hex() == r["planes"]
+
+
+# ------------------------------------------------------------------ engine vs recorded reference games
+def _play_and_check_golden(d, g, explicit_noise=False):
+    from oracle.oracle import noise_row
+    game = _game_of(d)
+    A = game.action_space
+    eng = _engine(game, 1, [_synth(game)], n_stores=g["n_stores"], max_batch=g["batch"], steps_before_tau_0=g["steps_before_tau_0"],
+                  seed=g["seed"], uid_base=g["uid"], node_cap=g["searches"] * g["batch"] * g["plies"] + 64)
+    eng.reset([g["first_player"]])
+    S, B = g["searches"], g["batch"]
+    for ply in range(g["plies"]):
+        keys, players, plies, uid = eng.roots()
+        assert str(game.from_key(keys[0])) == g["states"][ply]
+        assert int(players[0]) == g["players"][ply] and int(plies[0]) == ply
+        noise = None
+        if explicit_noise:
+            noise = np.stack([[[noise_row(g["seed"], g["uid"], ply, mb * B + b, A) for b in range(B)]]
+                              for mb in range(S)])  # [S, G=1, B, A]
+        eng.search(S, B, noise)
+        store = g["players"][ply] if g["n_stores"] == 2 else 0
+        nd = eng.lookup([0], [store], [int(g["states"][ply])])
+        tr = g["trace"][ply]
+        assert nd["found"][0] == 1
+        assert nd["N"][0].tolist() == tr["N"], ply
+        assert nd["W"][0].astype(np.float64).tolist() == tr["W"], ply  # float32 sums, queue order
+        assert nd["strong"][0].tolist() == tr["W_f32"], ply
+        # Q: float32 when strong, exact python ratio otherwise (the kernel recomputes it at the root)
+        for a in range(A):
+            if tr["W_f32"][a]:
+                assert float(nd["Q"][0][a]) == tr["Q"][a]
+            else:
+                assert np.float32(tr["Q"][a]) == nd["Q"][0][a]
+        assert eng.tree_sizes()[0][store] == tr["nodes"], ply
+        pi, counts = eng.policy()
+        assert pi[0].cpu().numpy().tolist() == g["pi"][ply], ply
+        eng.step()
+    dr = eng.drain(recycle=False)
+    assert dr["games"].shape[0] == 1
+    uid, first, result, steps = dr["games"][0].cpu().numpy().tolist()
+    assert (uid, first, result, steps) == (g["uid"], g["first_player"], g["result"], g["steps"])
+    n = g["plies"]
+    assert dr["z"].cpu().numpy().tolist() == g["z"][::-1]
+    assert dr["players"].cpu().numpy().tolist() == g["players"][::-1]
+    assert [str(s) for s in game.from_keys(dr["states"].cpu().numpy().view(np.uint64))] == g["states"][::-1]
+    assert dr["pi"].cpu().numpy().tolist() == g["pi"][::-1]
+    assert n == dr["z"].shape[0]
+    c = eng.counters()
+    assert c["overflows"] == 0 and c["finished"] == 1 and c["plies"] == n
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["synth_c4.json.gz", "synth_ttt3.json.gz", "synth_mnk5.json.gz",
+                                  "synth_mnk15.json.gz"])
+def test_engine_replays_reference_games(name):
+    """G2 on the GPU: the engine reproduces games recorded from the REFERENCE
+    (synthetic table net, noise generated on device from the spec)."""
+    d = load_golden(name)
+    for g in d["games"]:
+        _play_and_check_golden(d, g)
+
+
+def test_explicit_noise_table_path():
+    d = load_golden("synth_ttt3.json.gz")
+    _play_and_check_golden(d, d["games"][2], explicit_noise=True)
+    d = load_golden("synth_c4.json.gz")
+    _play_and_check_golden(d, d["games"][2], explicit_noise=True)
+
+
+# ------------------------------------------------------------------ many concurrent games vs the oracle
+def _oracle_games(d, uids, seed, sbt0, S, B, n_stores, first_mode=2):
+    out = {}
+    for uid in uids:
+        o = _oracle_of(d, n_stores)
+        o.use_synth_net()
+        o.set_stream(seed, int(uid))
+        fp = int(uid) & 1 if first_mode == 2 else first_mode
+        r = o.play_game(sbt0, S, B, fp)
+        r["counters"] = o.counters()
+        r["first"] = fp
+        out[int(uid)] = r
+    return out
+
+
+def _check_against_oracle(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base):
+    game = _game_of(d)
+    eng = _engine(game, G, [_synth(game)], n_stores=n_stores, max_batch=B, steps_before_tau_0=sbt0, seed=seed,
+                  uid_base=uid_base, node_cap=S * B * game.obs_shape[1] * game.obs_shape[2] + 64)
+    tuples, games = eng.play_until(S, B, n_finished=n_finish)
+    c = eng.counters()
+    assert c["overflows"] == 0
+    eng.close()
+    uids = games[:, 0]
+    assert len(set(uids.tolist())) == len(uids)
+    ref = _oracle_games(d, uids, seed, sbt0, S, B, n_stores)
+    # per-game records
+    for uid, first, result, steps in games.tolist():
+        r = ref[uid]
+        assert (first, result, steps) == (r["first"], r["result"], r["steps"]), uid
+    # tuples: each drain emits its games in slot order, plies last-to-first
+    S_all = np.concatenate([t["states"] for t in tuples])
+    P_all = np.concatenate([t["players"] for t in tuples])
+    PI_all = np.concatenate([t["pi"] for t in tuples])
+    Z_all = np.concatenate([t["z"] for t in tuples])
+    off = 0
+    for uid in uids.tolist():
+        r = ref[uid]
+        n = r["plies"]
+        assert game.from_keys(S_all[off:off + n].view(np.uint64)) == r["states"][::-1], uid
+        assert P_all[off:off + n].tolist() == r["players"][::-1].tolist()
+        assert np.array_equal(PI_all[off:off + n], r["pi"][::-1]), uid
+        assert Z_all[off:off + n].tolist() == r["z"][::-1].tolist()
+        off += n
+    assert off == len(Z_all)
+    return c, ref, games
+
+
+def test_connect4_64_games_vs_oracle():
+    """64 concurrent connect-four games, 25x8 sims/move (config 2's S x B), slots
+    recycled until 96 games finished: every game identical to the oracle's."""
+    c, ref, games = _check_against_oracle({"kind": "c4"}, 64, 96, 10, 25, 8, 1, seed=3, uid_base=1000)
+    assert len(games) >= 96
+
+
+def test_connect4_arena_two_stores_vs_oracle():
+    _check_against_oracle({"kind": "c4"}, 16, 16, 0, 10, 16, 2, seed=5, uid_base=5000)
+
+
+def test_tictactoe_games_vs_oracle_with_draws():
+    c, ref, games = _check_against_oracle({"kind": "mnk", "n": 3, "k": 3}, 64, 200, 2, 25, 4, 1, seed=9, uid_base=0)
+    assert (games[:, 2] == 0).any(), "no drawn game in the sample"  # draw path covered
+
+
+def test_gomoku15_games_vs_oracle():
+    _check_against_oracle({"kind": "mnk", "n": 15, "k": 5}, 8, 8, 6, 6, 8, 1, seed=17, uid_base=40)
+
+
+def test_mnk_mid_sizes_vs_oracle():
+    _check_against_oracle({"kind": "mnk", "n": 6, "k": 4}, 8, 8, 3, 8, 8, 1, seed=21, uid_base=0)
+    _check_against_oracle({"kind": "mnk", "n": 10, "k": 5}, 4, 4, 3, 6, 8, 1, seed=22, uid_base=0)
+
+
+def test_counters_match_oracle_totals():
+    """sims / levels / expansions / terminals / dropped summed over complete
+    games equal the oracle's (the roofline's byte formula is built on these)."""
+    d = {"kind": "c4"}
+    game = _game_of(d)
+    G, S, B = 32, 25, 8
+    eng = _engine(game, G, [_synth(game)], max_batch=B, steps_before_tau_0=10, seed=77, uid_base=0)
+    tuples, games = eng.play_until(S, B, recycle=False)
+    c = eng.counters()
+    eng.close()
+    assert len(games) == G and c["finished"] == G
+    ref = _oracle_games(d, range(G), 77, 10, S, B, 1)
+    tot = {k: sum(r["counters"][k] for r in ref.values()) for k in ["sims", "levels", "expansions", "terminals", "dropped"]}
+    # finished games keep idling in lock-step runs only until every game is done; they add no sims
+    for k in tot:
+        assert c[k] == tot[k], k
+    assert c["plies"] == sum(r["plies"] for r in ref.values())
+
+
+def test_full_size_1024_games_invariants():
+    """Config 2 geometry (1024 games, 25x8): size-independent properties."""
+    d = {"kind": "c4"}
+    game = _game_of(d)
+    G, S, B = 1024, 25, 8
+    eng = _engine(game, G, [_synth(game)], max_batch=B, steps_before_tau_0=10, seed=1, uid_base=0)
+    for _ in range(3):
+        eng.search(S, B)
+        pi, counts = eng.policy()
+        cn = counts.cpu().numpy()
+        # root visit counts: every sim except the dropped duplicates and the first expansion is backed up
+        assert (cn.sum(1) <= S * B * 3).all() and (cn.sum(1) > 0).all()
+        p = pi.cpu().numpy()
+        assert np.allclose(p.sum(1), 1.0)
+        eng.step()
+    c = eng.counters()
+    assert c["sims"] == 3 * G * S * B and c["overflows"] == 0
+    assert c["expansions"] + c["terminals"] + c["dropped"] == c["sims"]
+    # a sample of the 1024 games equals the oracle ply by ply
+    keys, players, plies, uid = eng.roots()
+    from oracle.oracle import Oracle
+    for gidx in [0, 1, 511, 1023]:
+        o = Oracle(Oracle.C4)
+        o.use_synth_net()
+        o.set_stream(1, gidx)
+        s, pl = o.initial_state, gidx & 1
+        for ply in range(3):
+            o.search_batch(S, B, s, pl, ply=ply)
+            prob = o.get_policy(s, 1)
+            from oracle.oracle import move_uniform, sample_index
+            a = sample_index(prob, move_uniform(1, gidx, ply))
+            s, won = o.move(s, a, pl)
+            pl = 1 - pl
+            assert not won
+        assert game.from_key(keys[gidx]) == s
+    eng.close()
