@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: self-play MCTS node-expansions/sec/GPU, Connect4,
+200 sims/move (25 x 8), 1024 concurrent games per GPU (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one move of every one of the G concurrent games on a rank: 25
+search minibatches (select -> net forward -> expand+backup), the ply itself,
+and the drain / recycling of finished games (plus, for N > 1, the all-gather of
+the drained (s, pi, z) tuples).  value = node-expansions (reference:
+`_create_node` calls, lib/mcts.py:178-190 = train.py's "leaves") summed over
+ranks / max-over-ranks wall time of the K timed steps.
+
+One JSON line on stdout (rank 0).  `roofline` is the select kernel (HIP events
+on its launch stream, inside the timed region); `cpu_baseline` is the oracle
+(CPU port of the reference algorithm) driving the same net on one host core for
+a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def load_net(game, device, weights):
+    from caro_ai_amd.lib.model import Net
+    torch.manual_seed(0)
+    net = Net(game.obs_shape, game.action_space)
+    tag = "random-init(seed 0)"
+    if weights and os.path.exists(weights):
+        net.load_state_dict(torch.load(weights, map_location="cpu"))
+        tag = os.path.basename(weights)
+    return net.to(device).eval(), tag
+
+
+def cpu_baseline(game_name, S, B, sbt0, weights, seconds):
+    """The oracle (oracle/caro_oracle.c) playing whole games with the same net on
+    ONE host core (torch CPU forward, 1 thread), for ~`seconds` of wall time."""
+    from caro_ai_amd.lib.model import Net
+    from oracle.oracle import Oracle
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        o = Oracle(Oracle.C4) if game_name == "c4" else Oracle(Oracle.MNK, 15, 5)
+        torch.manual_seed(0)
+        net = Net((2, o.rows, o.cols), o.A)
+        if weights and os.path.exists(weights):
+            net.load_state_dict(torch.load(weights, map_location="cpu"))
+        net.eval()
+
+        def fn(planes, states, players):
+            with torch.no_grad():
+                lg, vl = net(torch.from_numpy(np.ascontiguousarray(planes)))
+                return torch.softmax(lg, dim=1).numpy(), vl.numpy()[:, 0]
+
+        o.set_net(0, fn)
+        o.set_net(1, fn)
+        t0 = time.perf_counter()
+        games = 0
+        while time.perf_counter() - t0 < seconds:
+            o.set_stream(0, games)
+            o.play_game(sbt0, S, B, games & 1)
+            games += 1
+        dt = time.perf_counter() - t0
+        c = o.counters()
+        return {"value": c["expansions"] / dt, "unit": "node-expansions/s", "cores": 1, "kind": "port",
+                "sample": "%d whole games, %d sims, %.1f s, oracle/caro_oracle.c + torch CPU fp32 forward "
+                          "(1 thread, eval-mode BN, %.2f rows/net call)" % (games, c["sims"], dt,
+                                                                          c["net_rows"] / max(1, c["net_calls"]))}
+    finally:
+        torch.set_num_threads(nthreads)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--games", type=int, default=1024, help="concurrent games per GPU")
+    ap.add_argument("--searches", type=int, default=25)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--game", default="c4", choices=["c4", "gomoku15"])
+    ap.add_argument("--weights", default=os.path.join(ROOT, "tests", "golden", "weights", "best_026_12000.dat"))
+    ap.add_argument("--folded", type=int, default=1, help="fold eval-mode BN into the convs (inference form)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the kernels")
+    args = ap.parse_args()
+
+    from caro_ai_amd import parallel
+    from caro_ai_amd.engine import SelfPlayEngine, torch_evaluator
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.lib.model import FoldedNet
+
+    rank, local_rank, world = parallel.init()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    if args.game == "c4":
+        game, weights, sbt0 = ConnectFour(), args.weights, 10
+    else:
+        game, weights, sbt0 = TicTacToe(15, 5), None, 10
+    net, wtag = load_net(game, device, weights)
+    fnet = FoldedNet(net).to(device).eval() if args.folded else net
+    G, S, B = args.games, args.searches, args.batch
+    eng = SelfPlayEngine(game, G, evaluators=[torch_evaluator(fnet)], max_batch=B, steps_before_tau_0=sbt0,
+                         seed=0, device=str(device), searches_hint=S, **parallel.shard(G, rank, world))
+
+    n_tuples = 0
+
+    def one_step():
+        nonlocal n_tuples
+        eng.search(S, B)
+        eng.step()
+        d = eng.drain(recycle=True)
+        if world > 1:
+            d = parallel.gather_tuples(d)
+        n_tuples += int(d["z"].shape[0])
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    c0 = eng.counters()
+    if not args.no_profile:
+        eng.profile(True)
+        eng.profile_read(reset=True)
+    rows0, calls0 = eng.net_rows, eng.net_calls
+    n_tuples = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    c1 = eng.counters()
+    prof = eng.profile_read(reset=True) if not args.no_profile else None
+    eng.profile(False)
+
+    delta = {k: c1[k] - c0[k] for k in c1}
+    tot = torch.tensor([delta["expansions"], delta["sims"], delta["levels"], delta["plies"], delta["finished"],
+                        eng.net_rows - rows0], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    parallel.allreduce_sum(tot)
+    parallel.allreduce_max(tmax)
+    dt_max = float(tmax.item())
+    exp_all, sims_all, levels_all, plies_all, fin_all, rows_all = [float(x) for x in tot.tolist()]
+
+    if rank == 0:
+        A, KW, HW = game.action_space, game.key_words, game.obs_shape[1] * game.obs_shape[2]
+        bytes_per_level = 12 * A + 8 * KW + 28            # N,Q,P rows + key probe + backup RMW
+        bytes_per_exp = 16 * HW + 20 * A + 8 * KW + 12
+        roofline = None
+        if prof is not None and prof["select"][1] > 0:
+            ms, n = prof["select"]
+            avg_s = ms * 1e-3 / n
+            levels_per_launch = delta["levels"] / n
+            achieved = levels_per_launch * bytes_per_level / avg_s / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_select", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_us": avg_s * 1e6, "launches": n,
+                        "levels_per_launch": levels_per_launch, "bytes_per_level": bytes_per_level,
+                        "other_kernels_us": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in prof.items()
+                                             if k != "select"}}
+            pmc = os.path.join(ROOT, "profiles", "pmc_select.json")
+            if os.path.exists(pmc):
+                try:
+                    roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
+        out = {
+            "metric": "self-play MCTS node-expansions/sec/GPU (Connect4, 200 sims/move); 1->8 GPU scaling"
+            if args.game == "c4" else "self-play MCTS node-expansions/sec/GPU (15x15 k=5)",
+            "value": exp_all / dt_max,
+            "unit": "node-expansions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (self-play from empty boards; net weights: %s)" % wtag,
+            "config": {"workload": "%s %d concurrent self-play games/GPU, %dx%d = %d sims/move, tau=1 for %d plies"
+                                   % ("Connect4 6x7" if args.game == "c4" else "m,n,k 15x15 k=5", G, S, B, S * B, sbt0),
+                       "games_per_gpu": G, "searches": S, "batch": B, "net": "FoldedNet fp32" if args.folded else "Net fp32",
+                       "parallelism": "games sharded x%d, all-gather of tuples per step" % world},
+            "per_gpu": exp_all / dt_max / world,
+            "sims_per_s": sims_all / dt_max, "plies_per_s": plies_all / dt_max, "games_per_s": fin_all / dt_max,
+            "net_rows_per_s": rows_all / dt_max, "mean_depth": levels_all / max(1.0, sims_all),
+            "expansions_per_sim": exp_all / max(1.0, sims_all),
+            "algorithmic_GBps": (levels_all * bytes_per_level + exp_all * bytes_per_exp) / dt_max / 1e9,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.game, S, B, sbt0, weights, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1013,7 +1013,48 @@ struct caro_engine {
   int32_t* scratch;  // device i32 [maxply]
   int32_t* live;     // device i32
   int select_pending;
+  // optional HIP-event timing of the hot kernels (bench.py's live roofline)
+  int prof_on;
+  std::vector<hipEvent_t> ev;      // pairs: [2*i] start, [2*i+1] stop
+  std::vector<int> ev_kind;        // kernel id of pair i
+  size_t ev_used;
+  double prof_ms[4];
+  long long prof_n[4];
 };
+
+enum ProfKind { PK_SELECT = 0, PK_COMPACT = 1, PK_EXPAND = 2, PK_STEP = 3 };
+
+static void prof_flush(caro_engine* h) {
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(h->ev[2 * i + 1]) == hipSuccess &&
+        hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]) == hipSuccess) {
+      h->prof_ms[h->ev_kind[i]] += ms;
+      h->prof_n[h->ev_kind[i]] += 1;
+    }
+  }
+  h->ev_used = 0;
+}
+static int prof_begin(caro_engine* h, int kind, hipStream_t st) {
+  if (!h->prof_on) return -1;
+  if (h->ev_used * 2 + 2 > h->ev.size()) {
+    if (h->ev.size() >= 2 * 16384) prof_flush(h);
+    else
+      for (int i = 0; i < 512; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        h->ev.push_back(e);
+      }
+  }
+  const int i = (int)h->ev_used++;
+  if ((size_t)i >= h->ev_kind.size()) h->ev_kind.resize(i + 1);
+  h->ev_kind[i] = kind;
+  (void)hipEventRecord(h->ev[2 * i], st);
+  return i;
+}
+static void prof_end(caro_engine* h, int i, hipStream_t st) {
+  if (i >= 0) (void)hipEventRecord(h->ev[2 * i + 1], st);
+}
 
 template <class T>
 static int dalloc(caro_engine* h, T** p, size_t n) {
@@ -1157,6 +1198,9 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   h->cfg = *cfg;
   h->var = var;
   h->select_pending = 0;
+  h->prof_on = 0;
+  h->ev_used = 0;
+  for (int i = 0; i < 4; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
   View& v = h->v;
   memset(&v, 0, sizeof v);
   v.gp = make_gp(cfg->game_kind, cfg->n, cfg->k);
@@ -1222,6 +1266,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
 void caro_engine_destroy(caro_engine* h) {
   if (!h) return;
   for (void* p : h->allocs) (void)hipFree(p);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->pinned64) (void)hipHostFree(h->pinned64);
   delete h;
@@ -1251,11 +1296,16 @@ int caro_select(caro_engine* h, int batch, int mb_index, const double* noise, fl
   if (h->select_pending) return fail(CARO_E_STATE, "caro_select called twice without caro_expand_backup");
   const int lpd = variant_lpd(h->var);
   hipStream_t st = (hipStream_t)stream;
+  const int p0 = prof_begin(h, PK_SELECT, st);
+  DISPATCH(h->var, hipLaunchKernelGGL(k_select<GEO>, dim3(h->v.G), dim3(batch * lpd), 0, st, h->v, batch, mb_index,
+                                      noise));
+  prof_end(h, p0, st);
+  const int p1 = prof_begin(h, PK_COMPACT, st);
   DISPATCH(h->var, {
-    hipLaunchKernelGGL(k_select<GEO>, dim3(h->v.G), dim3(batch * lpd), 0, st, h->v, batch, mb_index, noise);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, h->v, batch);
     hipLaunchKernelGGL(k_encode<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, planes, leaf_keys);
   });
+  prof_end(h, p1, st);
   HIPCHK(hipGetLastError());
   h->select_pending = 1;
   return 0;
@@ -1273,8 +1323,10 @@ int caro_leaf_counts(caro_engine* h, int32_t counts[2], void* stream) {
 int caro_expand_backup(caro_engine* h, const float* probs, const float* values, void* stream) {
   if (!h) return fail(CARO_E_INVAL, "null engine");
   if (!h->select_pending) return fail(CARO_E_STATE, "caro_expand_backup without a pending caro_select");
+  const int p0 = prof_begin(h, PK_EXPAND, (hipStream_t)stream);
   DISPATCH(h->var, hipLaunchKernelGGL(k_expand_backup<GEO>, dim3(h->v.G), dim3(64), 0, (hipStream_t)stream, h->v,
                                       probs, values));
+  prof_end(h, p0, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   h->select_pending = 0;
   return 0;
@@ -1290,8 +1342,10 @@ int caro_policy(caro_engine* h, double* pi, int32_t* counts, void* stream) {
 int caro_step(caro_engine* h, const double* uniforms, int32_t* actions, int32_t* done, int32_t* result, void* stream) {
   if (!h) return fail(CARO_E_INVAL, "null engine");
   if (h->select_pending) return fail(CARO_E_STATE, "caro_step with a pending caro_select");
+  const int p0 = prof_begin(h, PK_STEP, (hipStream_t)stream);
   DISPATCH(h->var, hipLaunchKernelGGL(k_step<GEO>, dim3(h->v.G), dim3(64), 0, (hipStream_t)stream, h->v, uniforms,
                                       actions, done, result));
+  prof_end(h, p0, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1317,6 +1371,24 @@ int caro_counters(caro_engine* h, int64_t counters[8], void* stream) {
   HIPCHK(hipMemcpyAsync(h->pinned64, h->v.counters, C_N * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   for (int i = 0; i < 8; ++i) counters[i] = i < C_N ? h->pinned64[i] : 0;
+  return 0;
+}
+
+int caro_profile_enable(caro_engine* h, int on) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  if (!on && h->prof_on) prof_flush(h);
+  h->prof_on = on ? 1 : 0;
+  return 0;
+}
+
+int caro_profile_read(caro_engine* h, double ms[4], int64_t launches[4], int reset) {
+  if (!h || !ms || !launches) return fail(CARO_E_INVAL, "null argument");
+  prof_flush(h);
+  for (int i = 0; i < 4; ++i) {
+    ms[i] = h->prof_ms[i];
+    launches[i] = h->prof_n[i];
+    if (reset) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+  }
   return 0;
 }
 

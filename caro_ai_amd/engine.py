@@ -188,6 +188,16 @@ class SelfPlayEngine:
         _lib.check(self.L.caro_counters(self.h, out, self._stream()))
         return dict(zip(COUNTER_NAMES, list(out)))
 
+    def profile(self, on=True):
+        _lib.check(self.L.caro_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self, reset=True):
+        """{kernel: (total ms, launches)} measured with HIP events on the launch stream"""
+        ms = (C.c_double * 4)()
+        n = (C.c_int64 * 4)()
+        _lib.check(self.L.caro_profile_read(self.h, ms, n, 1 if reset else 0))
+        return {k: (ms[i], n[i]) for i, k in enumerate(["select", "compact", "expand_backup", "step"])}
+
     def live_games(self):
         out = C.c_int32(0)
         _lib.check(self.L.caro_live_games(self.h, C.addressof(out), self._stream()))

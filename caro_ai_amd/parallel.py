@@ -1,0 +1,104 @@
+"""Multi-GPU self-play: one process per GPU, games sharded by id, no data-path
+collective inside the search.  The reference has no distributed code at all
+(SURVEY.md section 2); this is the sharding of its independent `play_game` calls
+(train.py:41-47 runs them one after another).
+
+Exchanges (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests):
+  gather_tuples      variable-length all-gather of (state, player, pi, z) replay
+                     tuples: one int64 count all-gather + one padded
+                     all_gather_into_tensor per field group.  Messages are
+                     KB..MB, i.e. latency bound, so one flat all-gather per
+                     drain and no ring/bucketing.
+  broadcast_weights  state_dict broadcast from rank 0 after a training step.
+  allreduce_sum      arena W/L/D counters, expansion counters.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(
+        os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    rank, local_rank, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard(n_games_per_rank, rank, world):
+    """uid layout: game slot g of rank r starts as uid r*G + g and is recycled with
+    stride world*G, so every uid is played exactly once whatever the world size."""
+    return {"uid_base": rank * n_games_per_rank, "uid_stride": world * n_games_per_rank}
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def allreduce_sum(t):
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def allreduce_max(t):
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def gather_tuples(tuples, pi_dtype=torch.float32):
+    """All-gather one drain's tuples.  `tuples`: dict with states int64[n,KW],
+    players int32[n], pi float[n,A], z int32[n] on this rank's device.  Returns the
+    same dict holding every rank's rows, rank-major (deterministic order).
+    pi travels as float32 (what the trainer consumes, train.py:92)."""
+    if not is_dist():
+        return {"states": tuples["states"], "players": tuples["players"], "pi": tuples["pi"].to(pi_dtype),
+                "z": tuples["z"]}
+    world = dist.get_world_size()
+    dev = tuples["states"].device
+    n = tuples["states"].shape[0]
+    KW, A = tuples["states"].shape[1], tuples["pi"].shape[1]
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    mine = torch.tensor([n], dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, mine)
+    counts_h = counts.cpu().tolist()
+    m = max(counts_h)
+    if m == 0:
+        return {"states": tuples["states"][:0], "players": tuples["players"][:0],
+                "pi": tuples["pi"][:0].to(pi_dtype), "z": tuples["z"][:0]}
+    # one integer record [KW states | player | z] and one float record [pi]
+    ints = torch.zeros((m, KW + 2), dtype=torch.int64, device=dev)
+    ints[:n, :KW] = tuples["states"]
+    ints[:n, KW] = tuples["players"].to(torch.int64)
+    ints[:n, KW + 1] = tuples["z"].to(torch.int64)
+    flt = torch.zeros((m, A), dtype=pi_dtype, device=dev)
+    flt[:n] = tuples["pi"].to(pi_dtype)
+    all_i = torch.empty((world * m, KW + 2), dtype=torch.int64, device=dev)
+    all_f = torch.empty((world * m, A), dtype=pi_dtype, device=dev)
+    dist.all_gather_into_tensor(all_i, ints)
+    dist.all_gather_into_tensor(all_f, flt)
+    keep = torch.cat([torch.arange(r * m, r * m + c, device=dev) for r, c in enumerate(counts_h)])
+    all_i, all_f = all_i[keep], all_f[keep]
+    return {"states": all_i[:, :KW].contiguous(), "players": all_i[:, KW].to(torch.int32),
+            "pi": all_f, "z": all_i[:, KW + 1].to(torch.int32)}
+
+
+def broadcast_weights(net, src=0):
+    if is_dist():
+        for t in net.state_dict().values():
+            dist.broadcast(t, src=src)
+    return net
