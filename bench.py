@@ -92,7 +92,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--game", default="c4", choices=["c4", "gomoku15"])
     ap.add_argument("--weights", default=os.path.join(ROOT, "tests", "golden", "weights", "best_026_12000.dat"))
-    ap.add_argument("--folded", type=int, default=1, help="fold eval-mode BN into the convs (inference form)")
+    ap.add_argument("--net", default="gemm", choices=["gemm", "folded", "net"],
+                    help="inference form of lib/model.py Net: gather+GEMM (default), BN-folded conv2d, or the module as is")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the kernels")
@@ -102,7 +103,7 @@ def main():
     from caro_ai_amd.engine import SelfPlayEngine, torch_evaluator
     from caro_ai_amd.lib.game.connect_four import ConnectFour
     from caro_ai_amd.lib.game.tictactoe import TicTacToe
-    from caro_ai_amd.lib.model import FoldedNet
+    from caro_ai_amd.lib.model import FoldedNet, GemmNet
 
     rank, local_rank, world = parallel.init()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
@@ -114,9 +115,9 @@ def main():
     else:
         game, weights, sbt0 = TicTacToe(15, 5), None, 10
     net, wtag = load_net(game, device, weights)
-    fnet = FoldedNet(net).to(device).eval() if args.folded else net
+    fnet = {"gemm": GemmNet, "folded": FoldedNet, "net": lambda n: n}[args.net](net).to(device).eval()
     G, S, B = args.games, args.searches, args.batch
-    eng = SelfPlayEngine(game, G, evaluators=[torch_evaluator(fnet)], max_batch=B, steps_before_tau_0=sbt0,
+    eng = SelfPlayEngine(game, G, evaluators=[torch_evaluator(fnet, form="net")], max_batch=B, steps_before_tau_0=sbt0,
                          seed=0, device=str(device), searches_hint=S, **parallel.shard(G, rank, world))
 
     n_tuples = 0
@@ -135,8 +136,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         one_step()
+        if rank == 0 and i % 5 == 0:
+            print("[bench] warmup step %d" % i, file=sys.stderr, flush=True)
     barrier()
     c0 = eng.counters()
     if not args.no_profile:
@@ -145,8 +148,10 @@ def main():
     rows0, calls0 = eng.net_rows, eng.net_calls
     n_tuples = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         one_step()
+        if rank == 0 and i % 10 == 0:
+            print("[bench] step %d" % i, file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
     c1 = eng.counters()
@@ -196,7 +201,7 @@ def main():
             "data": "synthetic (self-play from empty boards; net weights: %s)" % wtag,
             "config": {"workload": "%s %d concurrent self-play games/GPU, %dx%d = %d sims/move, tau=1 for %d plies"
                                    % ("Connect4 6x7" if args.game == "c4" else "m,n,k 15x15 k=5", G, S, B, S * B, sbt0),
-                       "games_per_gpu": G, "searches": S, "batch": B, "net": "FoldedNet fp32" if args.folded else "Net fp32",
+                       "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py %s fp32" % args.net,
                        "parallelism": "games sharded x%d, all-gather of tuples per step" % world},
             "per_gpu": exp_all / dt_max / world,
             "sims_per_s": sims_all / dt_max, "plies_per_s": plies_all / dt_max, "games_per_s": fin_all / dt_max,

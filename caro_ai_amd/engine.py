@@ -29,9 +29,15 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def torch_evaluator(net):
-    """leaf planes -> (P float32[L,A] softmaxed, v float32[L]); mcts.py:212-218 on the device."""
+def torch_evaluator(net, form="gemm"):
+    """leaf planes -> (P float32[L,A] softmaxed, v float32[L]); mcts.py:212-218 on the device.
+    A `Net` is run in its GEMM inference form (lib/model.py GemmNet: no per-shape kernel search),
+    form="net" keeps the module as is."""
+    from caro_ai_amd.lib.model import GemmNet, Net
     net.eval()
+    if form == "gemm" and isinstance(net, Net):
+        dev = next(net.parameters()).device
+        net = GemmNet(net).to(dev).eval()
 
     @torch.no_grad()
     def fn(planes):

@@ -109,3 +109,69 @@ class FoldedNet(nn.Module):
         val = F.leaky_relu(F.conv2d(h, self.ws[nb], self.bs[nb]), self.slope)
         pol = F.leaky_relu(F.conv2d(h, self.ws[nb + 1], self.bs[nb + 1]), self.slope)
         return self.policy(pol.reshape(n, -1)), self.value(val.reshape(n, -1))
+
+
+class GemmNet(nn.Module):
+    """Inference form used on the leaf batch: every convolution is ONE gather +
+    ONE GEMM over channels-last activations X[L*HW, C],
+
+        patches[L*HW, 9*C] = X_padded[neighbour index]      (3x3, padding 1)
+        Y[L*HW, 64]        = patches @ Wmat[9*C, 64] + b    (rocBLAS / hipBLASLt, MFMA)
+
+    so the leaf-batch size L can change every minibatch without any kernel
+    being compiled or searched for (MIOpen has no tuned/compiled database for
+    gfx950 in this image and would JIT per shape).  Eval-mode batch-norm is
+    folded into Wmat / b.  Same function as `Net.eval()` up to float32
+    re-association (tests/test_model.py states the tolerance).
+    """
+
+    def __init__(self, net: Net, negative_slope=0.01):
+        super().__init__()
+        self.slope = negative_slope
+        _, H, W = net.input_shape
+        self.H, self.W, self.HW = H, W, H * W
+        self.actions_n = net.actions_n
+        idx = torch.full((H * W, 9), H * W, dtype=torch.long)  # H*W = the zero padding row
+        for y in range(H):
+            for x in range(W):
+                for ky in range(3):
+                    for kx in range(3):
+                        yy, xx = y + ky - 1, x + kx - 1
+                        if 0 <= yy < H and 0 <= xx < W:
+                            idx[y * W + x, ky * 3 + kx] = yy * W + xx
+        self.register_buffer("idx", idx.reshape(-1))
+        self.wm = nn.ParameterList()
+        self.bs = nn.ParameterList()
+        for blk in [net.conv_in] + net.residual_blocks():
+            w, b = _fold(blk)  # [Cout, Cin, 3, 3]
+            wm = w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]).contiguous()  # [(ky,kx,c), Cout]
+            self.wm.append(nn.Parameter(wm, requires_grad=False))
+            self.bs.append(nn.Parameter(b, requires_grad=False))
+        wv, bv = _fold(net.conv_val)      # [1, 64, 1, 1]
+        wp, bp = _fold(net.conv_policy)   # [2, 64, 1, 1]
+        self.wh = nn.Parameter(torch.cat([wv, wp]).reshape(3, -1).t().contiguous(), requires_grad=False)  # [64, 3]
+        self.bh = nn.Parameter(torch.cat([bv, bp]), requires_grad=False)
+        self.value = copy.deepcopy(net.value)
+        self.policy = copy.deepcopy(net.policy)
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def _conv3(self, x, i):
+        # x: [L, HW, C]
+        L, HW, Cc = x.shape
+        xp = F.pad(x, (0, 0, 0, 1))                      # zero row at index HW
+        patches = xp.index_select(1, self.idx).reshape(L * HW, 9 * Cc)
+        y = torch.addmm(self.bs[i], patches, self.wm[i])
+        return F.leaky_relu(y, self.slope).reshape(L, HW, -1)
+
+    def forward(self, x):
+        L = x.shape[0]
+        h = x.reshape(L, x.shape[1], self.HW).transpose(1, 2)  # [L, HW, 2] channels-last view
+        h = self._conv3(h.contiguous(), 0)
+        for i in range(1, len(self.wm)):
+            h = h + self._conv3(h, i)
+        heads = F.leaky_relu(torch.addmm(self.bh, h.reshape(L * self.HW, -1), self.wh), self.slope)
+        heads = heads.reshape(L, self.HW, 3)
+        val = self.value(heads[:, :, 0])
+        pol = self.policy(heads[:, :, 1:3].transpose(1, 2).reshape(L, 2 * self.HW))
+        return pol, val
