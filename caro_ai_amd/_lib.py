@@ -54,6 +54,8 @@ _SIGNATURES = {
     "caro_set_roots": (C.c_int, [_P, _P, _P, _P]),
     "caro_select": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "caro_leaf_counts": (C.c_int, [_P, _P, _P]),
+    "caro_get_descent": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "caro_select_cancel": (C.c_int, [_P]),
     "caro_expand_backup": (C.c_int, [_P, _P, _P, _P]),
     "caro_policy": (C.c_int, [_P, _P, _P, _P]),
     "caro_step": (C.c_int, [_P, _P, _P, _P, _P, _P]),

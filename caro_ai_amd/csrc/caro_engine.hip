@@ -853,6 +853,29 @@ __global__ void k_dump(View v, int game, int store, long long cap, uint64_t* key
   if (threadIdx.x < KW) keys[(size_t)node * KW + threadIdx.x] = v.node_key[((size_t)t * v.cap + node) * KW + threadIdx.x];
 }
 
+// one descent of the pending select, for MCTS.find_leaf (lib/mcts.py:97-148)
+template <class GEO>
+__global__ void k_get_descent(View v, int game, int b, int32_t* info, float* value, uint64_t* leaf_key,
+                              uint64_t* path_keys, int32_t* path_actions) {
+  constexpr int KW = GEO::KW;
+  const size_t di = (size_t)game * v.maxB + b;
+  const int len = v.path_len[di];
+  const int t = v.g_tree[game];
+  if (threadIdx.x == 0) {
+    info[0] = v.d_status[di];
+    info[1] = len;
+    info[2] = v.d_player[di];
+    info[3] = v.d_local[di];
+    *value = v.d_value[di];
+    for (int w = 0; w < KW; ++w) leaf_key[w] = v.d_key[di * KW + w];
+  }
+  for (int i = threadIdx.x; i < len; i += blockDim.x) {
+    const int node = v.path_node[di * v.maxd + i];
+    path_actions[i] = v.path_act[di * v.maxd + i];
+    for (int w = 0; w < KW; ++w) path_keys[(size_t)i * KW + w] = v.node_key[((size_t)t * v.cap + node) * KW + w];
+  }
+}
+
 __global__ void k_tree_sizes(View v, int32_t* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < v.G * v.n_stores) out[i] = v.n_created[i];
@@ -1371,6 +1394,24 @@ int caro_counters(caro_engine* h, int64_t counters[8], void* stream) {
   HIPCHK(hipMemcpyAsync(h->pinned64, h->v.counters, C_N * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   for (int i = 0; i < 8; ++i) counters[i] = i < C_N ? h->pinned64[i] : 0;
+  return 0;
+}
+
+int caro_select_cancel(caro_engine* h) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  h->select_pending = 0;
+  return 0;
+}
+
+int caro_get_descent(caro_engine* h, int game, int b, int32_t* info_dev, float* value_dev, uint64_t* leaf_key_dev,
+                     uint64_t* path_keys_dev, int32_t* path_actions_dev, void* stream) {
+  if (!h || !info_dev || !value_dev || !leaf_key_dev || !path_keys_dev || !path_actions_dev)
+    return fail(CARO_E_INVAL, "null argument");
+  if (!h->select_pending) return fail(CARO_E_STATE, "caro_get_descent needs a pending caro_select");
+  if (game < 0 || game >= h->v.G || b < 0 || b >= h->v.maxB) return fail(CARO_E_INVAL, "bad descent index");
+  DISPATCH(h->var, hipLaunchKernelGGL(k_get_descent<GEO>, dim3(1), dim3(64), 0, (hipStream_t)stream, h->v, game, b,
+                                      info_dev, value_dev, leaf_key_dev, path_keys_dev, path_actions_dev));
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

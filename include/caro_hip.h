@@ -122,6 +122,14 @@ int caro_set_roots(caro_engine* h, const uint64_t* keys_dev, const int32_t* play
  * leaf_keys_dev (optional, may be NULL): u64[>= G*batch, KW] keys of the rows. */
 int caro_select(caro_engine* h, int batch, int mb_index, const double* noise_dev, float* planes_dev,
                 uint64_t* leaf_keys_dev, void* stream);
+/* MCTS.find_leaf (lib/mcts.py:97-148) of descent `b` of game `game` of the pending select:
+ * info_dev i32[4] = (status 0 dropped duplicate / 1 terminal / 2 new leaf, path length, player at the leaf, -),
+ * value_dev f32[1] (terminal value), leaf_key_dev u64[KW], path_keys_dev u64[maxd,KW] (the `states` list),
+ * path_actions_dev i32[maxd] (the `actions` list); maxd = H*W. */
+int caro_get_descent(caro_engine* h, int game, int b, int32_t* info_dev, float* value_dev, uint64_t* leaf_key_dev,
+                     uint64_t* path_keys_dev, int32_t* path_actions_dev, void* stream);
+/* drop a pending select without expanding (find_leaf alone does not modify the tree) */
+int caro_select_cancel(caro_engine* h);
 /* Blocks until the select on `stream` has finished; counts[0..1] = L0, L1. */
 int caro_leaf_counts(caro_engine* h, int32_t counts[2], void* stream);
 /* Second half (mcts.py:281-287): _create_node (:178-190) for every unique leaf
