@@ -1,0 +1,98 @@
+"""N > 1 path on CPU: two gloo ranks exercise the sharding rule, the
+variable-length tuple all-gather, the weight broadcast and the counter
+all-reduce that bench.py / multi-GPU self-play use over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_tuples(rank, n, KW=1, A=7):
+    g = torch.Generator().manual_seed(100 + rank)
+    pi = torch.rand((n, A), generator=g, dtype=torch.float64)
+    pi = pi / pi.sum(1, keepdim=True) if n else pi
+    return {"states": torch.randint(0, 2**62, (n, KW), generator=g, dtype=torch.int64),
+            "players": torch.randint(0, 2, (n,), generator=g, dtype=torch.int32),
+            "pi": pi, "z": torch.randint(-1, 2, (n,), generator=g, dtype=torch.int32)}
+
+
+def _worker(rank, world, port, counts, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from caro_ai_amd import parallel
+    r, lr, w = parallel.init(backend="gloo")
+    assert (r, w) == (rank, world) and parallel.is_dist()
+    out = {}
+    # 1. sharding: disjoint uid sets whatever the world size
+    sh = parallel.shard(4, rank, world)
+    uids = [sh["uid_base"] + g + k * sh["uid_stride"] for g in range(4) for k in range(3)]
+    out["uids"] = uids
+    # 2. variable-length gather (including an empty rank in round 1)
+    for rnd, cnt in enumerate(counts):
+        mine = _fake_tuples(rank * 10 + rnd, cnt[rank])
+        allt = parallel.gather_tuples(mine)
+        out["gather%d" % rnd] = {k: v.numpy() for k, v in allt.items()}
+    # 3. weight broadcast
+    from caro_ai_amd.lib.model import Net
+    torch.manual_seed(rank)
+    net = Net((2, 3, 3), 9)
+    parallel.broadcast_weights(net, src=0)
+    out["wsum"] = float(sum(v.double().sum() for v in net.state_dict().values()))
+    # 4. counters
+    t = torch.tensor([rank + 1, 10 * (rank + 1), 3], dtype=torch.int64)
+    out["sum"] = parallel.allreduce_sum(t.clone()).tolist()
+    out["max"] = parallel.allreduce_max(t.clone()).tolist()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    world = 2
+    counts = [(5, 3), (0, 4), (0, 0)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, counts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert not set(res[0]["uids"]) & set(res[1]["uids"])
+    assert sorted(res[0]["uids"] + res[1]["uids"]) == list(range(24))
+    for rnd, cnt in enumerate(counts):
+        exp = [_fake_tuples(r * 10 + rnd, cnt[r]) for r in range(world)]
+        for rank in range(world):
+            got = res[rank]["gather%d" % rnd]
+            assert got["z"].shape[0] == sum(cnt)
+            np.testing.assert_array_equal(got["states"], torch.cat([e["states"] for e in exp]).numpy())
+            np.testing.assert_array_equal(got["players"], torch.cat([e["players"] for e in exp]).numpy())
+            np.testing.assert_array_equal(got["z"], torch.cat([e["z"] for e in exp]).numpy())
+            np.testing.assert_array_equal(got["pi"], torch.cat([e["pi"] for e in exp]).float().numpy())
+    assert res[0]["wsum"] == res[1]["wsum"]
+    assert res[0]["sum"] == res[1]["sum"] == [3, 30, 6]
+    assert res[0]["max"] == [2, 20, 3]
+
+
+def test_single_process_paths_are_noops():
+    from caro_ai_amd import parallel
+    assert not parallel.is_dist()
+    t = _fake_tuples(0, 4)
+    out = parallel.gather_tuples(t)
+    assert out["pi"].dtype == torch.float32 and out["z"].shape[0] == 4
+    assert parallel.shard(1024, 0, 1) == {"uid_base": 0, "uid_stride": 1024}
+    assert parallel.allreduce_sum(torch.tensor([5])).item() == 5
