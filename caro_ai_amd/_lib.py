@@ -54,6 +54,12 @@ _SIGNATURES = {
     "caro_set_roots": (C.c_int, [_P, _P, _P, _P]),
     "caro_select": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "caro_leaf_counts": (C.c_int, [_P, _P, _P]),
+    "caro_leaf_counts_dev": (C.c_int, [_P, _P]),
+    "caro_net_packed_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "caro_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int64, C.c_int, _P]),
+    "caro_net_destroy": (None, [_P]),
+    "caro_net_boards_per_workgroup": (C.c_int, [_P]),
+    "caro_net_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P]),
     "caro_get_descent": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "caro_select_cancel": (C.c_int, [_P]),
     "caro_expand_backup": (C.c_int, [_P, _P, _P, _P]),

@@ -12,14 +12,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libcaro_hip.so")
-SOURCES = [os.path.join(CSRC, "caro_engine.hip")]
+SOURCES = [os.path.join(CSRC, "caro_engine.hip"), os.path.join(CSRC, "caro_net.hip")]
 DEPS = SOURCES + [os.path.join(CSRC, "caro_rules.h"),
                   os.path.join(HERE, "..", "include", "caro_hip.h"),
                   os.path.join(HERE, "..", "include", "caro_noise.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-ffp-contract=off",          # PUCT / noise arithmetic must not be fused (bit parity with the oracle)
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# caro_engine.hip: PUCT / noise arithmetic must not be fused (bit parity with the oracle)
+PER_FILE = {"caro_engine.hip": ["-ffp-contract=off"], "caro_net.hip": []}
 
 
 def stale():
@@ -32,7 +32,15 @@ def stale():
 def build(force=False, verbose=False):
     if not force and not stale():
         return OUT
-    cmd = [HIPCC] + FLAGS + SOURCES + ["-o", OUT]
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, os.path.basename(src) + ".o")
+        cmd = [HIPCC] + FLAGS + PER_FILE[os.path.basename(src)] + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

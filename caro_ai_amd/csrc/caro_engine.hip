@@ -1092,6 +1092,7 @@ static int dalloc(caro_engine* h, T** p, size_t n) {
 extern "C" {
 
 const char* caro_last_error(void) { return g_err.c_str(); }
+void caro__set_error(const char* msg) { g_err = msg ? msg : ""; }  // for the other translation units
 int caro_version(void) { return 100; }
 
 int caro_key_words(int kind, int n) { return variant_kw(pick_variant(kind, n)); }
@@ -1394,6 +1395,12 @@ int caro_counters(caro_engine* h, int64_t counters[8], void* stream) {
   HIPCHK(hipMemcpyAsync(h->pinned64, h->v.counters, C_N * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   for (int i = 0; i < 8; ++i) counters[i] = i < C_N ? h->pinned64[i] : 0;
+  return 0;
+}
+
+int caro_leaf_counts_dev(caro_engine* h, const int32_t** counts_dev) {
+  if (!h || !counts_dev) return fail(CARO_E_INVAL, "null argument");
+  *counts_dev = h->v.leaf_count;
   return 0;
 }
 

@@ -1,0 +1,385 @@
+// caro_net.hip -- fused float32 inference of the policy/value net (reference
+// lib/model.py:10-94, eval-mode batch-norm folded) for the leaf batch of the
+// self-play engine, as ONE kernel per minibatch.
+//
+// Why a kernel of our own: the leaf count L changes every minibatch and lives in
+// device memory; a torch forward needs L on the host (a stream sync per
+// minibatch) and ~45 launches; MIOpen has no gfx950 database in this image.
+// Here the grid is sized for the maximum and every workgroup reads L itself.
+//
+// Structure (one workgroup = 256 threads = 4 waves = one CU, TB boards):
+//   rows r = board*HW + cell, at most 255 real rows; row 255 is a permanent zero
+//   row (3x3 padding).  Activations X[row][64] float32 stay in LDS for the whole
+//   trunk (two 64 KiB ping-pong buffers, XOR-swizzled 16-byte granules), the
+//   3x3 convolutions are implicit GEMMs on v_mfma_f32_32x32x2_f32:
+//       M = 256 rows (8 row tiles), N = 64 (2 col tiles), K = 9 taps x 64 channels,
+//   wave w owns row tiles 2w, 2w+1 x both col tiles (4 accumulators of 16 regs).
+//   K order inside a tap: MFMA k-half h = lane>>5 carries channel 32h + j, so a
+//   lane's A operands for 4 consecutive k-steps are one ds_read_b128.
+//   Weights stream from L2 one tap (64x64 floats = 16 KiB) at a time through a
+//   single LDS buffer: global loads for tap t+1 are issued before the MFMAs of
+//   tap t and written to LDS after them (issue-early / write-late).
+//   conv_in (K = 18), the 1x1 heads, the two FC heads, tanh and the softmax
+//   run on the VALU in the same kernel.
+// float32 throughout: MFMA f32 is an exact fma chain in k order.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/caro_hip.h"
+
+namespace cnet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NF = 64;          // filters
+constexpr int ZROW = 255;       // permanent zero row
+constexpr int ACT = 256 * NF;   // floats per activation buffer
+constexpr int WCHUNK = 64 * 64; // floats per tap chunk
+constexpr int NRES = 5;
+constexpr int LDS_FLOATS = 2 * ACT + WCHUNK;
+
+struct NetParams {
+  int H, W, HW, A, TB;
+  float slope;
+  const float* w_in;    // [9][2][64]
+  const float* b_in;    // [64]
+  const float* w_res;   // [5][9][4096]  LDS image order (see pack_res_index)
+  const float* b_res;   // [5][64]
+  const float* w_head;  // [3][64]  (value, policy0, policy1)
+  const float* b_head;  // [3]
+  const float* w_v1;    // [20][HW]
+  const float* b_v1;    // [20]
+  const float* w_v2;    // [20]
+  const float* b_v2;    // [1]
+  const float* w_p;     // [A][2*HW]
+  const float* b_p;     // [A]
+};
+
+__device__ __forceinline__ int aoff(int row, int c) {
+  return row * NF + ((((c >> 2) ^ (row & 15)) << 2) | (c & 3));
+}
+__device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+__global__ __launch_bounds__(256, 1) void k_net_forward(NetParams p, const float* __restrict__ planes,
+                                                         const int32_t* __restrict__ counts, int which,
+                                                         float* __restrict__ probs, float* __restrict__ values) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float* bufA = lds;
+  float* bufB = lds + ACT;
+  float* wbuf = lds + 2 * ACT;
+
+  const int L = counts[which];
+  const int row0 = which ? counts[0] : 0;
+  const int board0 = blockIdx.x * p.TB;
+  if (board0 >= L) return;
+  const int nb = min(p.TB, L - board0);
+  const int HW = p.HW;
+  const int R = nb * HW;  // real rows
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 31, h = lane >> 5;
+
+  // zero both activation buffers (dummy rows and the zero row stay zero for ever)
+  for (int k = tid; k < 2 * ACT / 4; k += 256) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // conv_in weights into wbuf: [9][2][64] = 1152 floats
+  for (int k = tid; k < 9 * 2 * NF; k += 256) wbuf[k] = p.w_in[k];
+  __syncthreads();
+
+  // ---- conv_in on the VALU: thread = row
+  {
+    const int r = tid;
+    if (r < R) {
+      const int bi = r / HW, cell = r - bi * HW;
+      const int y = cell / p.W, x = cell - y * p.W;
+      const float* pl = planes + (size_t)(row0 + board0 + bi) * 2 * HW;
+      float in[18];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ny = y + t / 3 - 1, nx = x + t % 3 - 1;
+        const bool ok = ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
+        in[2 * t] = ok ? pl[ny * p.W + nx] : 0.f;
+        in[2 * t + 1] = ok ? pl[HW + ny * p.W + nx] : 0.f;
+      }
+      for (int c4 = 0; c4 < NF / 4; ++c4) {
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = p.b_in[c4 * 4 + u];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+          const float4 w = *reinterpret_cast<const float4*>(wbuf + k * NF + c4 * 4);
+          o[0] = fmaf(in[k], w.x, o[0]);
+          o[1] = fmaf(in[k], w.y, o[1]);
+          o[2] = fmaf(in[k], w.z, o[2]);
+          o[3] = fmaf(in[k], w.w, o[3]);
+        }
+        float4 out = make_float4(leaky(o[0], p.slope), leaky(o[1], p.slope), leaky(o[2], p.slope),
+                                 leaky(o[3], p.slope));
+        *reinterpret_cast<float4*>(bufA + r * NF + ((c4 ^ (r & 15)) << 2)) = out;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- stage weights of (layer 0, tap 0)
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.w_res);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) reinterpret_cast<float4*>(wbuf)[tid + 256 * m] = src[tid + 256 * m];
+  }
+  __syncthreads();
+
+  // per-lane geometry of its two row tiles
+  int rbi[2], ry[2], rx[2];
+  bool rvalid[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int r = (2 * wave + rt) * 32 + i;
+    rvalid[rt] = r < R;
+    const int bi = r / HW, cell = r - bi * HW;
+    rbi[rt] = bi;
+    ry[rt] = cell / p.W;
+    rx[rt] = cell - ry[rt] * p.W;
+  }
+  const int bswz = (i >> 1) & 7;
+
+  float* in = bufA;
+  float* out = bufB;
+  for (int layer = 0; layer < NRES; ++layer) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.f;
+
+    for (int tap = 0; tap < 9; ++tap) {
+      const int chunk = layer * 9 + tap;
+      const bool has_next = chunk + 1 < NRES * 9;
+      float4 wn[4];
+      if (has_next) {
+        const float4* src = reinterpret_cast<const float4*>(p.w_res + (size_t)(chunk + 1) * WCHUNK);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wn[m] = src[tid + 256 * m];
+      }
+      const float* abase[2];
+      int aswz[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int ny = ry[rt] + tap / 3 - 1, nx = rx[rt] + tap % 3 - 1;
+        const bool ok = rvalid[rt] && ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
+        const int nrow = ok ? rbi[rt] * HW + ny * p.W + nx : ZROW;
+        abase[rt] = in + nrow * NF;
+        aswz[rt] = nrow & 15;
+      }
+      const float* bbase0 = wbuf + (h * 64 + i) * 32;
+      const float* bbase1 = wbuf + (h * 64 + 32 + i) * 32;
+#pragma unroll 2
+      for (int q = 0; q < 8; ++q) {
+        const float4 a0 = *reinterpret_cast<const float4*>(abase[0] + (((h * 8 + q) ^ aswz[0]) << 2));
+        const float4 a1 = *reinterpret_cast<const float4*>(abase[1] + (((h * 8 + q) ^ aswz[1]) << 2));
+        const float4 b0 = *reinterpret_cast<const float4*>(bbase0 + ((q ^ bswz) << 2));
+        const float4 b1 = *reinterpret_cast<const float4*>(bbase1 + ((q ^ bswz) << 2));
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[1][1], 0, 0, 0);
+      }
+      __syncthreads();  // every wave is done reading wbuf
+      if (has_next) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) reinterpret_cast<float4*>(wbuf)[tid + 256 * m] = wn[m];
+      }
+      if (tap == 8) {
+        // epilogue: v = v + leaky(conv(v) + b)   (lib/model.py:85-89)
+        const float* bias = p.b_res + layer * NF;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const int col = ct * 32 + i;
+            const float bc = bias[col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = (2 * wave + rt) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              if (row < R) {
+                const int o = aoff(row, col);
+                out[o] = in[o] + leaky(acc[rt][ct][e] + bc, p.slope);
+              }
+            }
+          }
+      }
+      __syncthreads();  // wbuf (and, after tap 8, the new activations) visible to every wave
+    }
+    float* tmp = in;
+    in = out;
+    out = tmp;
+  }
+  // `in` now holds the trunk output; `out` is free scratch
+  float* feat = out;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
+  {
+    const int r = tid;
+    if (r < R) {
+      float s0 = p.b_head[0], s1 = p.b_head[1], s2 = p.b_head[2];
+      for (int g = 0; g < 16; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(in + r * NF + ((g ^ (r & 15)) << 2));
+        const int c = g * 4;
+        s0 = fmaf(v.x, p.w_head[c], s0); s0 = fmaf(v.y, p.w_head[c + 1], s0);
+        s0 = fmaf(v.z, p.w_head[c + 2], s0); s0 = fmaf(v.w, p.w_head[c + 3], s0);
+        s1 = fmaf(v.x, p.w_head[NF + c], s1); s1 = fmaf(v.y, p.w_head[NF + c + 1], s1);
+        s1 = fmaf(v.z, p.w_head[NF + c + 2], s1); s1 = fmaf(v.w, p.w_head[NF + c + 3], s1);
+        s2 = fmaf(v.x, p.w_head[2 * NF + c], s2); s2 = fmaf(v.y, p.w_head[2 * NF + c + 1], s2);
+        s2 = fmaf(v.z, p.w_head[2 * NF + c + 2], s2); s2 = fmaf(v.w, p.w_head[2 * NF + c + 3], s2);
+      }
+      feat[r] = leaky(s0, p.slope);
+      feat[256 + r] = leaky(s1, p.slope);
+      feat[512 + r] = leaky(s2, p.slope);
+    }
+  }
+  __syncthreads();
+  float* hid = feat + 768;      // [TB][20]
+  float* logit = feat + 768 + 20 * 32;  // [TB * A] (TB*A <= 255*... see host check)
+  // value head: Linear(HW,20) + LeakyReLU
+  for (int k = tid; k < nb * 20; k += 256) {
+    const int bi = k / 20, u = k - bi * 20;
+    float s = p.b_v1[u];
+    const float* w = p.w_v1 + u * HW;
+    const float* f = feat + bi * HW;
+    for (int c = 0; c < HW; ++c) s = fmaf(f[c], w[c], s);
+    hid[k] = leaky(s, p.slope);
+  }
+  // policy head: Linear(2*HW, A) on the (c, y, x)-flattened planes
+  for (int k = tid; k < nb * p.A; k += 256) {
+    const int bi = k / p.A, a = k - bi * p.A;
+    float s = p.b_p[a];
+    const float* w = p.w_p + (size_t)a * 2 * HW;
+    const float* f0 = feat + 256 + bi * HW;
+    const float* f1 = feat + 512 + bi * HW;
+    for (int c = 0; c < HW; ++c) s = fmaf(f0[c], w[c], s);
+    for (int c = 0; c < HW; ++c) s = fmaf(f1[c], w[HW + c], s);
+    logit[k] = s;
+  }
+  __syncthreads();
+  // Linear(20,1) + tanh; softmax statistics per board
+  float* stat = logit + 256 * 4;  // [TB][2] max, sum  (logit region sized 1024 floats)
+  if (tid < nb) {
+    float s = p.b_v2[0];
+    for (int u = 0; u < 20; ++u) s = fmaf(hid[tid * 20 + u], p.w_v2[u], s);
+    values[row0 + board0 + tid] = tanhf(s);
+    float mx = -3.4e38f;
+    for (int a = 0; a < p.A; ++a) mx = fmaxf(mx, logit[tid * p.A + a]);
+    float sum = 0.f;
+    for (int a = 0; a < p.A; ++a) sum += __expf(logit[tid * p.A + a] - mx);
+    stat[2 * tid] = mx;
+    stat[2 * tid + 1] = sum;
+  }
+  __syncthreads();
+  for (int k = tid; k < nb * p.A; k += 256) {
+    const int bi = k / p.A;
+    probs[(size_t)(row0 + board0) * p.A + k] = __expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
+  }
+}
+
+}  // namespace cnet
+
+// =================================================================== host side
+extern "C" void caro__set_error(const char* msg);  // caro_engine.hip
+
+struct caro_net {
+  cnet::NetParams p;
+  float* dev;
+  int device;
+};
+
+static int nfail(int code, const std::string& m) {
+  caro__set_error(m.c_str());
+  return code;
+}
+
+extern "C" {
+
+// number of floats caro_net_create expects for an H x W board with A actions
+int64_t caro_net_packed_size(int H, int W, int A) {
+  const int64_t HW = (int64_t)H * W;
+  return 9 * 2 * 64 + 64 + (int64_t)cnet::NRES * 9 * cnet::WCHUNK + cnet::NRES * 64 + 3 * 64 + 3 +
+         20 * HW + 20 + 20 + 1 + (int64_t)A * 2 * HW + A;
+}
+
+int caro_net_create(int H, int W, int A, float negative_slope, const float* packed_host, int64_t n_floats,
+                    int device_id, caro_net** out) {
+  if (!packed_host || !out) return nfail(CARO_E_INVAL, "null argument");
+  if (H < 2 || W < 2 || H > 15 || W > 15 || A < 1 || A > 255) return nfail(CARO_E_INVAL, "unsupported board / action count");
+  if (n_floats != caro_net_packed_size(H, W, A)) return nfail(CARO_E_INVAL, "packed weight buffer has the wrong size");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return nfail(CARO_E_NODEV, "no HIP device: libcaro_hip needs a GPU (there is no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return nfail(CARO_E_INVAL, "device_id out of range");
+  if (hipSetDevice(device_id) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
+  caro_net* n = new caro_net();
+  n->device = device_id;
+  if (hipMalloc((void**)&n->dev, n_floats * sizeof(float)) != hipSuccess) {
+    delete n;
+    return nfail(CARO_E_NOMEM, "hipMalloc failed");
+  }
+  if (hipMemcpy(n->dev, packed_host, n_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(n->dev);
+    delete n;
+    return nfail(CARO_E_HIP, "hipMemcpy failed");
+  }
+  cnet::NetParams& p = n->p;
+  const int HW = H * W;
+  p.H = H; p.W = W; p.HW = HW; p.A = A; p.TB = 255 / HW; p.slope = negative_slope;
+  if (p.TB * A > 1024 || p.TB > 32) p.TB = p.TB > 32 ? 32 : p.TB;
+  const float* q = n->dev;
+  p.w_in = q;   q += 9 * 2 * 64;
+  p.b_in = q;   q += 64;
+  p.w_res = q;  q += (size_t)cnet::NRES * 9 * cnet::WCHUNK;
+  p.b_res = q;  q += cnet::NRES * 64;
+  p.w_head = q; q += 3 * 64;
+  p.b_head = q; q += 3;
+  p.w_v1 = q;   q += 20 * HW;
+  p.b_v1 = q;   q += 20;
+  p.w_v2 = q;   q += 20;
+  p.b_v2 = q;   q += 1;
+  p.w_p = q;    q += (size_t)A * 2 * HW;
+  p.b_p = q;    q += A;
+  *out = n;
+  return 0;
+}
+
+void caro_net_destroy(caro_net* n) {
+  if (!n) return;
+  (void)hipFree(n->dev);
+  delete n;
+}
+
+int caro_net_boards_per_workgroup(const caro_net* n) { return n ? n->p.TB : 0; }
+
+int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which, int64_t max_rows,
+                     float* probs_dev, float* values_dev, void* stream) {
+  if (!n || !planes_dev || !counts_dev || !probs_dev || !values_dev) return nfail(CARO_E_INVAL, "null argument");
+  if (which != 0 && which != 1) return nfail(CARO_E_INVAL, "which must be 0 or 1");
+  if (max_rows <= 0) return 0;
+  const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
+  hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(256), 0, (hipStream_t)stream, n->p, planes_dev,
+                     counts_dev, which, probs_dev, values_dev);
+  if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
+  return 0;
+}
+
+}  // extern "C"

@@ -132,6 +132,9 @@ int caro_get_descent(caro_engine* h, int game, int b, int32_t* info_dev, float* 
 int caro_select_cancel(caro_engine* h);
 /* Blocks until the select on `stream` has finished; counts[0..1] = L0, L1. */
 int caro_leaf_counts(caro_engine* h, int32_t counts[2], void* stream);
+/* Device address of the two leaf counts {L0, L1} (i32[2], engine-owned), so that a consumer kernel
+ * (caro_net_forward) can read them without a host round trip. */
+int caro_leaf_counts_dev(caro_engine* h, const int32_t** counts_dev);
 /* Second half (mcts.py:281-287): _create_node (:178-190) for every unique leaf
  * with prior row probs_dev f32[L, A] (softmax ALREADY applied, mcts.py:216) and
  * _backup (:225-246) of terminals (sim order) then new leaves (first-seen
@@ -191,6 +194,22 @@ int caro_backup_path(caro_engine* h, int game, int store, float value, int value
  * *n_nodes set on return (synchronises). */
 int caro_dump_tree(caro_engine* h, int game, int store, int64_t cap, uint64_t* keys_dev, int32_t* N_dev,
                    float* W_dev, float* Q_dev, float* P_dev, int32_t* strong_dev, int64_t* n_nodes, void* stream);
+
+/* ---- fused float32 policy/value net (lib/model.py:10-94, Net.forward in eval mode + F.softmax of
+ *      lib/mcts.py:216) for the leaf batch.  Weights: one flat float32 host buffer in the order
+ *      conv_in [9 taps][2][64], b[64]; 5 x 9 tap chunks of 4096 floats in the kernel's LDS image order
+ *      (caro_ai_amd/net_hip.py packs them, batch-norm folded), b[5][64]; heads [3][64], b[3];
+ *      value.0 [20][HW], b[20]; value.2 [20], b[1]; policy.0 [A][2HW], b[A]. ---- */
+typedef struct caro_net caro_net;
+int64_t caro_net_packed_size(int H, int W, int A);
+int caro_net_create(int H, int W, int A, float negative_slope, const float* packed_host, int64_t n_floats,
+                    int device_id, caro_net** out);
+void caro_net_destroy(caro_net* n);
+int caro_net_boards_per_workgroup(const caro_net* n);
+/* rows [row0, row0 + L) of planes_dev f32[max_rows,2,H,W] -> probs_dev f32[.,A] (softmaxed), values_dev f32[.]
+ * with L = counts_dev[which] and row0 = which ? counts_dev[0] : 0, both read ON DEVICE. */
+int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which, int64_t max_rows,
+                     float* probs_dev, float* values_dev, void* stream);
 
 #ifdef __cplusplus
 }
