@@ -1,0 +1,84 @@
+"""The fused HIP net kernel against a plain PyTorch float32 reference of the
+same op (Net.eval() + softmax, computed on the CPU in float32 and float64)."""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(shape, A, weights=None, seed=0):
+    from caro_ai_amd.lib.model import Net
+    torch.manual_seed(seed)
+    net = Net(shape, A)
+    if weights:
+        net.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", weights), map_location="cpu"))
+    else:
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.5, 0.5)
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.uniform_(-0.3, 0.3)
+    return net.eval()
+
+
+def _boards(L, shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand((L,) + shape, generator=g) < 0.3).float()
+    x[:, 1] *= (1 - x[:, 0])
+    return x
+
+
+@pytest.mark.parametrize("shape,A,weights", [((2, 6, 7), 7, "best_026_12000.dat"), ((2, 3, 3), 9, "best_005_00900.dat"),
+                                             ((2, 15, 15), 225, None), ((2, 5, 5), 25, None), ((2, 10, 10), 100, None)])
+@pytest.mark.parametrize("L", [1, 5, 6, 7, 29, 300])
+def test_hip_net_matches_torch_fp32(shape, A, weights, L):
+    from caro_ai_amd.net_hip import HipNet
+    net = _net(shape, A, weights)
+    x = _boards(L, shape, L)
+    with torch.no_grad():
+        lg, vl = net(x)
+        p_ref = torch.softmax(lg, dim=1)
+        lg64, vl64 = net.double()(x.double())
+        p64 = torch.softmax(lg64, dim=1)
+    net.float()
+    hn = HipNet(net, "cuda:0")
+    p, v = hn(x.to("cuda:0"))
+    torch.cuda.synchronize()
+    p, v = p.cpu(), v.cpu()
+    # stated tolerance: float32 re-association only. |dP| < 2e-5 absolute (P in [0,1]), |dv| < 2e-5
+    assert (p - p_ref).abs().max().item() < 2e-5, (p - p_ref).abs().max().item()
+    assert (v - vl[:, 0]).abs().max().item() < 2e-5
+    # and the kernel is no further from the float64 truth than torch's own float32 forward (x4 slack)
+    e_hip = (p.double() - p64).abs().max().item()
+    e_ref = (p_ref.double() - p64).abs().max().item()
+    assert e_hip < max(4 * e_ref, 1e-6), (e_hip, e_ref)
+    assert torch.allclose(p.sum(1), torch.ones(L), atol=1e-5)
+    hn.close()
+
+
+def test_hip_net_device_count_and_second_net_offset():
+    """rows come from counts on the device: which = 1 starts at counts[0]."""
+    from caro_ai_amd.net_hip import HipNet
+    net = _net((2, 6, 7), 7, "best_026_12000.dat")
+    hn = HipNet(net, "cuda:0")
+    x = _boards(50, (2, 6, 7), 3).to("cuda:0")
+    counts = torch.tensor([20, 30], dtype=torch.int32, device="cuda:0")
+    probs = torch.full((64, 7), -1.0, device="cuda:0")
+    values = torch.full((64,), -9.0, device="cuda:0")
+    xx = torch.zeros((64, 2, 6, 7), device="cuda:0")
+    xx[:50] = x
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    hn.forward_dev(xx, counts.data_ptr(), 1, 64, probs, values, st)
+    torch.cuda.synchronize()
+    assert (probs[:20] == -1).all() and (probs[50:] == -1).all() and (values[50:] == -9).all()
+    p_all, v_all = hn(x)
+    torch.cuda.synchronize()
+    # same boards, different position inside the workgroup tile: same arithmetic, same bits
+    assert torch.allclose(probs[20:50], p_all[20:50], atol=1e-6) and torch.allclose(values[20:50], v_all[20:50], atol=1e-6)
+    hn.close()
