@@ -92,8 +92,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--game", default="c4", choices=["c4", "gomoku15"])
     ap.add_argument("--weights", default=os.path.join(ROOT, "tests", "golden", "weights", "best_026_12000.dat"))
-    ap.add_argument("--net", default="gemm", choices=["gemm", "folded", "net"],
-                    help="inference form of lib/model.py Net: gather+GEMM (default), BN-folded conv2d, or the module as is")
+    ap.add_argument("--net", default="hip", choices=["hip", "gemm", "folded", "net"],
+                    help="inference form of lib/model.py Net: fused HIP fp32 MFMA kernel (default), torch gather+GEMM, "
+                         "BN-folded conv2d, or the module as is")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the kernels")
@@ -115,9 +116,14 @@ def main():
     else:
         game, weights, sbt0 = TicTacToe(15, 5), None, 10
     net, wtag = load_net(game, device, weights)
-    fnet = {"gemm": GemmNet, "folded": FoldedNet, "net": lambda n: n}[args.net](net).to(device).eval()
     G, S, B = args.games, args.searches, args.batch
-    eng = SelfPlayEngine(game, G, evaluators=[torch_evaluator(fnet, form="net")], max_batch=B, steps_before_tau_0=sbt0,
+    if args.net == "hip":
+        from caro_ai_amd.net_hip import HipNet
+        evaluators = [HipNet(net, str(device))]
+    else:
+        fnet = {"gemm": GemmNet, "folded": FoldedNet, "net": lambda n: n}[args.net](net).to(device).eval()
+        evaluators = [torch_evaluator(fnet, form="net")]
+    eng = SelfPlayEngine(game, G, evaluators=evaluators, max_batch=B, steps_before_tau_0=sbt0,
                          seed=0, device=str(device), searches_hint=S, **parallel.shard(G, rank, world))
 
     n_tuples = 0
@@ -160,7 +166,7 @@ def main():
 
     delta = {k: c1[k] - c0[k] for k in c1}
     tot = torch.tensor([delta["expansions"], delta["sims"], delta["levels"], delta["plies"], delta["finished"],
-                        eng.net_rows - rows0], dtype=torch.float64, device=device)
+                        delta["expansions"]], dtype=torch.float64, device=device)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     parallel.allreduce_sum(tot)
     parallel.allreduce_max(tmax)
@@ -201,7 +207,7 @@ def main():
             "data": "synthetic (self-play from empty boards; net weights: %s)" % wtag,
             "config": {"workload": "%s %d concurrent self-play games/GPU, %dx%d = %d sims/move, tau=1 for %d plies"
                                    % ("Connect4 6x7" if args.game == "c4" else "m,n,k 15x15 k=5", G, S, B, S * B, sbt0),
-                       "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py %s fp32" % args.net,
+                       "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py Net, %s fp32" % {"hip": "fused HIP MFMA kernel", "gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net],
                        "parallelism": "games sharded x%d, all-gather of tuples per step" % world},
             "per_gpu": exp_all / dt_max / world,
             "sims_per_s": sims_all / dt_max, "plies_per_s": plies_all / dt_max, "games_per_s": fin_all / dt_max,

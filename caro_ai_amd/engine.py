@@ -51,7 +51,7 @@ class SelfPlayEngine:
     def __init__(self, game, n_games, net1=None, net2=None, evaluators=None, n_stores=1, max_batch=None,
                  node_cap=None, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, first_player_mode=2,
                  c_puct=cfg.C_PUCT, alpha=cfg.ALPHA, explore=cfg.EXPLORE, seed=0, uid_base=0, uid_stride=None,
-                 device="cuda:0", searches_hint=cfg.MCTS_SEARCHES):
+                 device="cuda:0", searches_hint=cfg.MCTS_SEARCHES, inference="hip"):
         if not torch.cuda.is_available():
             raise _lib.CaroError("SelfPlayEngine needs a GPU (torch.cuda.is_available() is False); "
                                  "there is no CPU fallback")
@@ -66,8 +66,14 @@ class SelfPlayEngine:
         self.max_batch = int(max_batch or cfg.MCTS_BATCH_SIZE)
         if evaluators is None:
             nets = [net1] if net2 is None or net2 is net1 else [net1, net2]
-            evaluators = [torch_evaluator(n.to(self.device)) for n in nets]
+            if inference == "hip":
+                from caro_ai_amd.net_hip import HipNet
+                evaluators = [HipNet(n, str(self.device)) for n in nets]
+            else:
+                evaluators = [torch_evaluator(n.to(self.device), form=inference) for n in nets]
         self.evaluators = list(evaluators)
+        # evaluators that read the leaf count on the device let a whole move be enqueued without a host sync
+        self.async_net = all(getattr(e, "device_counts", False) for e in self.evaluators)
         self.n_nets = len(self.evaluators)
         assert self.n_nets in (1, 2)
         if node_cap is None:
@@ -93,6 +99,9 @@ class SelfPlayEngine:
         self._probs = torch.zeros((rows, self.A), dtype=torch.float32, device=self.device)
         self._values = torch.zeros(rows, dtype=torch.float32, device=self.device)
         self._counts = (C.c_int32 * 2)()
+        cd = C.c_void_p()
+        _lib.check(self.L.caro_leaf_counts_dev(self.h, C.byref(cd)))
+        self._counts_dev = cd
         self.maxply = self.HW
         self.net_rows = 0
         self.net_calls = 0
@@ -135,6 +144,13 @@ class SelfPlayEngine:
             nz = nz.to(self.device, dtype=torch.float64).contiguous()
             assert nz.numel() == self.G * batch * self.A
         _lib.check(self.L.caro_select(self.h, batch, mb_index, _ptr(nz), _ptr(self.planes), _ptr(self.leaf_keys), st))
+        if self.async_net:
+            # fused HIP net: L is read on the device, nothing waits on the host
+            for which, ev in enumerate(self.evaluators):
+                ev.forward_dev(self.planes, self._counts_dev, which, self.G * batch, self._probs, self._values, st)
+            self.net_calls += self.n_nets
+            _lib.check(self.L.caro_expand_backup(self.h, _ptr(self._probs), _ptr(self._values), st))
+            return None
         _lib.check(self.L.caro_leaf_counts(self.h, self._counts, st))
         l0, l1 = self._counts[0], self._counts[1]
         if l0:
