@@ -30,7 +30,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
+
+
+def load_pmc():
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_r01.json), keyed by kernel."""
+    path = os.path.join(ROOT, "profiles", "pmc_r01.json")
+    try:
+        return {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(path))["kernels"].items()}
+    except Exception:
+        return {}
 
 
 def load_net(game, device, weights):
@@ -174,27 +184,35 @@ def main():
     exp_all, sims_all, levels_all, plies_all, fin_all, rows_all = [float(x) for x in tot.tolist()]
 
     if rank == 0:
+        pmc = load_pmc() if args.game == "c4" and G == 1024 else {}
         A, KW, HW = game.action_space, game.key_words, game.obs_shape[1] * game.obs_shape[2]
         bytes_per_level = 12 * A + 8 * KW + 28            # N,Q,P rows + key probe + backup RMW
         bytes_per_exp = 16 * HW + 20 * A + 8 * KW + 12
-        roofline = None
+        # FLOPs of one leaf through lib/model.py Net (2 x MAC): conv_in, 5 residual 3x3 convs, 1x1 heads, FC heads
+        flops_per_leaf = 2.0 * (HW * 64 * 18 + 5 * HW * 64 * 576 + HW * 3 * 64 + 20 * HW + 20 + 2 * HW * A)
+        roofline = roofline_tree = None
         if prof is not None and prof["select"][1] > 0:
             ms, n = prof["select"]
             avg_s = ms * 1e-3 / n
             levels_per_launch = delta["levels"] / n
             achieved = levels_per_launch * bytes_per_level / avg_s / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_select", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "avg_launch_us": avg_s * 1e6, "launches": n,
-                        "levels_per_launch": levels_per_launch, "bytes_per_level": bytes_per_level,
-                        "other_kernels_us": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in prof.items()
-                                             if k != "select"}}
-            pmc = os.path.join(ROOT, "profiles", "pmc_select.json")
-            if os.path.exists(pmc):
-                try:
-                    roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    pass
+            roofline_tree = {"bound": "hbm", "kernel": "k_select", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("k_select"),
+                             "avg_launch_us": avg_s * 1e6, "launches": n,
+                             "levels_per_launch": levels_per_launch, "bytes_per_level": bytes_per_level,
+                             "other_kernels_us": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in prof.items()
+                                                  if k not in ("select", "net")}}
+        if prof is not None and prof.get("net", (0, 0))[1] > 0:
+            ms, n = prof["net"]
+            avg_s = ms * 1e-3 / n
+            leaves_per_launch = delta["expansions"] / n
+            achieved = leaves_per_launch * flops_per_leaf / avg_s / 1e12
+            roofline = {"bound": "mfma", "kernel": "k_net_forward", "achieved": achieved, "peak": MFMA_F32_PEAK_TFS,
+                        "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFS, "traffic": pmc.get("k_net_forward"),
+                        "avg_launch_us": avg_s * 1e6, "launches": n, "leaves_per_launch": leaves_per_launch,
+                        "flops_per_leaf": flops_per_leaf}
+        if roofline is None:  # torch evaluators: the net is not our kernel; the tree walk is the dominant own kernel
+            roofline = roofline_tree
         out = {
             "metric": "self-play MCTS node-expansions/sec/GPU (Connect4, 200 sims/move); 1->8 GPU scaling"
             if args.game == "c4" else "self-play MCTS node-expansions/sec/GPU (15x15 k=5)",
@@ -215,6 +233,7 @@ def main():
             "expansions_per_sim": exp_all / max(1.0, sims_all),
             "algorithmic_GBps": (levels_all * bytes_per_level + exp_all * bytes_per_exp) / dt_max / 1e9,
             "roofline": roofline,
+            "roofline_tree": roofline_tree,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.game, S, B, sbt0, weights, args.cpu_seconds)

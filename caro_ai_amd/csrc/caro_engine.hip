@@ -1041,11 +1041,11 @@ struct caro_engine {
   std::vector<hipEvent_t> ev;      // pairs: [2*i] start, [2*i+1] stop
   std::vector<int> ev_kind;        // kernel id of pair i
   size_t ev_used;
-  double prof_ms[4];
-  long long prof_n[4];
+  double prof_ms[8];
+  long long prof_n[8];
 };
 
-enum ProfKind { PK_SELECT = 0, PK_COMPACT = 1, PK_EXPAND = 2, PK_STEP = 3 };
+enum ProfKind { PK_SELECT = 0, PK_COMPACT = 1, PK_EXPAND = 2, PK_STEP = 3, PK_NET = 4, PK_N = 8 };
 
 static void prof_flush(caro_engine* h) {
   for (size_t i = 0; i < h->ev_used; ++i) {
@@ -1224,7 +1224,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   h->select_pending = 0;
   h->prof_on = 0;
   h->ev_used = 0;
-  for (int i = 0; i < 4; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+  for (int i = 0; i < 8; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
   View& v = h->v;
   memset(&v, 0, sizeof v);
   v.gp = make_gp(cfg->game_kind, cfg->n, cfg->k);
@@ -1429,10 +1429,18 @@ int caro_profile_enable(caro_engine* h, int on) {
   return 0;
 }
 
-int caro_profile_read(caro_engine* h, double ms[4], int64_t launches[4], int reset) {
+int caro_profile_begin(caro_engine* h, int kind, void* stream) {
+  if (!h || kind < 0 || kind >= PK_N) return -1;
+  return prof_begin(h, kind, (hipStream_t)stream);
+}
+void caro_profile_end(caro_engine* h, int slot, void* stream) {
+  if (h) prof_end(h, slot, (hipStream_t)stream);
+}
+
+int caro_profile_read(caro_engine* h, double ms[8], int64_t launches[8], int reset) {
   if (!h || !ms || !launches) return fail(CARO_E_INVAL, "null argument");
   prof_flush(h);
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
     ms[i] = h->prof_ms[i];
     launches[i] = h->prof_n[i];
     if (reset) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }

@@ -105,6 +105,7 @@ class SelfPlayEngine:
         self.maxply = self.HW
         self.net_rows = 0
         self.net_calls = 0
+        self._prof = False
 
     def close(self):
         if getattr(self, "h", None):
@@ -146,8 +147,11 @@ class SelfPlayEngine:
         _lib.check(self.L.caro_select(self.h, batch, mb_index, _ptr(nz), _ptr(self.planes), _ptr(self.leaf_keys), st))
         if self.async_net:
             # fused HIP net: L is read on the device, nothing waits on the host
+            slot = self.L.caro_profile_begin(self.h, 4, st) if self._prof else -1
             for which, ev in enumerate(self.evaluators):
                 ev.forward_dev(self.planes, self._counts_dev, which, self.G * batch, self._probs, self._values, st)
+            if slot >= 0:
+                self.L.caro_profile_end(self.h, slot, st)
             self.net_calls += self.n_nets
             _lib.check(self.L.caro_expand_backup(self.h, _ptr(self._probs), _ptr(self._values), st))
             return None
@@ -212,13 +216,14 @@ class SelfPlayEngine:
 
     def profile(self, on=True):
         _lib.check(self.L.caro_profile_enable(self.h, 1 if on else 0))
+        self._prof = bool(on)
 
     def profile_read(self, reset=True):
         """{kernel: (total ms, launches)} measured with HIP events on the launch stream"""
-        ms = (C.c_double * 4)()
-        n = (C.c_int64 * 4)()
+        ms = (C.c_double * 8)()
+        n = (C.c_int64 * 8)()
         _lib.check(self.L.caro_profile_read(self.h, ms, n, 1 if reset else 0))
-        return {k: (ms[i], n[i]) for i, k in enumerate(["select", "compact", "expand_backup", "step"])}
+        return {k: (ms[i], n[i]) for i, k in enumerate(["select", "compact", "expand_backup", "step", "net"])}
 
     def live_games(self):
         out = C.c_int32(0)

@@ -164,11 +164,14 @@ int caro_drain_tuples(caro_engine* h, int64_t cap, uint64_t* states_dev, int32_t
 /* counters[8] (host array): sims, levels, expansions, terminals, dropped
  * duplicates, node-pool overflows, plies, finished games.  Synchronises. */
 int caro_counters(caro_engine* h, int64_t counters[8], void* stream);
-/* HIP-event timing of the engine's own kernels on the stream they are launched on
- * (bench.py's live roofline).  Kinds: 0 select, 1 scan+encode, 2 expand+backup, 3 step.
+/* HIP-event timing of the path's kernels on the stream they are launched on (bench.py's live
+ * roofline).  Kinds: 0 select, 1 scan+encode, 2 expand+backup, 3 step, 4 net forward (bracketed by the
+ * caller with caro_profile_begin/_end around caro_net_forward), 5-7 free.
  * caro_profile_read synchronises on the recorded events; ms[] / launches[] are running totals. */
 int caro_profile_enable(caro_engine* h, int on);
-int caro_profile_read(caro_engine* h, double ms[4], int64_t launches[4], int reset);
+int caro_profile_begin(caro_engine* h, int kind, void* stream); /* returns a slot, or -1 when profiling is off */
+void caro_profile_end(caro_engine* h, int slot, void* stream);
+int caro_profile_read(caro_engine* h, double ms[8], int64_t launches[8], int reset);
 /* number of live (unfinished) games; synchronises */
 int caro_live_games(caro_engine* h, int32_t* live, void* stream);
 
