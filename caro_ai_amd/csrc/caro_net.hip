@@ -7,13 +7,14 @@
 // minibatch) and ~45 launches; MIOpen has no gfx950 database in this image.
 // Here the grid is sized for the maximum and every workgroup reads L itself.
 //
-// Structure (one workgroup = 256 threads = 4 waves = one CU, TB boards):
+// Structure (one workgroup = 512 threads = 8 waves = one CU, two waves per SIMD so that one wave's
+// MFMAs cover the other's LDS operand reads; TB boards):
 //   rows r = board*HW + cell, at most 255 real rows; row 255 is a permanent zero
 //   row (3x3 padding).  Activations X[row][64] float32 stay in LDS for the whole
 //   trunk (two 64 KiB ping-pong buffers, XOR-swizzled 16-byte granules), the
 //   3x3 convolutions are implicit GEMMs on v_mfma_f32_32x32x2_f32:
 //       M = 256 rows (8 row tiles), N = 64 (2 col tiles), K = 9 taps x 64 channels,
-//   wave w owns row tiles 2w, 2w+1 x both col tiles (4 accumulators of 16 regs).
+//   wave w owns row tile w x both col tiles (2 accumulators of 16 regs).
 //   K order inside a tap: MFMA k-half h = lane>>5 carries channel 32h + j, so a
 //   lane's A operands for 4 consecutive k-steps are one ds_read_b128.
 //   Weights stream from L2 one tap (64x64 floats = 16 KiB) at a time through a
@@ -63,7 +64,9 @@ __device__ __forceinline__ int aoff(int row, int c) {
 }
 __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
 
-__global__ __launch_bounds__(256, 1) void k_net_forward(NetParams p, const float* __restrict__ planes,
+constexpr int NT = 512;  // threads per workgroup
+
+__global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float* __restrict__ planes,
                                                          const int32_t* __restrict__ counts, int which,
                                                          float* __restrict__ probs, float* __restrict__ values) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -83,14 +86,15 @@ __global__ __launch_bounds__(256, 1) void k_net_forward(NetParams p, const float
   const int i = lane & 31, h = lane >> 5;
 
   // zero both activation buffers (dummy rows and the zero row stay zero for ever)
-  for (int k = tid; k < 2 * ACT / 4; k += 256) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = tid; k < 2 * ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   // conv_in weights into wbuf: [9][2][64] = 1152 floats
-  for (int k = tid; k < 9 * 2 * NF; k += 256) wbuf[k] = p.w_in[k];
+  for (int k = tid; k < 9 * 2 * NF; k += NT) wbuf[k] = p.w_in[k];
   __syncthreads();
 
-  // ---- conv_in on the VALU: thread = row
+  // ---- conv_in on the VALU: two threads per row, 32 output channels each
   {
-    const int r = tid;
+    const int r = tid & 255;
+    const int chalf = tid >> 8;
     if (r < R) {
       const int bi = r / HW, cell = r - bi * HW;
       const int y = cell / p.W, x = cell - y * p.W;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256, 1) void k_net_forward(NetParams p, const float
         in[2 * t] = ok ? pl[ny * p.W + nx] : 0.f;
         in[2 * t + 1] = ok ? pl[HW + ny * p.W + nx] : 0.f;
       }
-      for (int c4 = 0; c4 < NF / 4; ++c4) {
+      for (int c4 = chalf * 8; c4 < chalf * 8 + 8; ++c4) {
         float o[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = p.b_in[c4 * 4 + u];
@@ -127,102 +131,87 @@ __global__ __launch_bounds__(256, 1) void k_net_forward(NetParams p, const float
   {
     const float4* src = reinterpret_cast<const float4*>(p.w_res);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) reinterpret_cast<float4*>(wbuf)[tid + 256 * m] = src[tid + 256 * m];
+    for (int m = 0; m < 2; ++m) reinterpret_cast<float4*>(wbuf)[tid + NT * m] = src[tid + NT * m];
   }
   __syncthreads();
 
-  // per-lane geometry of its two row tiles
-  int rbi[2], ry[2], rx[2];
-  bool rvalid[2];
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    const int r = (2 * wave + rt) * 32 + i;
-    rvalid[rt] = r < R;
-    const int bi = r / HW, cell = r - bi * HW;
-    rbi[rt] = bi;
-    ry[rt] = cell / p.W;
-    rx[rt] = cell - ry[rt] * p.W;
-  }
+  // per-lane geometry of its row tile
+  const int myrow = wave * 32 + i;
+  const bool rvalid = myrow < R;
+  const int rbi = myrow / HW;
+  const int rcell = myrow - rbi * HW;
+  const int ry = rcell / p.W, rx = rcell - ry * p.W;
   const int bswz = (i >> 1) & 7;
 
   float* in = bufA;
   float* out = bufB;
   for (int layer = 0; layer < NRES; ++layer) {
-    f32x16 acc[2][2];
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.f;
-
+    for (int e = 0; e < 16; ++e) {
+      acc0[e] = 0.f;
+      acc1[e] = 0.f;
+    }
     for (int tap = 0; tap < 9; ++tap) {
       const int chunk = layer * 9 + tap;
       const bool has_next = chunk + 1 < NRES * 9;
-      float4 wn[4];
+      float4 wn[2];
       if (has_next) {
         const float4* src = reinterpret_cast<const float4*>(p.w_res + (size_t)(chunk + 1) * WCHUNK);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) wn[m] = src[tid + 256 * m];
+        for (int m = 0; m < 2; ++m) wn[m] = src[tid + NT * m];
       }
-      const float* abase[2];
-      int aswz[2];
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int ny = ry[rt] + tap / 3 - 1, nx = rx[rt] + tap % 3 - 1;
-        const bool ok = rvalid[rt] && ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
-        const int nrow = ok ? rbi[rt] * HW + ny * p.W + nx : ZROW;
-        abase[rt] = in + nrow * NF;
-        aswz[rt] = nrow & 15;
-      }
+      const int ny = ry + tap / 3 - 1, nx = rx + tap % 3 - 1;
+      const bool ok = rvalid && ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
+      const int nrow = ok ? rbi * HW + ny * p.W + nx : ZROW;
+      const float* abase = in + nrow * NF;
+      const int aswz = nrow & 15;
       const float* bbase0 = wbuf + (h * 64 + i) * 32;
       const float* bbase1 = wbuf + (h * 64 + 32 + i) * 32;
-#pragma unroll 2
+      // software pipeline: operands of group q+1 are read while the MFMAs of group q issue
+      float4 a = *reinterpret_cast<const float4*>(abase + (((h * 8) ^ aswz) << 2));
+      float4 b0 = *reinterpret_cast<const float4*>(bbase0 + (bswz << 2));
+      float4 b1 = *reinterpret_cast<const float4*>(bbase1 + (bswz << 2));
+#pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float4 a0 = *reinterpret_cast<const float4*>(abase[0] + (((h * 8 + q) ^ aswz[0]) << 2));
-        const float4 a1 = *reinterpret_cast<const float4*>(abase[1] + (((h * 8 + q) ^ aswz[1]) << 2));
-        const float4 b0 = *reinterpret_cast<const float4*>(bbase0 + ((q ^ bswz) << 2));
-        const float4 b1 = *reinterpret_cast<const float4*>(bbase1 + ((q ^ bswz) << 2));
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[1][1], 0, 0, 0);
+        float4 an, b0n, b1n;
+        if (q < 7) {
+          an = *reinterpret_cast<const float4*>(abase + (((h * 8 + q + 1) ^ aswz) << 2));
+          b0n = *reinterpret_cast<const float4*>(bbase0 + (((q + 1) ^ bswz) << 2));
+          b1n = *reinterpret_cast<const float4*>(bbase1 + (((q + 1) ^ bswz) << 2));
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+        if (q < 7) {
+          a = an;
+          b0 = b0n;
+          b1 = b1n;
+        }
       }
       __syncthreads();  // every wave is done reading wbuf
       if (has_next) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) reinterpret_cast<float4*>(wbuf)[tid + 256 * m] = wn[m];
+        for (int m = 0; m < 2; ++m) reinterpret_cast<float4*>(wbuf)[tid + NT * m] = wn[m];
       }
       if (tap == 8) {
         // epilogue: v = v + leaky(conv(v) + b)   (lib/model.py:85-89)
         const float* bias = p.b_res + layer * NF;
+        const float bc0 = bias[i], bc1 = bias[32 + i];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            const int col = ct * 32 + i;
-            const float bc = bias[col];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int row = (2 * wave + rt) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-              if (row < R) {
-                const int o = aoff(row, col);
-                out[o] = in[o] + leaky(acc[rt][ct][e] + bc, p.slope);
-              }
-            }
+        for (int e = 0; e < 16; ++e) {
+          const int row = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < R) {
+            const int o0 = aoff(row, i), o1 = aoff(row, 32 + i);
+            out[o0] = in[o0] + leaky(acc0[e] + bc0, p.slope);
+            out[o1] = in[o1] + leaky(acc1[e] + bc1, p.slope);
           }
+        }
       }
       __syncthreads();  // wbuf (and, after tap 8, the new activations) visible to every wave
     }
@@ -255,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void k_net_forward(NetParams p, const float
   float* hid = feat + 768;      // [TB][20]
   float* logit = feat + 768 + 20 * 32;  // [TB * A] (TB*A <= 255*... see host check)
   // value head: Linear(HW,20) + LeakyReLU
-  for (int k = tid; k < nb * 20; k += 256) {
+  for (int k = tid; k < nb * 20; k += NT) {
     const int bi = k / 20, u = k - bi * 20;
     float s = p.b_v1[u];
     const float* w = p.w_v1 + u * HW;
@@ -264,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void k_net_forward(NetParams p, const float
     hid[k] = leaky(s, p.slope);
   }
   // policy head: Linear(2*HW, A) on the (c, y, x)-flattened planes
-  for (int k = tid; k < nb * p.A; k += 256) {
+  for (int k = tid; k < nb * p.A; k += NT) {
     const int bi = k / p.A, a = k - bi * p.A;
     float s = p.b_p[a];
     const float* w = p.w_p + (size_t)a * 2 * HW;
@@ -289,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void k_net_forward(NetParams p, const float
     stat[2 * tid + 1] = sum;
   }
   __syncthreads();
-  for (int k = tid; k < nb * p.A; k += 256) {
+  for (int k = tid; k < nb * p.A; k += NT) {
     const int bi = k / p.A;
     probs[(size_t)(row0 + board0) * p.A + k] = __expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
   }
@@ -376,7 +365,7 @@ int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts
   if (which != 0 && which != 1) return nfail(CARO_E_INVAL, "which must be 0 or 1");
   if (max_rows <= 0) return 0;
   const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
-  hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(256), 0, (hipStream_t)stream, n->p, planes_dev,
+  hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, planes_dev,
                      counts_dev, which, probs_dev, values_dev);
   if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
   return 0;
