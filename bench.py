@@ -105,13 +105,16 @@ def main():
     ap.add_argument("--net", default="hip", choices=["hip", "gemm", "folded", "net"],
                     help="inference form of lib/model.py Net: fused HIP fp32 MFMA kernel (default), torch gather+GEMM, "
                          "BN-folded conv2d, or the module as is")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="split the games of a GPU over this many engines on separate HIP streams (tree kernels of "
+                         "one part overlap the net kernel of another)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the kernels")
     args = ap.parse_args()
 
     from caro_ai_amd import parallel
-    from caro_ai_amd.engine import SelfPlayEngine, torch_evaluator
+    from caro_ai_amd.engine import SelfPlayEngine, StreamedSelfPlay, torch_evaluator
     from caro_ai_amd.lib.game.connect_four import ConnectFour
     from caro_ai_amd.lib.game.tictactoe import TicTacToe
     from caro_ai_amd.lib.model import FoldedNet, GemmNet
@@ -129,12 +132,18 @@ def main():
     G, S, B = args.games, args.searches, args.batch
     if args.net == "hip":
         from caro_ai_amd.net_hip import HipNet
-        evaluators = [HipNet(net, str(device))]
+        hipnet = HipNet(net, str(device))
+        make_evaluators = lambda: [hipnet]
     else:
         fnet = {"gemm": GemmNet, "folded": FoldedNet, "net": lambda n: n}[args.net](net).to(device).eval()
-        evaluators = [torch_evaluator(fnet, form="net")]
-    eng = SelfPlayEngine(game, G, evaluators=evaluators, max_batch=B, steps_before_tau_0=sbt0,
-                         seed=0, device=str(device), searches_hint=S, **parallel.shard(G, rank, world))
+        make_evaluators = lambda: [torch_evaluator(fnet, form="net")]
+    n_streams = args.streams if args.net == "hip" else 1
+    if n_streams > 1:
+        eng = StreamedSelfPlay(game, G, make_evaluators, n_streams=n_streams, max_batch=B, steps_before_tau_0=sbt0,
+                               seed=0, device=str(device), searches_hint=S, **parallel.shard(G, rank, world))
+    else:
+        eng = SelfPlayEngine(game, G, evaluators=make_evaluators(), max_batch=B, steps_before_tau_0=sbt0,
+                             seed=0, device=str(device), searches_hint=S, **parallel.shard(G, rank, world))
 
     n_tuples = 0
 
@@ -161,7 +170,6 @@ def main():
     if not args.no_profile:
         eng.profile(True)
         eng.profile_read(reset=True)
-    rows0, calls0 = eng.net_rows, eng.net_calls
     n_tuples = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -226,6 +234,7 @@ def main():
             "config": {"workload": "%s %d concurrent self-play games/GPU, %dx%d = %d sims/move, tau=1 for %d plies"
                                    % ("Connect4 6x7" if args.game == "c4" else "m,n,k 15x15 k=5", G, S, B, S * B, sbt0),
                        "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py Net, %s fp32" % {"hip": "fused HIP MFMA kernel", "gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net],
+                       "streams_per_gpu": n_streams,
                        "parallelism": "games sharded x%d, all-gather of tuples per step" % world},
             "per_gpu": exp_all / dt_max / world,
             "sims_per_s": sims_all / dt_max, "plies_per_s": plies_all / dt_max, "games_per_s": fin_all / dt_max,

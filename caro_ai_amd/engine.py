@@ -290,3 +290,79 @@ class SelfPlayEngine:
                 break
         games = np.concatenate(games) if games else np.zeros((0, 4), np.int64)
         return out, games
+
+
+class StreamedSelfPlay:
+    """The same G games split over `n_streams` independent engines, each on its own HIP stream.
+
+    The tree kernels of one part (latency bound, a handful of waves per CU) run underneath the net kernel of
+    another part (MFMA bound), and no part's leaf batch exceeds one round of net workgroups.  Game uids are
+    laid out exactly as in a single engine (slot g of part k is global slot k*G/n + g), so the set of games
+    played does not depend on n_streams.  Interface = the subset of SelfPlayEngine that bench.py / play loops use.
+    """
+
+    def __init__(self, game, n_games, make_evaluators, n_streams=2, uid_base=0, uid_stride=None, device="cuda:0",
+                 **kw):
+        assert n_games % n_streams == 0
+        self.G = n_games
+        self.device = torch.device(device)
+        per = n_games // n_streams
+        stride = uid_stride if uid_stride is not None else n_games
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        self.parts = []
+        for k in range(n_streams):
+            with torch.cuda.stream(self.streams[k]):
+                self.parts.append(SelfPlayEngine(game, per, evaluators=make_evaluators(), uid_base=uid_base + k * per,
+                                                 uid_stride=stride, device=device, **kw))
+        torch.cuda.synchronize(self.device)
+
+    def _each(self):
+        return zip(self.parts, self.streams)
+
+    def search(self, searches, batch):
+        for mb in range(searches):
+            for e, st in self._each():
+                with torch.cuda.stream(st):
+                    e.minibatch(batch, mb)
+
+    def step(self):
+        for e, st in self._each():
+            with torch.cuda.stream(st):
+                e.step()
+
+    def drain(self, recycle=True):
+        outs = []
+        for e, st in self._each():
+            with torch.cuda.stream(st):
+                outs.append(e.drain(recycle=recycle))
+        for st in self.streams:
+            st.synchronize()
+        return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+
+    def counters(self):
+        tot = {}
+        for e, st in self._each():
+            with torch.cuda.stream(st):
+                for k, v in e.counters().items():
+                    tot[k] = tot.get(k, 0) + v
+        return tot
+
+    def profile(self, on=True):
+        for e in self.parts:
+            e.profile(on)
+
+    def profile_read(self, reset=True):
+        tot = {}
+        for e in self.parts:
+            for k, (ms, n) in e.profile_read(reset).items():
+                a = tot.get(k, (0.0, 0))
+                tot[k] = (a[0] + ms, a[1] + n)
+        return tot
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def close(self):
+        for e in self.parts:
+            e.close()
