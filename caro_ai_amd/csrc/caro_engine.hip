@@ -1356,6 +1356,30 @@ int caro_expand_backup(caro_engine* h, const float* probs, const float* values, 
   return 0;
 }
 
+// MCTS.search_batch (lib/mcts.py:162-176) for every game with the fused HIP net(s): `searches` minibatches of
+// select -> net forward (leaf count read on device) -> expand+backup, enqueued back to back from C.
+int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch, const double* noise,
+                      float* planes, uint64_t* leaf_keys, float* probs, float* values, void* stream) {
+  if (!h || !net0 || !planes || !probs || !values) return fail(CARO_E_INVAL, "null argument");
+  if (h->v.n_nets == 2 && !net1) return fail(CARO_E_INVAL, "engine has two nets, net1 is null");
+  if (searches < 1) return fail(CARO_E_INVAL, "searches must be >= 1");
+  const int64_t max_rows = (int64_t)h->v.G * batch;
+  const size_t noise_stride = (size_t)h->v.G * batch * h->v.A;
+  for (int mb = 0; mb < searches; ++mb) {
+    int rc = caro_select(h, batch, mb, noise ? noise + (size_t)mb * noise_stride : nullptr, planes, leaf_keys, stream);
+    if (rc) return rc;
+    // sample the net timing on every 4th minibatch only: event records are host work
+    const int p0 = (mb & 3) == 0 ? prof_begin(h, PK_NET, (hipStream_t)stream) : -1;
+    rc = caro_net_forward(net0, planes, h->v.leaf_count, 0, max_rows, probs, values, stream);
+    if (!rc && h->v.n_nets == 2) rc = caro_net_forward(net1, planes, h->v.leaf_count, 1, max_rows, probs, values, stream);
+    prof_end(h, p0, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = caro_expand_backup(h, probs, values, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int caro_policy(caro_engine* h, double* pi, int32_t* counts, void* stream) {
   if (!h) return fail(CARO_E_INVAL, "null engine");
   DISPATCH(h->var, hipLaunchKernelGGL(k_policy<GEO>, dim3(h->v.G), dim3(64), 0, (hipStream_t)stream, h->v, pi, counts));

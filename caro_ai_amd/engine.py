@@ -172,6 +172,14 @@ class SelfPlayEngine:
 
     def search(self, searches, batch, noise=None):
         """search_batch (mcts.py:162-176) for all games. noise: optional [searches, G, batch, A] rows."""
+        if self.async_net and noise is None:
+            # whole search_batch enqueued by one C call (no Python / ctypes work per launch)
+            nets = [e.h for e in self.evaluators] + [None]
+            _lib.check(self.L.caro_search_batch(self.h, nets[0], nets[1], searches, batch, None, _ptr(self.planes),
+                                                _ptr(self.leaf_keys), _ptr(self._probs), _ptr(self._values),
+                                                self._stream()))
+            self.net_calls += searches * self.n_nets
+            return
         for mb in range(searches):
             self.minibatch(batch, mb, None if noise is None else noise[mb])
 
@@ -320,10 +328,9 @@ class StreamedSelfPlay:
         return zip(self.parts, self.streams)
 
     def search(self, searches, batch):
-        for mb in range(searches):
-            for e, st in self._each():
-                with torch.cuda.stream(st):
-                    e.minibatch(batch, mb)
+        for e, st in self._each():
+            with torch.cuda.stream(st):
+                e.search(searches, batch)
 
     def step(self):
         for e, st in self._each():

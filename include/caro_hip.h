@@ -214,6 +214,14 @@ int caro_net_boards_per_workgroup(const caro_net* n);
 int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which, int64_t max_rows,
                      float* probs_dev, float* values_dev, void* stream);
 
+/* MCTS.search_batch (lib/mcts.py:162-176) for every live game with the fused net(s): `searches` x
+ * (caro_select -> caro_net_forward per net -> caro_expand_backup) enqueued on `stream` from one call, no host
+ * synchronisation.  noise_dev: f64[searches, G, batch, A] or NULL (generated); buffers as for caro_select /
+ * caro_expand_backup; net1 may be NULL when the engine has one net. */
+int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch,
+                      const double* noise_dev, float* planes_dev, uint64_t* leaf_keys_dev, float* probs_dev,
+                      float* values_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
