@@ -213,11 +213,12 @@ def main():
         if prof is not None and prof.get("net", (0, 0))[1] > 0:
             ms, n = prof["net"]
             avg_s = ms * 1e-3 / n
-            leaves_per_launch = delta["expansions"] / n
+            # the net is timed on a sample of the launches (every 4th minibatch); one net launch per select launch
+            leaves_per_launch = delta["expansions"] / max(1, prof["select"][1])
             achieved = leaves_per_launch * flops_per_leaf / avg_s / 1e12
             roofline = {"bound": "mfma", "kernel": "k_net_forward", "achieved": achieved, "peak": MFMA_F32_PEAK_TFS,
                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFS, "traffic": pmc.get("k_net_forward"),
-                        "avg_launch_us": avg_s * 1e6, "launches": n, "leaves_per_launch": leaves_per_launch,
+                        "avg_launch_us": avg_s * 1e6, "launches_timed": n, "leaves_per_launch": leaves_per_launch,
                         "flops_per_leaf": flops_per_leaf}
         if roofline is None:  # torch evaluators: the net is not our kernel; the tree walk is the dominant own kernel
             roofline = roofline_tree
