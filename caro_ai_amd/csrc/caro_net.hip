@@ -11,7 +11,11 @@
 // MFMAs cover the other's LDS operand reads; TB boards):
 //   rows r = board*HW + cell, at most 255 real rows; row 255 is a permanent zero
 //   row (3x3 padding).  Activations X[row][64] float32 stay in LDS for the whole
-//   trunk (two 64 KiB ping-pong buffers, XOR-swizzled 16-byte granules), the
+//   trunk in ONE 64 KiB buffer (XOR-swizzled 16-byte granules) that is updated in
+//   place: a layer's outputs live in the MFMA accumulators until every wave has
+//   finished reading the layer's input, then overwrite it.  80 KiB of LDS and
+//   240 VGPRs per SIMD per workgroup leave room on the CU for a second net
+//   workgroup or for the tree kernels of another stream.  The
 //   3x3 convolutions are implicit GEMMs on v_mfma_f32_32x32x2_f32:
 //       M = 256 rows (8 row tiles), N = 64 (2 col tiles), K = 9 taps x 64 channels,
 //   wave w owns row tile w x both col tiles (2 accumulators of 16 regs).
@@ -40,7 +44,7 @@ constexpr int ZROW = 255;       // permanent zero row
 constexpr int ACT = 256 * NF;   // floats per activation buffer
 constexpr int WCHUNK = 64 * 64; // floats per tap chunk
 constexpr int NRES = 5;
-constexpr int LDS_FLOATS = 2 * ACT + WCHUNK;
+constexpr int LDS_FLOATS = ACT + WCHUNK;
 
 struct NetParams {
   int H, W, HW, A, TB;
@@ -66,13 +70,12 @@ __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? 
 
 constexpr int NT = 512;  // threads per workgroup
 
-__global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float* __restrict__ planes,
+__global__ __launch_bounds__(NT, 4) void k_net_forward(NetParams p, const float* __restrict__ planes,
                                                          const int32_t* __restrict__ counts, int which,
                                                          float* __restrict__ probs, float* __restrict__ values) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  float* bufA = lds;
-  float* bufB = lds + ACT;
-  float* wbuf = lds + 2 * ACT;
+  float* act = lds;
+  float* wbuf = lds + ACT;
 
   const int L = counts[which];
   const int row0 = which ? counts[0] : 0;
@@ -85,8 +88,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
   const int wave = tid >> 6, lane = tid & 63;
   const int i = lane & 31, h = lane >> 5;
 
-  // zero both activation buffers (dummy rows and the zero row stay zero for ever)
-  for (int k = tid; k < 2 * ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // zero the activation buffer (dummy rows and the zero row stay zero for ever)
+  for (int k = tid; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   // conv_in weights into wbuf: [9][2][64] = 1152 floats
   for (int k = tid; k < 9 * 2 * NF; k += NT) wbuf[k] = p.w_in[k];
   __syncthreads();
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
         }
         float4 out = make_float4(leaky(o[0], p.slope), leaky(o[1], p.slope), leaky(o[2], p.slope),
                                  leaky(o[3], p.slope));
-        *reinterpret_cast<float4*>(bufA + r * NF + ((c4 ^ (r & 15)) << 2)) = out;
+        *reinterpret_cast<float4*>(act + r * NF + ((c4 ^ (r & 15)) << 2)) = out;
       }
     }
   }
@@ -143,8 +146,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
   const int ry = rcell / p.W, rx = rcell - ry * p.W;
   const int bswz = (i >> 1) & 7;
 
-  float* in = bufA;
-  float* out = bufB;
+  float* const in = act;
+  float* const out = act;  // in place: see the barrier before the epilogue
   for (int layer = 0; layer < NRES; ++layer) {
     f32x16 acc0, acc1;
 #pragma unroll
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
           b1 = b1n;
         }
       }
-      __syncthreads();  // every wave is done reading wbuf
+      __syncthreads();  // every wave is done reading wbuf and (tap 8) this layer's input activations
       if (has_next) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) reinterpret_cast<float4*>(wbuf)[tid + NT * m] = wn[m];
@@ -215,12 +218,9 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
       }
       __syncthreads();  // wbuf (and, after tap 8, the new activations) visible to every wave
     }
-    float* tmp = in;
-    in = out;
-    out = tmp;
   }
-  // `in` now holds the trunk output; `out` is free scratch
-  float* feat = out;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
+  // `act` now holds the trunk output; the weight buffer is free scratch (4096 floats)
+  float* feat = wbuf;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
   {
     const int r = tid;
     if (r < R) {
