@@ -1428,6 +1428,28 @@ int caro_leaf_counts_dev(caro_engine* h, const int32_t** counts_dev) {
   return 0;
 }
 
+// A HIP stream restricted to CUs [part, part+1) / nparts of the device (hipExtStreamCreateWithCUMask), so that
+// independent engines on different streams get disjoint compute units instead of sharing them.
+int caro_stream_create_partition(int device_id, int part, int nparts, void** stream_out) {
+  if (!stream_out || nparts < 1 || part < 0 || part >= nparts) return fail(CARO_E_INVAL, "bad partition");
+  HIPCHK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device_id));
+  const int ncu = prop.multiProcessorCount;
+  const int words = (ncu + 31) / 32;
+  std::vector<uint32_t> mask(words, 0u);
+  const int lo = (int)((long long)ncu * part / nparts), hi = (int)((long long)ncu * (part + 1) / nparts);
+  for (int c = lo; c < hi; ++c) mask[c >> 5] |= 1u << (c & 31);
+  hipStream_t st = nullptr;
+  HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()));
+  *stream_out = (void*)st;
+  return 0;
+}
+int caro_stream_destroy(void* stream) {
+  if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+
 int caro_select_cancel(caro_engine* h) {
   if (!h) return fail(CARO_E_INVAL, "null engine");
   h->select_pending = 0;

@@ -310,13 +310,24 @@ class StreamedSelfPlay:
     """
 
     def __init__(self, game, n_games, make_evaluators, n_streams=2, uid_base=0, uid_stride=None, device="cuda:0",
-                 **kw):
+                 partition_cus=True, **kw):
         assert n_games % n_streams == 0
         self.G = n_games
         self.device = torch.device(device)
         per = n_games // n_streams
         stride = uid_stride if uid_stride is not None else n_games
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        self._raw_streams = []
+        if partition_cus:
+            # each part gets its own slice of the CUs: the parts run side by side instead of sharing CUs
+            L = _lib.load()
+            self.streams = []
+            for k in range(n_streams):
+                ptr = C.c_void_p()
+                _lib.check(L.caro_stream_create_partition(self.device.index or 0, k, n_streams, C.byref(ptr)))
+                self._raw_streams.append(ptr)
+                self.streams.append(torch.cuda.ExternalStream(ptr.value, device=self.device))
+        else:
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.parts = []
         for k in range(n_streams):
             with torch.cuda.stream(self.streams[k]):
@@ -373,3 +384,6 @@ class StreamedSelfPlay:
     def close(self):
         for e in self.parts:
             e.close()
+        for ptr in self._raw_streams:
+            _lib.load().caro_stream_destroy(ptr)
+        self._raw_streams = []

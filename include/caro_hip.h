@@ -214,6 +214,10 @@ int caro_net_boards_per_workgroup(const caro_net* n);
 int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which, int64_t max_rows,
                      float* probs_dev, float* values_dev, void* stream);
 
+/* A HIP stream confined to the compute units [part/nparts, (part+1)/nparts) of the device
+ * (hipExtStreamCreateWithCUMask): independent engines on such streams run side by side on disjoint CUs. */
+int caro_stream_create_partition(int device_id, int part, int nparts, void** stream_out);
+int caro_stream_destroy(void* stream);
 /* MCTS.search_batch (lib/mcts.py:162-176) for every live game with the fused net(s): `searches` x
  * (caro_select -> caro_net_forward per net -> caro_expand_backup) enqueued on `stream` from one call, no host
  * synchronisation.  noise_dev: f64[searches, G, batch, A] or NULL (generated); buffers as for caro_select /
