@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--net", default="hip", choices=["hip", "gemm", "folded", "net"],
                     help="inference form of lib/model.py Net: fused HIP fp32 MFMA kernel (default), torch gather+GEMM, "
                          "BN-folded conv2d, or the module as is")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=1,
                     help="split the games of a GPU over this many engines on separate HIP streams (tree kernels of "
                          "one part overlap the net kernel of another)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
