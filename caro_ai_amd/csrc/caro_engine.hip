@@ -13,10 +13,11 @@
 //                    [lib/mcts.py:289-313, lib/utils.py:80-99].
 //   k_drain_*        replay emission [lib/utils.py:101-106] + slot recycling.
 //
-// Data layout in HBM (T = G * n_stores trees, AP = padded action count):
-//   slots    i32 [T][hcap]          open-addressing table, -1 = empty
-//   node_key u64 [T][cap][KW]       board of each node (the transposition key)
-//   edges    u32 [T][cap][4][AP]    per node four action rows N | W | Q | P,
+// Data layout in HBM (T = G * n_stores trees, AP = padded action count).  The transposition table IS
+// the node store: open addressing with linear probing over hcap = 2^k >= 2*cap slots, node id = slot,
+// so one descent level costs ONE memory latency (key and action rows of the home slot load together).
+//   node_key u64 [T][hcap][KW]      board of the node in the slot (the key); word 0 == ~0 marks an empty slot
+//   edges    u32 [T][hcap][4][AP]   per node four action rows N | W | Q | P,
 //                                   adjacent in memory (connect four: one
 //                                   128-byte line per node); N carries the
 //                                   "strong" flag in bit 30 (W has absorbed a
@@ -52,7 +53,6 @@ struct View {
   double alpha, explore;
   uint64_t seed, uid_base, uid_stride;
   // trees
-  int32_t* slots;
   uint64_t* node_key;
   uint32_t* edges;
   int32_t* n_nodes;
@@ -119,37 +119,51 @@ __device__ __forceinline__ void store_board(uint64_t* p, const typename R::Board
   for (int i = 0; i < R::KW; ++i) p[i] = b.w[i];
 }
 
-// `state in self.probs` (lib/mcts.py:160): open-addressing probe of tree t
+constexpr uint64_t EMPTY_KEY = ~0ULL;  // no board has bit 63 set (C4) / overlapping planes (m,n,k)
+
 template <class R>
-__device__ __forceinline__ int probe(const View& v, int t, const typename R::Board& b) {
+__device__ __forceinline__ uint32_t home_slot(const View& v, const typename R::Board& b) {
+  return (uint32_t)R::hash(b) & ((uint32_t)v.hcap - 1u);
+}
+
+// `state in self.probs` (lib/mcts.py:160): probe of tree t, returns the node's slot or -1
+template <class R>
+__device__ __forceinline__ int probe_from(const View& v, int t, const typename R::Board& b, uint32_t i) {
   const uint32_t mask = (uint32_t)v.hcap - 1u;
-  uint32_t i = (uint32_t)R::hash(b) & mask;
-  const int32_t* sl = v.slots + (size_t)t * v.hcap;
+  const uint64_t* keys = v.node_key + (size_t)t * v.hcap * R::KW;
   for (int it = 0; it < v.hcap; ++it) {
-    const int s = sl[i];
-    if (s < 0) return -1;
-    const uint64_t* k = v.node_key + ((size_t)t * v.cap + s) * R::KW;
-    bool eq = true;
+    const uint64_t* k = keys + (size_t)i * R::KW;
+    const uint64_t k0 = k[0];
+    if (k0 == EMPTY_KEY) return -1;
+    bool eq = k0 == b.w[0];
 #pragma unroll
-    for (int w = 0; w < R::KW; ++w) eq = eq && (k[w] == b.w[w]);
-    if (eq) return s;
+    for (int w = 1; w < R::KW; ++w) eq = eq && (k[w] == b.w[w]);
+    if (eq) return (int)i;
     i = (i + 1u) & mask;
   }
   return -1;
 }
-
 template <class R>
-__device__ __forceinline__ void insert_slot(const View& v, int t, const typename R::Board& b, int node) {
+__device__ __forceinline__ int probe(const View& v, int t, const typename R::Board& b) {
+  return probe_from<R>(v, t, b, home_slot<R>(v, b));
+}
+
+// first free slot from the board's home slot; writes the key; returns the slot (-1: table full)
+template <class R>
+__device__ __forceinline__ int insert_key(const View& v, int t, const typename R::Board& b) {
   const uint32_t mask = (uint32_t)v.hcap - 1u;
-  uint32_t i = (uint32_t)R::hash(b) & mask;
-  int32_t* sl = v.slots + (size_t)t * v.hcap;
+  uint32_t i = home_slot<R>(v, b);
+  uint64_t* keys = v.node_key + (size_t)t * v.hcap * R::KW;
   for (int it = 0; it < v.hcap; ++it) {
-    if (sl[i] < 0) {
-      sl[i] = node;
-      return;
+    uint64_t* k = keys + (size_t)i * R::KW;
+    if (k[0] == EMPTY_KEY) {
+#pragma unroll
+      for (int w = R::KW - 1; w >= 0; --w) k[w] = b.w[w];
+      return (int)i;
     }
     i = (i + 1u) & mask;
   }
+  return -1;
 }
 
 template <int LPD>
@@ -224,20 +238,48 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
   const float c32 = v.c_puct;
   const double c64 = (double)v.c_puct;
 
-  int node = probe<R>(v, t, cur);
-  while (node >= 0 && depth < v.maxd) {
-    const uint32_t* row = v.edges + ((size_t)t * v.cap + node) * 4 * AP;
+  const uint64_t* tkeys = v.node_key + (size_t)t * v.hcap * KW;
+  const uint32_t* tedges = v.edges + (size_t)t * v.hcap * 4 * AP;
+  uint32_t slot = home_slot<R>(v, cur);
+  while (depth < v.maxd) {
+    // one latency per level: the key and the action rows of the home slot are loaded together
+    const uint32_t* row = tedges + (size_t)slot * 4 * AP;
     uint32_t nraw[APL];
     float q[APL], p[APL];
-    int nsum = 0;
 #pragma unroll
     for (int j = 0; j < APL; ++j) {
       const int a = l * APL + j;
       nraw[j] = row[a];
       q[j] = __uint_as_float(row[2 * AP + a]);
       p[j] = __uint_as_float(row[3 * AP + a]);
-      nsum += (int)(nraw[j] & NMASK);
     }
+    int node;
+    {
+      const uint64_t* k = tkeys + (size_t)slot * KW;
+      const uint64_t k0 = k[0];
+      bool eq = k0 == cur.w[0];
+#pragma unroll
+      for (int w = 1; w < KW; ++w) eq = eq && (k[w] == cur.w[w]);
+      if (eq) node = (int)slot;
+      else if (k0 == EMPTY_KEY) node = -1;
+      else {  // collision with another board: walk the probe sequence, then reload the rows
+        node = probe_from<R>(v, t, cur, (slot + 1u) & ((uint32_t)v.hcap - 1u));
+        if (node >= 0) {
+          row = tedges + (size_t)node * 4 * AP;
+#pragma unroll
+          for (int j = 0; j < APL; ++j) {
+            const int a = l * APL + j;
+            nraw[j] = row[a];
+            q[j] = __uint_as_float(row[2 * AP + a]);
+            p[j] = __uint_as_float(row[3 * AP + a]);
+          }
+        }
+      }
+    }
+    if (node < 0) break;  // not in the tree: this is the leaf (mcts.py:123)
+    int nsum = 0;
+#pragma unroll
+    for (int j = 0; j < APL; ++j) nsum += (int)(nraw[j] & NMASK);
     nsum = group_sum_i32<LPD>(nsum);
     const double sq = caro_sqrt((double)nsum);  // m.sqrt(sum(counts)), mcts.py:79
     double best = -__builtin_huge_val();
@@ -318,7 +360,7 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
       value = 0.0f;
       break;
     }
-    node = probe<R>(v, t, cur);
+    slot = home_slot<R>(v, cur);
   }
 
   if (l == 0) {
@@ -437,7 +479,7 @@ __device__ __forceinline__ void backup_path(const View& v, int t, float value, b
                                             const int32_t* pa, int len) {
   float cur = -value;
   for (int i = len - 1; i >= 0; --i) {
-    uint32_t* row = v.edges + ((size_t)t * v.cap + pn[i]) * 4 * AP;
+    uint32_t* row = v.edges + ((size_t)t * v.hcap + pn[i]) * 4 * AP;
     const int a = pa[i];
     const uint32_t nraw = row[a];
     const int n = (int)(nraw & NMASK) + 1;
@@ -469,19 +511,17 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
     for (int b = 0; b < B; ++b) {
       const size_t di = (size_t)g * v.maxB + b;
       if (v.d_status[di] != ST_LEAF) continue;
-      const int local = v.d_local[di];
-      const int rowi = off + local, node = base + local;
-      uint32_t* row = v.edges + ((size_t)t * v.cap + node) * 4 * AP;
+      const int rowi = off + v.d_local[di];
+      int node = 0;
+      if (lane == 0) node = insert_key<R>(v, t, load_board<R>(v.d_key + di * KW));
+      node = __shfl(node, 0);
+      if (node < 0) continue;  // cannot happen while n_nodes <= cap < hcap
+      uint32_t* row = v.edges + ((size_t)t * v.hcap + node) * 4 * AP;
       for (int a = lane; a < AP; a += blockDim.x) {  // _create_node, mcts.py:178-190
         row[a] = 0u;
         row[AP + a] = 0u;
         row[2 * AP + a] = 0u;
         row[3 * AP + a] = a < A ? __float_as_uint(probs[(size_t)rowi * A + a]) : 0u;
-      }
-      if (lane == 0) {
-        const typename R::Board brd = load_board<R>(v.d_key + di * KW);
-        store_board<R>(v.node_key + ((size_t)t * v.cap + node) * KW, brd);
-        insert_slot<R>(v, t, brd, node);
       }
     }
   }
@@ -517,7 +557,7 @@ __device__ __forceinline__ void root_policy(const View& v, int g, int t, const t
   constexpr int AP = GEO::AP;
   const int node = probe<R>(v, t, root);
   for (int a = threadIdx.x; a < AP; a += blockDim.x)
-    s_n[a] = (node >= 0 && a < v.A) ? (int)(v.edges[((size_t)t * v.cap + node) * 4 * AP + a] & NMASK) : 0;
+    s_n[a] = (node >= 0 && a < v.A) ? (int)(v.edges[((size_t)t * v.hcap + node) * 4 * AP + a] & NMASK) : 0;
   __syncthreads();
   __shared__ int s_best;
   __shared__ double s_total;
@@ -624,8 +664,8 @@ __device__ __forceinline__ void reset_game(const View& v, int g, uint64_t uid, i
   constexpr int KW = GEO::KW;
   for (int s = 0; s < v.n_stores; ++s) {
     const int t = g * v.n_stores + s;
-    int32_t* sl = v.slots + (size_t)t * v.hcap;
-    for (int i = threadIdx.x; i < v.hcap; i += blockDim.x) sl[i] = -1;
+    uint64_t* keys = v.node_key + (size_t)t * v.hcap * KW;
+    for (int i = threadIdx.x; i < v.hcap * KW; i += blockDim.x) keys[i] = EMPTY_KEY;
     if (threadIdx.x == 0) {
       v.n_nodes[t] = 0;
       v.n_created[t] = 0;
@@ -771,7 +811,7 @@ __global__ void k_lookup(View v, long long M, const int32_t* __restrict__ game, 
   const int node = probe<R>(v, t, b);
   if (threadIdx.x == 0) found[m] = node >= 0;
   if (node < 0) return;
-  const uint32_t* row = v.edges + ((size_t)t * v.cap + node) * 4 * AP;
+  const uint32_t* row = v.edges + ((size_t)t * v.hcap + node) * 4 * AP;
   for (int a = threadIdx.x; a < v.A; a += blockDim.x) {
     const size_t o = (size_t)m * v.A + a;
     N[o] = (int)(row[a] & NMASK);
@@ -796,17 +836,18 @@ __global__ void k_poke(View v, long long M, const int32_t* __restrict__ game, co
     if (threadIdx.x == 0) {
       int node = probe<R>(v, t, b);
       if (node < 0 && v.n_nodes[t] < v.cap) {
-        node = v.n_nodes[t]++;
-        v.n_created[t]++;
-        store_board<R>(v.node_key + ((size_t)t * v.cap + node) * KW, b);
-        insert_slot<R>(v, t, b, node);
+        node = insert_key<R>(v, t, b);
+        if (node >= 0) {
+          v.n_nodes[t]++;
+          v.n_created[t]++;
+        }
       }
       s_node = node;
     }
     __syncthreads();
     const int node = s_node;
     if (node >= 0) {
-      uint32_t* row = v.edges + ((size_t)t * v.cap + node) * 4 * AP;
+      uint32_t* row = v.edges + ((size_t)t * v.hcap + node) * 4 * AP;
       for (int a = threadIdx.x; a < AP; a += blockDim.x) {
         const size_t o = (size_t)m * v.A + a;
         const bool in = a < v.A;
@@ -835,13 +876,19 @@ __global__ void k_backup_one(View v, int game, int store, float value, int stron
 
 template <class GEO>
 __global__ void k_dump(View v, int game, int store, long long cap, uint64_t* keys, int32_t* N, float* W, float* Q,
-                       float* P, int32_t* strong) {
+                       float* P, int32_t* strong, int32_t* cursor) {
   constexpr int AP = GEO::AP, KW = GEO::KW;
   const int t = game * v.n_stores + store;
-  const int nn = v.n_nodes[t];
-  const long long node = blockIdx.x;
-  if (node >= nn || node >= cap) return;
-  const uint32_t* row = v.edges + ((size_t)t * v.cap + node) * 4 * AP;
+  const long long slot = blockIdx.x;
+  if (slot >= v.hcap) return;
+  const uint64_t* k = v.node_key + ((size_t)t * v.hcap + slot) * KW;
+  if (k[0] == EMPTY_KEY) return;
+  __shared__ int s_out;
+  if (threadIdx.x == 0) s_out = atomicAdd(cursor, 1);
+  __syncthreads();
+  const long long node = s_out;
+  if (node >= cap) return;
+  const uint32_t* row = v.edges + ((size_t)t * v.hcap + slot) * 4 * AP;
   for (int a = threadIdx.x; a < v.A; a += blockDim.x) {
     const size_t o = (size_t)node * v.A + a;
     N[o] = (int)(row[a] & NMASK);
@@ -850,30 +897,7 @@ __global__ void k_dump(View v, int game, int store, long long cap, uint64_t* key
     Q[o] = __uint_as_float(row[2 * AP + a]);
     P[o] = __uint_as_float(row[3 * AP + a]);
   }
-  if (threadIdx.x < KW) keys[(size_t)node * KW + threadIdx.x] = v.node_key[((size_t)t * v.cap + node) * KW + threadIdx.x];
-}
-
-// one descent of the pending select, for MCTS.find_leaf (lib/mcts.py:97-148)
-template <class GEO>
-__global__ void k_get_descent(View v, int game, int b, int32_t* info, float* value, uint64_t* leaf_key,
-                              uint64_t* path_keys, int32_t* path_actions) {
-  constexpr int KW = GEO::KW;
-  const size_t di = (size_t)game * v.maxB + b;
-  const int len = v.path_len[di];
-  const int t = v.g_tree[game];
-  if (threadIdx.x == 0) {
-    info[0] = v.d_status[di];
-    info[1] = len;
-    info[2] = v.d_player[di];
-    info[3] = v.d_local[di];
-    *value = v.d_value[di];
-    for (int w = 0; w < KW; ++w) leaf_key[w] = v.d_key[di * KW + w];
-  }
-  for (int i = threadIdx.x; i < len; i += blockDim.x) {
-    const int node = v.path_node[di * v.maxd + i];
-    path_actions[i] = v.path_act[di * v.maxd + i];
-    for (int w = 0; w < KW; ++w) path_keys[(size_t)i * KW + w] = v.node_key[((size_t)t * v.cap + node) * KW + w];
-  }
+  if (threadIdx.x < KW) keys[(size_t)node * KW + threadIdx.x] = k[threadIdx.x];
 }
 
 __global__ void k_tree_sizes(View v, int32_t* out) {
@@ -1252,9 +1276,8 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   const size_t T = (size_t)v.G * v.n_stores, G = (size_t)v.G;
   int rc = 0;
 #define DA(p, n) if ((rc = dalloc(h, &p, (n))) != 0) { caro_engine_destroy(h); return rc; }
-  DA(v.slots, T * v.hcap);
-  DA(v.node_key, T * v.cap * KW);
-  DA(v.edges, T * v.cap * 4 * AP);
+  DA(v.node_key, T * v.hcap * KW);
+  DA(v.edges, T * v.hcap * 4 * AP);
   DA(v.n_nodes, T);
   DA(v.n_created, T);
   DA(v.root, G * KW);
@@ -1565,9 +1588,9 @@ int caro_dump_tree(caro_engine* h, int game, int store, int64_t cap, uint64_t* k
   const int nn = h->pinned[5];
   *n_nodes = nn;
   if (nn == 0 || cap <= 0 || !keys) return 0;
-  const unsigned grid = (unsigned)(nn < cap ? nn : cap);
-  DISPATCH(h->var, hipLaunchKernelGGL(k_dump<GEO>, dim3(grid), dim3(64), 0, st, h->v, game, store, (long long)cap, keys,
-                                      N, W, Q, P, strong));
+  HIPCHK(hipMemsetAsync(h->live, 0, sizeof(int32_t), st));
+  DISPATCH(h->var, hipLaunchKernelGGL(k_dump<GEO>, dim3((unsigned)h->v.hcap), dim3(64), 0, st, h->v, game, store,
+                                      (long long)cap, keys, N, W, Q, P, strong, h->live));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
   return 0;
