@@ -191,9 +191,9 @@ __device__ __forceinline__ void noise_group(uint64_t key, int l, int A, double a
     g[j] = a < A ? caro_gamma_small(key, (uint32_t)a, alpha) : 0.0;
   }
   double s;
-  if (APL == 1) s = g[0];
-  else if (APL == 2) s = g[0] + g[1];
-  else s = (g[0] + g[1]) + (g[2 % APL] + g[3 % APL]);
+  if constexpr (APL == 1) s = g[0];
+  else if constexpr (APL == 2) s = g[0] + g[1];
+  else s = (g[0] + g[1]) + (g[2] + g[3]);
   s = group_sum_f64<LPD>(s);
 #pragma unroll
   for (int j = 0; j < APL; ++j) out[j] = g[j] / s;
@@ -898,6 +898,29 @@ __global__ void k_dump(View v, int game, int store, long long cap, uint64_t* key
     P[o] = __uint_as_float(row[3 * AP + a]);
   }
   if (threadIdx.x < KW) keys[(size_t)node * KW + threadIdx.x] = k[threadIdx.x];
+}
+
+// one descent of the pending select, for MCTS.find_leaf (lib/mcts.py:97-148)
+template <class GEO>
+__global__ void k_get_descent(View v, int game, int b, int32_t* info, float* value, uint64_t* leaf_key,
+                              uint64_t* path_keys, int32_t* path_actions) {
+  constexpr int KW = GEO::KW;
+  const size_t di = (size_t)game * v.maxB + b;
+  const int len = v.path_len[di];
+  const int t = v.g_tree[game];
+  if (threadIdx.x == 0) {
+    info[0] = v.d_status[di];
+    info[1] = len;
+    info[2] = v.d_player[di];
+    info[3] = v.d_local[di];
+    *value = v.d_value[di];
+    for (int w = 0; w < KW; ++w) leaf_key[w] = v.d_key[di * KW + w];
+  }
+  for (int i = threadIdx.x; i < len; i += blockDim.x) {
+    const int node = v.path_node[di * v.maxd + i];
+    path_actions[i] = v.path_act[di * v.maxd + i];
+    for (int w = 0; w < KW; ++w) path_keys[(size_t)i * KW + w] = v.node_key[((size_t)t * v.hcap + node) * KW + w];
+  }
 }
 
 __global__ void k_tree_sizes(View v, int32_t* out) {
