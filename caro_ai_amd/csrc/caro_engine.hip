@@ -85,7 +85,8 @@ struct View {
   int32_t* g_tree;
   int32_t* g_class;
   int32_t* leaf_count;  // [4]: L0, L1, batch of the pending minibatch, -
-  unsigned long long* counters;
+  unsigned long long* counters;  // [G][C_N] per-game tallies (no atomics on the hot path), summed on read
+  unsigned long long* counters_sum;  // [C_N]
   // drain scratch
   int32_t* dr_off;
   int32_t* dr_gidx;
@@ -410,10 +411,11 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
     v.g_nleaf[g] = nleaf;
     v.g_tree[g] = t;
     v.g_class[g] = v.n_nets == 2 ? player0 : 0;
-    atomicAdd(&v.counters[C_SIMS], (unsigned long long)B);
-    atomicAdd(&v.counters[C_LEVELS], (unsigned long long)levels);
-    if (term) atomicAdd(&v.counters[C_TERMINALS], (unsigned long long)term);
-    if (drop) atomicAdd(&v.counters[C_DROPPED], (unsigned long long)drop);
+    unsigned long long* ctr = v.counters + (size_t)g * C_N;  // this block is the only writer of game g's row
+    ctr[C_SIMS] += (unsigned long long)B;
+    ctr[C_LEVELS] += (unsigned long long)levels;
+    ctr[C_TERMINALS] += (unsigned long long)term;
+    ctr[C_DROPPED] += (unsigned long long)drop;
   }
 }
 
@@ -448,7 +450,6 @@ __global__ void k_scan(View v, int B) {
     v.leaf_count[0] = tot0;
     v.leaf_count[1] = tot1;
     v.leaf_count[2] = B;
-    atomicAdd(&v.counters[C_EXPANSIONS], (unsigned long long)(tot0 + tot1));
   }
 }
 
@@ -526,11 +527,13 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
     }
   }
   if (lane == 0) {
+    unsigned long long* ctr = v.counters + (size_t)g * C_N;
     if (overflow) {
-      atomicAdd(&v.counters[C_OVERFLOW], 1ull);
+      ctr[C_OVERFLOW] += 1ull;
     } else {
       v.n_nodes[t] = base + nleaf;
       v.n_created[t] += nleaf;
+      ctr[C_EXPANSIONS] += (unsigned long long)nleaf;
     }
     // backup queue order (mcts.py:269-271,221-223,286-287): terminals in sim order, then new leaves
     for (int b = 0; b < B; ++b) {
@@ -645,12 +648,13 @@ __global__ void k_step(View v, const double* __restrict__ uniforms, int32_t* __r
         v.step[g] = v.step[g] + 1;  // utils.py:97
       }
     }
+    unsigned long long* ctr = v.counters + (size_t)g * C_N;
     if (done) {
       v.done[g] = 1;
       v.result[g] = res;
-      atomicAdd(&v.counters[C_FINISHED], 1ull);
+      ctr[C_FINISHED] += 1ull;
     }
-    atomicAdd(&v.counters[C_PLIES], 1ull);
+    ctr[C_PLIES] += 1ull;
     if (actions) actions[g] = action;
     if (done_out) done_out[g] = done;
     if (result_out) result_out[g] = res;
@@ -788,6 +792,22 @@ __global__ void k_drain_copy(View v, uint64_t* __restrict__ states, int32_t* __r
     reset_game<GEO>(v, g, v.uid[g] + v.uid_stride, -1);
   } else if (threadIdx.x == 0) {
     v.done[g] = 2;  // drained, stays finished
+  }
+}
+
+__global__ void k_sum_counters(View v) {
+  __shared__ unsigned long long s[256];
+  for (int c = 0; c < C_N; ++c) {
+    unsigned long long acc = 0;
+    for (int g = threadIdx.x; g < v.G; g += blockDim.x) acc += v.counters[(size_t)g * C_N + c];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+      if (threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) v.counters_sum[c] = s[0];
+    __syncthreads();
   }
 }
 
@@ -1316,12 +1336,13 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   DA(v.d_key, G * v.maxB * KW);
   DA(v.g_nleaf, G); DA(v.g_off, G); DA(v.g_tree, G); DA(v.g_class, G);
   DA(v.leaf_count, 4);
-  DA(v.counters, C_N);
+  DA(v.counters, G * C_N);
+  DA(v.counters_sum, C_N);
   DA(v.dr_off, G); DA(v.dr_gidx, G); DA(v.dr_sel, G); DA(v.dr_tot, 2);
   DA(h->scratch, (size_t)v.maxd + 8);
   DA(h->live, 1);
 #undef DA
-  HIPCHK(hipMemset(v.counters, 0, sizeof(unsigned long long) * C_N));
+  HIPCHK(hipMemset(v.counters, 0, sizeof(unsigned long long) * C_N * G));
   HIPCHK(hipMemset(v.leaf_count, 0, sizeof(int32_t) * 4));
   HIPCHK(hipMemset(v.g_nleaf, 0, sizeof(int32_t) * G));
   HIPCHK(hipHostMalloc((void**)&h->pinned, 64, hipHostMallocDefault));
@@ -1462,7 +1483,9 @@ int caro_drain_tuples(caro_engine* h, int64_t cap, uint64_t* states, int32_t* pl
 
 int caro_counters(caro_engine* h, int64_t counters[8], void* stream) {
   if (!h || !counters) return fail(CARO_E_INVAL, "null argument");
-  HIPCHK(hipMemcpyAsync(h->pinned64, h->v.counters, C_N * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  hipLaunchKernelGGL(k_sum_counters, dim3(1), dim3(256), 0, (hipStream_t)stream, h->v);
+  HIPCHK(hipMemcpyAsync(h->pinned64, h->v.counters_sum, C_N * sizeof(int64_t), hipMemcpyDeviceToHost,
+                        (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   for (int i = 0; i < 8; ++i) counters[i] = i < C_N ? h->pinned64[i] : 0;
   return 0;
