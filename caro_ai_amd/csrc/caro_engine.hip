@@ -6,8 +6,8 @@
 //                    [lib/mcts.py:265-278].  One workgroup per game, one group
 //                    of LPD lanes per descent, lanes = actions; PUCT argmax is
 //                    a xor-butterfly over (score, action) inside the group.
-//   k_scan/k_encode  deterministic compaction of the unique leaves into dense
-//                    net rows + NN planes [game.states_to_training_batch].
+//   k_encode         deterministic compaction of the unique leaves into dense net rows (each block sums the
+//                    counts of the games before it) + NN planes [game.states_to_training_batch].
 //   k_expand_backup  _create_node + ordered _backup [lib/mcts.py:178-190,225-246,281-287].
 //   k_step           get_policy_value + one ply of play_game
 //                    [lib/mcts.py:289-313, lib/utils.py:80-99].
@@ -419,47 +419,41 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
   }
 }
 
-// exclusive scan of the per-game unique-leaf counts, class 0 rows first, then class 1
-__global__ void k_scan(View v, int B) {
-  __shared__ int s0[1024], s1[1024];
-  const int tid = threadIdx.x;
-  const int chunk = (v.G + 1023) / 1024;
-  const int lo = tid * chunk, hi = min(v.G, lo + chunk);
-  int c0 = 0, c1 = 0;
-  for (int g = lo; g < hi; ++g) {
-    const int n = v.g_nleaf[g];
-    if (v.g_class[g]) c1 += n; else c0 += n;
-  }
-  s0[tid] = c0;
-  s1[tid] = c1;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const int a0 = tid >= d ? s0[tid - d] : 0, a1 = tid >= d ? s1[tid - d] : 0;
-    __syncthreads();
-    s0[tid] += a0;
-    s1[tid] += a1;
-    __syncthreads();
-  }
-  const int tot0 = s0[1023], tot1 = s1[1023];
-  int o0 = s0[tid] - c0, o1 = tot0 + s1[tid] - c1;
-  for (int g = lo; g < hi; ++g) {
-    const int n = v.g_nleaf[g];
-    if (v.g_class[g]) { v.g_off[g] = o1; o1 += n; } else { v.g_off[g] = o0; o0 += n; }
-  }
-  if (tid == 0) {
-    v.leaf_count[0] = tot0;
-    v.leaf_count[1] = tot1;
-    v.leaf_count[2] = B;
-  }
-}
-
+// NN planes of the unique leaves, written as dense rows (rows of net 0 first, then net 1).  Every block
+// derives its game's row offset itself by summing the unique-leaf counts of the games before it (a few KB of
+// L2-resident ints), which replaces a separate scan launch; the last block also publishes the totals.
 template <class GEO>
 __global__ void k_encode(View v, int B, float* __restrict__ planes, uint64_t* __restrict__ leaf_keys) {
   using R = typename GEO::R;
   constexpr int KW = GEO::KW;
+  __shared__ int s_sum[4][128];
   const int g = blockIdx.x;
+  const int tid = threadIdx.x;
+  // c0b / c1b: leaves of class 0 / 1 in games before g; c0a: class 0 in all games
+  int c0b = 0, c1b = 0, c0a = 0, c1a = 0;
+  for (int k = tid; k < v.G; k += blockDim.x) {
+    const int n = v.g_nleaf[k];
+    const int cls = v.g_class[k];
+    if (cls) { c1a += n; if (k < g) c1b += n; } else { c0a += n; if (k < g) c0b += n; }
+  }
+  s_sum[0][tid] = c0b; s_sum[1][tid] = c1b; s_sum[2][tid] = c0a; s_sum[3][tid] = c1a;
+  __syncthreads();
+  for (int d = 64; d > 0; d >>= 1) {
+    if (tid < d)
+      for (int c = 0; c < 4; ++c) s_sum[c][tid] += s_sum[c][tid + d];
+    __syncthreads();
+  }
+  const int tot0 = s_sum[2][0], tot1 = s_sum[3][0];
+  const int off = v.g_class[g] ? tot0 + s_sum[1][0] : s_sum[0][0];
+  if (tid == 0) {
+    v.g_off[g] = off;
+    if (g == v.G - 1) {
+      v.leaf_count[0] = tot0;
+      v.leaf_count[1] = tot1;
+      v.leaf_count[2] = B;
+    }
+  }
   if (v.g_nleaf[g] == 0) return;
-  const int off = v.g_off[g];
   const int HW = v.HW;
   for (int b = 0; b < B; ++b) {
     const size_t di = (size_t)g * v.maxB + b;
@@ -468,9 +462,8 @@ __global__ void k_encode(View v, int B, float* __restrict__ planes, uint64_t* __
     const typename R::Board brd = load_board<R>(v.d_key + di * KW);
     const int who = v.d_player[di];
     float* dst = planes + (size_t)rowi * 2 * HW;
-    for (int i = threadIdx.x; i < 2 * HW; i += blockDim.x)
-      dst[i] = R::plane(v.gp, brd, who, i / HW, i % HW);
-    if (leaf_keys && threadIdx.x < KW) leaf_keys[(size_t)rowi * KW + threadIdx.x] = brd.w[threadIdx.x];
+    for (int i = tid; i < 2 * HW; i += blockDim.x) dst[i] = R::plane(v.gp, brd, who, i / HW, i % HW);
+    if (leaf_keys && tid < KW) leaf_keys[(size_t)rowi * KW + tid] = brd.w[tid];
   }
 }
 
@@ -494,10 +487,22 @@ __device__ __forceinline__ void backup_path(const View& v, int t, float value, b
   }
 }
 
+// _create_node (mcts.py:178-190) for every unique leaf, then the queued _backup calls (mcts.py:225-246,
+// 286-287).  The reference applies the backups one after another; contributions to DIFFERENT edges commute,
+// contributions to the SAME edge must keep queue order because W is a float32 running sum.  So the queue is
+// flattened into (edge, +-value) entries in reference order (terminals by sim index, then new leaves first
+// seen; inside a path from the leaf upwards), the first entry of every distinct edge becomes its owner and
+// applies all entries of that edge in order, and the owners' read-modify-writes proceed in parallel.
 template <class GEO>
 __global__ void k_expand_backup(View v, const float* __restrict__ probs, const float* __restrict__ values) {
   using R = typename GEO::R;
   constexpr int AP = GEO::AP, KW = GEO::KW;
+  constexpr int MAXE = 512;  // entries held in LDS; longer queues fall back to the sequential form
+  __shared__ int e_node[MAXE];
+  __shared__ short e_act[MAXE];
+  __shared__ float e_val[MAXE];
+  __shared__ unsigned char e_strong[MAXE];
+  __shared__ int s_total;
   const int g = blockIdx.x;
   if (v.done[g]) return;
   const int B = v.leaf_count[2];
@@ -518,7 +523,7 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
       node = __shfl(node, 0);
       if (node < 0) continue;  // cannot happen while n_nodes <= cap < hcap
       uint32_t* row = v.edges + ((size_t)t * v.hcap + node) * 4 * AP;
-      for (int a = lane; a < AP; a += blockDim.x) {  // _create_node, mcts.py:178-190
+      for (int a = lane; a < AP; a += blockDim.x) {
         row[a] = 0u;
         row[AP + a] = 0u;
         row[2 * AP + a] = 0u;
@@ -526,6 +531,7 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
       }
     }
   }
+  // flatten the backup queue (lane 0; the queue is a handful of entries)
   if (lane == 0) {
     unsigned long long* ctr = v.counters + (size_t)g * C_N;
     if (overflow) {
@@ -535,20 +541,64 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
       v.n_created[t] += nleaf;
       ctr[C_EXPANSIONS] += (unsigned long long)nleaf;
     }
-    // backup queue order (mcts.py:269-271,221-223,286-287): terminals in sim order, then new leaves
+    // total queue length first: a queue that does not fit the LDS list is applied sequentially, in order
+    int total = 0;
     for (int b = 0; b < B; ++b) {
       const size_t di = (size_t)g * v.maxB + b;
-      if (v.d_status[di] == ST_TERMINAL)
-        backup_path<AP>(v, t, v.d_value[di], false, v.path_node + di * v.maxd, v.path_act + di * v.maxd,
-                        v.path_len[di]);
+      const int st = v.d_status[di];
+      if (st == ST_TERMINAL || (st == ST_LEAF && !overflow)) total += v.path_len[di];
     }
-    if (!overflow)
+    const bool fits = total <= MAXE;
+    int n = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1 && overflow) break;
       for (int b = 0; b < B; ++b) {
         const size_t di = (size_t)g * v.maxB + b;
-        if (v.d_status[di] == ST_LEAF)
-          backup_path<AP>(v, t, values[off + v.d_local[di]], true, v.path_node + di * v.maxd,
-                          v.path_act + di * v.maxd, v.path_len[di]);
+        const int st = v.d_status[di];
+        if (st != (pass == 0 ? ST_TERMINAL : ST_LEAF)) continue;
+        const float value = pass == 0 ? v.d_value[di] : values[off + v.d_local[di]];
+        const int len = v.path_len[di];
+        const int32_t* pn = v.path_node + di * v.maxd;
+        const int32_t* pa = v.path_act + di * v.maxd;
+        if (!fits) {
+          backup_path<AP>(v, t, value, pass == 1, pn, pa, len);
+          continue;
+        }
+        float cur = -value;  // mcts.py:238
+        for (int i = len - 1; i >= 0; --i) {
+          e_node[n] = pn[i];
+          e_act[n] = (short)pa[i];
+          e_val[n] = cur;
+          e_strong[n] = (unsigned char)pass;
+          ++n;
+          cur = -cur;
+        }
       }
+    }
+    s_total = n;
+  }
+  __syncthreads();
+  const int n = s_total;
+  for (int j = lane; j < n; j += blockDim.x) {
+    const int node = e_node[j], a = e_act[j];
+    bool owner = true;
+    for (int k = 0; k < j; ++k) owner = owner && !(e_node[k] == node && e_act[k] == a);
+    if (!owner) continue;
+    uint32_t* row = v.edges + ((size_t)t * v.hcap + node) * 4 * AP;
+    const uint32_t nraw = row[a];
+    int cnt = (int)(nraw & NMASK);
+    uint32_t strong = nraw & NSTRONG;
+    float w = __uint_as_float(row[AP + a]);
+    for (int k = j; k < n; ++k) {
+      if (e_node[k] == node && e_act[k] == a) {
+        cnt += 1;                 // visit_count += 1
+        w = w + e_val[k];         // value += cur_value (float32, queue order)
+        if (e_strong[k]) strong = NSTRONG;
+      }
+    }
+    row[a] = (uint32_t)cnt | strong;
+    row[AP + a] = __float_as_uint(w);
+    row[2 * AP + a] = __float_as_uint(w / (float)cnt);  // value_avg = value / visit_count
   }
 }
 
@@ -1392,10 +1442,7 @@ int caro_select(caro_engine* h, int batch, int mb_index, const double* noise, fl
                                       noise));
   prof_end(h, p0, st);
   const int p1 = prof_begin(h, PK_COMPACT, st);
-  DISPATCH(h->var, {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, h->v, batch);
-    hipLaunchKernelGGL(k_encode<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, planes, leaf_keys);
-  });
+  DISPATCH(h->var, hipLaunchKernelGGL(k_encode<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, planes, leaf_keys));
   prof_end(h, p1, st);
   HIPCHK(hipGetLastError());
   h->select_pending = 1;
