@@ -201,20 +201,21 @@ def main():
         roofline = roofline_tree = None
         if prof is not None and prof["select"][1] > 0:
             ms, n = prof["select"]
-            avg_s = ms * 1e-3 / n
-            levels_per_launch = delta["levels"] / n
+            avg_s = ms * 1e-3 / n               # timed on a sample of the launches (every 8th minibatch)
+            n_launches = args.steps * S * n_streams
+            levels_per_launch = delta["levels"] / n_launches
             achieved = levels_per_launch * bytes_per_level / avg_s / 1e9
             roofline_tree = {"bound": "hbm", "kernel": "k_select", "achieved": achieved, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("k_select"),
-                             "avg_launch_us": avg_s * 1e6, "launches": n,
+                             "avg_launch_us": avg_s * 1e6, "launches": n_launches, "launches_timed": n,
                              "levels_per_launch": levels_per_launch, "bytes_per_level": bytes_per_level,
                              "other_kernels_us": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in prof.items()
                                                   if k not in ("select", "net")}}
         if prof is not None and prof.get("net", (0, 0))[1] > 0:
             ms, n = prof["net"]
             avg_s = ms * 1e-3 / n
-            # the net is timed on a sample of the launches (every 4th minibatch); one net launch per select launch
-            leaves_per_launch = delta["expansions"] / max(1, prof["select"][1])
+            # the net is timed on a sample of the launches; one net launch per select launch
+            leaves_per_launch = delta["expansions"] / (args.steps * S * n_streams)
             achieved = leaves_per_launch * flops_per_leaf / avg_s / 1e12
             roofline = {"bound": "mfma", "kernel": "k_net_forward", "achieved": achieved, "peak": MFMA_F32_PEAK_TFS,
                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFS, "traffic": pmc.get("k_net_forward"),

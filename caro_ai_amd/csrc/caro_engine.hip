@@ -1155,6 +1155,7 @@ struct caro_engine {
   int select_pending;
   // optional HIP-event timing of the hot kernels (bench.py's live roofline)
   int prof_on;
+  int prof_gate;  // 0: skip event records for this launch (sampling inside caro_search_batch)
   std::vector<hipEvent_t> ev;      // pairs: [2*i] start, [2*i+1] stop
   std::vector<int> ev_kind;        // kernel id of pair i
   size_t ev_used;
@@ -1176,7 +1177,7 @@ static void prof_flush(caro_engine* h) {
   h->ev_used = 0;
 }
 static int prof_begin(caro_engine* h, int kind, hipStream_t st) {
-  if (!h->prof_on) return -1;
+  if (!h->prof_on || !h->prof_gate) return -1;
   if (h->ev_used * 2 + 2 > h->ev.size()) {
     if (h->ev.size() >= 2 * 16384) prof_flush(h);
     else
@@ -1340,6 +1341,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   h->var = var;
   h->select_pending = 0;
   h->prof_on = 0;
+  h->prof_gate = 1;
   h->ev_used = 0;
   for (int i = 0; i < 8; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
   View& v = h->v;
@@ -1480,17 +1482,18 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
   const int64_t max_rows = (int64_t)h->v.G * batch;
   const size_t noise_stride = (size_t)h->v.G * batch * h->v.A;
   for (int mb = 0; mb < searches; ++mb) {
+    // HIP-event timing is SAMPLED (every 8th minibatch): an event pair per kernel costs ~8 % of the step
+    h->prof_gate = (mb & 7) == 0;
     int rc = caro_select(h, batch, mb, noise ? noise + (size_t)mb * noise_stride : nullptr, planes, leaf_keys, stream);
-    if (rc) return rc;
-    // sample the net timing on every 4th minibatch only: event records are host work
-    const int p0 = (mb & 3) == 0 ? prof_begin(h, PK_NET, (hipStream_t)stream) : -1;
+    if (rc) { h->prof_gate = 1; return rc; }
+    const int p0 = prof_begin(h, PK_NET, (hipStream_t)stream);
     rc = caro_net_forward(net0, planes, h->v.leaf_count, 0, max_rows, probs, values, stream);
     if (!rc && h->v.n_nets == 2) rc = caro_net_forward(net1, planes, h->v.leaf_count, 1, max_rows, probs, values, stream);
     prof_end(h, p0, (hipStream_t)stream);
-    if (rc) return rc;
-    rc = caro_expand_backup(h, probs, values, stream);
-    if (rc) return rc;
+    if (!rc) rc = caro_expand_backup(h, probs, values, stream);
+    if (rc) { h->prof_gate = 1; return rc; }
   }
+  h->prof_gate = 1;
   return 0;
 }
 
