@@ -101,6 +101,10 @@ def main():
     ap.add_argument("--searches", type=int, default=25)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--game", default="c4", choices=["c4", "gomoku15"])
+    ap.add_argument("--arena", action="store_true",
+                    help="BASELINE config 5: best_026 vs best_025, one tree per player, tau = 0 from move 0 "
+                         "(use with --games 512 --searches 100)")
+    ap.add_argument("--node-cap", type=int, default=0, help="nodes per tree (0 = searches*batch*cells bound)")
     ap.add_argument("--weights", default=os.path.join(ROOT, "tests", "golden", "weights", "best_026_12000.dat"))
     ap.add_argument("--net", default="hip", choices=["hip", "gemm", "folded", "net"],
                     help="inference form of lib/model.py Net: fused HIP fp32 MFMA kernel (default), torch gather+GEMM, "
@@ -130,20 +134,30 @@ def main():
         game, weights, sbt0 = TicTacToe(15, 5), None, 10
     net, wtag = load_net(game, device, weights)
     G, S, B = args.games, args.searches, args.batch
+    extra = {}
+    if args.node_cap:
+        extra["node_cap"] = args.node_cap
+    if args.arena:
+        assert args.game == "c4" and args.net == "hip"
+        sbt0 = 0
+        net2, wtag2 = load_net(game, device, os.path.join(os.path.dirname(weights), "best_025_10600.dat"))
+        wtag = wtag + " vs " + wtag2
+        extra.update(n_stores=2, first_player_mode=2)
     if args.net == "hip":
         from caro_ai_amd.net_hip import HipNet
         hipnet = HipNet(net, str(device))
-        make_evaluators = lambda: [hipnet]
+        hipnets = [hipnet] + ([HipNet(net2, str(device))] if args.arena else [])
+        make_evaluators = lambda: list(hipnets)
     else:
         fnet = {"gemm": GemmNet, "folded": FoldedNet, "net": lambda n: n}[args.net](net).to(device).eval()
         make_evaluators = lambda: [torch_evaluator(fnet, form="net")]
     n_streams = args.streams if args.net == "hip" else 1
     if n_streams > 1:
         eng = StreamedSelfPlay(game, G, make_evaluators, n_streams=n_streams, max_batch=B, steps_before_tau_0=sbt0,
-                               seed=0, device=str(device), searches_hint=S, **parallel.shard(G, rank, world))
+                               seed=0, device=str(device), searches_hint=S, **extra, **parallel.shard(G, rank, world))
     else:
         eng = SelfPlayEngine(game, G, evaluators=make_evaluators(), max_batch=B, steps_before_tau_0=sbt0,
-                             seed=0, device=str(device), searches_hint=S, **parallel.shard(G, rank, world))
+                             seed=0, device=str(device), searches_hint=S, **extra, **parallel.shard(G, rank, world))
 
     n_tuples = 0
 
@@ -233,8 +247,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (self-play from empty boards; net weights: %s)" % wtag,
-            "config": {"workload": "%s %d concurrent self-play games/GPU, %dx%d = %d sims/move, tau=1 for %d plies"
-                                   % ("Connect4 6x7" if args.game == "c4" else "m,n,k 15x15 k=5", G, S, B, S * B, sbt0),
+            "config": {"workload": "%s %d concurrent %s/GPU, %dx%d = %d sims/move, tau=1 for %d plies"
+                                   % ("Connect4 6x7" if args.game == "c4" else "m,n,k 15x15 k=5", G,
+                                      "arena matches (two nets, one tree per player)" if args.arena else "self-play games",
+                                      S, B, S * B, sbt0),
                        "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py Net, %s fp32" % {"hip": "fused HIP MFMA kernel", "gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net],
                        "streams_per_gpu": n_streams,
                        "parallelism": "games sharded x%d, all-gather of tuples per step" % world},
@@ -243,10 +259,11 @@ def main():
             "net_rows_per_s": rows_all / dt_max, "mean_depth": levels_all / max(1.0, sims_all),
             "expansions_per_sim": exp_all / max(1.0, sims_all),
             "algorithmic_GBps": (levels_all * bytes_per_level + exp_all * bytes_per_exp) / dt_max / 1e9,
+            "overflows": delta["overflows"],
             "roofline": roofline,
             "roofline_tree": roofline_tree,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.arena:
             out["cpu_baseline"] = cpu_baseline(args.game, S, B, sbt0, weights, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
