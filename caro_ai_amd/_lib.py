@@ -26,7 +26,7 @@ class CaroConfig(C.Structure):
         ("steps_before_tau_0", C.c_int32), ("first_player_mode", C.c_int32),
         ("c_puct", C.c_float), ("alpha", C.c_double), ("explore", C.c_double),
         ("seed", C.c_uint64), ("uid_base", C.c_uint64), ("uid_stride", C.c_uint64),
-        ("device_id", C.c_int32), ("reserved", C.c_int32),
+        ("device_id", C.c_int32), ("evict", C.c_int32),
     ]
 
 

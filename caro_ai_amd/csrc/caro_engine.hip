@@ -48,11 +48,12 @@ enum Counter { C_SIMS, C_LEVELS, C_EXPANSIONS, C_TERMINALS, C_DROPPED, C_OVERFLO
 
 struct View {
   GameParams gp;
-  int G, n_stores, n_nets, cap, hcap, A, HW, maxply, maxd, maxB, sbt0, first_mode;
+  int G, n_stores, n_nets, cap, hcap, A, HW, maxply, maxd, maxB, sbt0, first_mode, ntab;
   float c_puct;
   double alpha, explore;
   uint64_t seed, uid_base, uid_stride;
-  // trees
+  // trees (ntab == 2: two tables per tree, tbl[t] is the live one; see k_evict)
+  int32_t* tbl;
   uint64_t* node_key;
   uint32_t* edges;
   int32_t* n_nodes;
@@ -120,6 +121,11 @@ __device__ __forceinline__ void store_board(uint64_t* p, const typename R::Board
   for (int i = 0; i < R::KW; ++i) p[i] = b.w[i];
 }
 
+// first slot of tree t's live table
+__device__ __forceinline__ size_t tbase(const View& v, int t) {
+  return (size_t)(t * v.ntab + (v.ntab == 2 ? v.tbl[t] : 0)) * (size_t)v.hcap;
+}
+
 constexpr uint64_t EMPTY_KEY = ~0ULL;  // no board has bit 63 set (C4) / overlapping planes (m,n,k)
 
 template <class R>
@@ -131,7 +137,7 @@ __device__ __forceinline__ uint32_t home_slot(const View& v, const typename R::B
 template <class R>
 __device__ __forceinline__ int probe_from(const View& v, int t, const typename R::Board& b, uint32_t i) {
   const uint32_t mask = (uint32_t)v.hcap - 1u;
-  const uint64_t* keys = v.node_key + (size_t)t * v.hcap * R::KW;
+  const uint64_t* keys = v.node_key + tbase(v, t) * R::KW;
   for (int it = 0; it < v.hcap; ++it) {
     const uint64_t* k = keys + (size_t)i * R::KW;
     const uint64_t k0 = k[0];
@@ -154,7 +160,7 @@ template <class R>
 __device__ __forceinline__ int insert_key(const View& v, int t, const typename R::Board& b) {
   const uint32_t mask = (uint32_t)v.hcap - 1u;
   uint32_t i = home_slot<R>(v, b);
-  uint64_t* keys = v.node_key + (size_t)t * v.hcap * R::KW;
+  uint64_t* keys = v.node_key + tbase(v, t) * R::KW;
   for (int it = 0; it < v.hcap; ++it) {
     uint64_t* k = keys + (size_t)i * R::KW;
     if (k[0] == EMPTY_KEY) {
@@ -239,8 +245,9 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
   const float c32 = v.c_puct;
   const double c64 = (double)v.c_puct;
 
-  const uint64_t* tkeys = v.node_key + (size_t)t * v.hcap * KW;
-  const uint32_t* tedges = v.edges + (size_t)t * v.hcap * 4 * AP;
+  const size_t tb = tbase(v, t);
+  const uint64_t* tkeys = v.node_key + tb * KW;
+  const uint32_t* tedges = v.edges + tb * 4 * AP;
   uint32_t slot = home_slot<R>(v, cur);
   while (depth < v.maxd) {
     // one latency per level: the key and the action rows of the home slot are loaded together
@@ -473,7 +480,7 @@ __device__ __forceinline__ void backup_path(const View& v, int t, float value, b
                                             const int32_t* pa, int len) {
   float cur = -value;
   for (int i = len - 1; i >= 0; --i) {
-    uint32_t* row = v.edges + ((size_t)t * v.hcap + pn[i]) * 4 * AP;
+    uint32_t* row = v.edges + (tbase(v, t) + pn[i]) * 4 * AP;
     const int a = pa[i];
     const uint32_t nraw = row[a];
     const int n = (int)(nraw & NMASK) + 1;
@@ -522,7 +529,7 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
       if (lane == 0) node = insert_key<R>(v, t, load_board<R>(v.d_key + di * KW));
       node = __shfl(node, 0);
       if (node < 0) continue;  // cannot happen while n_nodes <= cap < hcap
-      uint32_t* row = v.edges + ((size_t)t * v.hcap + node) * 4 * AP;
+      uint32_t* row = v.edges + (tbase(v, t) + node) * 4 * AP;
       for (int a = lane; a < AP; a += blockDim.x) {
         row[a] = 0u;
         row[AP + a] = 0u;
@@ -584,7 +591,7 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
     bool owner = true;
     for (int k = 0; k < j; ++k) owner = owner && !(e_node[k] == node && e_act[k] == a);
     if (!owner) continue;
-    uint32_t* row = v.edges + ((size_t)t * v.hcap + node) * 4 * AP;
+    uint32_t* row = v.edges + (tbase(v, t) + node) * 4 * AP;
     const uint32_t nraw = row[a];
     int cnt = (int)(nraw & NMASK);
     uint32_t strong = nraw & NSTRONG;
@@ -610,7 +617,7 @@ __device__ __forceinline__ void root_policy(const View& v, int g, int t, const t
   constexpr int AP = GEO::AP;
   const int node = probe<R>(v, t, root);
   for (int a = threadIdx.x; a < AP; a += blockDim.x)
-    s_n[a] = (node >= 0 && a < v.A) ? (int)(v.edges[((size_t)t * v.hcap + node) * 4 * AP + a] & NMASK) : 0;
+    s_n[a] = (node >= 0 && a < v.A) ? (int)(v.edges[(tbase(v, t) + node) * 4 * AP + a] & NMASK) : 0;
   __syncthreads();
   __shared__ int s_best;
   __shared__ double s_total;
@@ -711,6 +718,58 @@ __global__ void k_step(View v, const double* __restrict__ uniforms, int32_t* __r
   }
 }
 
+// ------------------------------------------------------------------ eviction
+// After a move only nodes whose board CONTAINS the new root can ever be looked up again (stones are never
+// removed), so every other node is dropped: the survivors are re-inserted into the tree's second table, the
+// old table is cleared on the way, and the tables swap roles.  Result-neutral: the reference keeps the dead
+// nodes in its dict but can never reach them.  n_created (= len(MCTS)) keeps counting every node ever made.
+template <class GEO>
+__global__ void k_evict(View v) {
+  using R = typename GEO::R;
+  using Board = typename R::Board;
+  constexpr int AP = GEO::AP, KW = GEO::KW;
+  const int g = blockIdx.x;
+  __shared__ int s_cnt;
+  const Board root = load_board<R>(v.root + (size_t)g * KW);
+  for (int st = 0; st < v.n_stores; ++st) {
+    const int t = g * v.n_stores + st;
+    const int live = v.tbl[t];
+    const size_t ob = (size_t)(t * 2 + live) * v.hcap, nb = (size_t)(t * 2 + (1 - live)) * v.hcap;
+    uint64_t* okeys = v.node_key + ob * KW;
+    uint64_t* nkeys = v.node_key + nb * KW;
+    const uint32_t mask = (uint32_t)v.hcap - 1u;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < v.hcap; i += blockDim.x) {
+      uint64_t* k = okeys + (size_t)i * KW;
+      if (k[0] == EMPTY_KEY) continue;
+      const Board b = load_board<R>(k);
+      k[0] = EMPTY_KEY;  // the old table ends up empty
+      if (!v.done[g] && R::contains(v.gp, b, root)) {
+        uint32_t j = (uint32_t)R::hash(b) & mask;
+        for (int it = 0; it < v.hcap; ++it) {  // claim a slot: all inserted keys are distinct
+          unsigned long long* w0 = (unsigned long long*)(nkeys + (size_t)j * KW);
+          if (atomicCAS(w0, (unsigned long long)EMPTY_KEY, (unsigned long long)b.w[0]) == (unsigned long long)EMPTY_KEY) break;
+          j = (j + 1u) & mask;
+        }
+        for (int w = 1; w < KW; ++w) nkeys[(size_t)j * KW + w] = b.w[w];
+        const uint4* src = reinterpret_cast<const uint4*>(v.edges + (ob + i) * 4 * AP);
+        uint4* dst = reinterpret_cast<uint4*>(v.edges + (nb + j) * 4 * AP);
+        for (int q = 0; q < AP; ++q) dst[q] = src[q];  // 4*AP dwords = AP uint4
+        ++mine;
+      }
+    }
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      v.n_nodes[t] = s_cnt;
+      v.tbl[t] = 1 - live;
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ reset / drain
 template <class GEO>
 __device__ __forceinline__ void reset_game(const View& v, int g, uint64_t uid, int first) {
@@ -718,11 +777,12 @@ __device__ __forceinline__ void reset_game(const View& v, int g, uint64_t uid, i
   constexpr int KW = GEO::KW;
   for (int s = 0; s < v.n_stores; ++s) {
     const int t = g * v.n_stores + s;
-    uint64_t* keys = v.node_key + (size_t)t * v.hcap * KW;
-    for (int i = threadIdx.x; i < v.hcap * KW; i += blockDim.x) keys[i] = EMPTY_KEY;
+    uint64_t* keys = v.node_key + (size_t)t * v.ntab * v.hcap * KW;
+    for (int i = threadIdx.x; i < v.ntab * v.hcap * KW; i += blockDim.x) keys[i] = EMPTY_KEY;
     if (threadIdx.x == 0) {
       v.n_nodes[t] = 0;
       v.n_created[t] = 0;
+      v.tbl[t] = 0;
     }
   }
   if (threadIdx.x == 0) {
@@ -881,7 +941,7 @@ __global__ void k_lookup(View v, long long M, const int32_t* __restrict__ game, 
   const int node = probe<R>(v, t, b);
   if (threadIdx.x == 0) found[m] = node >= 0;
   if (node < 0) return;
-  const uint32_t* row = v.edges + ((size_t)t * v.hcap + node) * 4 * AP;
+  const uint32_t* row = v.edges + (tbase(v, t) + node) * 4 * AP;
   for (int a = threadIdx.x; a < v.A; a += blockDim.x) {
     const size_t o = (size_t)m * v.A + a;
     N[o] = (int)(row[a] & NMASK);
@@ -917,7 +977,7 @@ __global__ void k_poke(View v, long long M, const int32_t* __restrict__ game, co
     __syncthreads();
     const int node = s_node;
     if (node >= 0) {
-      uint32_t* row = v.edges + ((size_t)t * v.hcap + node) * 4 * AP;
+      uint32_t* row = v.edges + (tbase(v, t) + node) * 4 * AP;
       for (int a = threadIdx.x; a < AP; a += blockDim.x) {
         const size_t o = (size_t)m * v.A + a;
         const bool in = a < v.A;
@@ -951,14 +1011,14 @@ __global__ void k_dump(View v, int game, int store, long long cap, uint64_t* key
   const int t = game * v.n_stores + store;
   const long long slot = blockIdx.x;
   if (slot >= v.hcap) return;
-  const uint64_t* k = v.node_key + ((size_t)t * v.hcap + slot) * KW;
+  const uint64_t* k = v.node_key + (tbase(v, t) + slot) * KW;
   if (k[0] == EMPTY_KEY) return;
   __shared__ int s_out;
   if (threadIdx.x == 0) s_out = atomicAdd(cursor, 1);
   __syncthreads();
   const long long node = s_out;
   if (node >= cap) return;
-  const uint32_t* row = v.edges + ((size_t)t * v.hcap + slot) * 4 * AP;
+  const uint32_t* row = v.edges + (tbase(v, t) + slot) * 4 * AP;
   for (int a = threadIdx.x; a < v.A; a += blockDim.x) {
     const size_t o = (size_t)node * v.A + a;
     N[o] = (int)(row[a] & NMASK);
@@ -989,7 +1049,7 @@ __global__ void k_get_descent(View v, int game, int b, int32_t* info, float* val
   for (int i = threadIdx.x; i < len; i += blockDim.x) {
     const int node = v.path_node[di * v.maxd + i];
     path_actions[i] = v.path_act[di * v.maxd + i];
-    for (int w = 0; w < KW; ++w) path_keys[(size_t)i * KW + w] = v.node_key[((size_t)t * v.hcap + node) * KW + w];
+    for (int w = 0; w < KW; ++w) path_keys[(size_t)i * KW + w] = v.node_key[(tbase(v, t) + node) * KW + w];
   }
 }
 
@@ -1357,6 +1417,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   v.maxB = cfg->max_batch;
   v.sbt0 = cfg->steps_before_tau_0;
   v.first_mode = cfg->first_player_mode;
+  v.ntab = cfg->evict ? 2 : 1;
   v.c_puct = cfg->c_puct;
   v.alpha = cfg->alpha;
   v.explore = cfg->explore;
@@ -1371,8 +1432,9 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   const size_t T = (size_t)v.G * v.n_stores, G = (size_t)v.G;
   int rc = 0;
 #define DA(p, n) if ((rc = dalloc(h, &p, (n))) != 0) { caro_engine_destroy(h); return rc; }
-  DA(v.node_key, T * v.hcap * KW);
-  DA(v.edges, T * v.hcap * 4 * AP);
+  DA(v.tbl, T);
+  DA(v.node_key, T * v.ntab * v.hcap * KW);
+  DA(v.edges, T * v.ntab * v.hcap * 4 * AP);
   DA(v.n_nodes, T);
   DA(v.n_created, T);
   DA(v.root, G * KW);
@@ -1511,6 +1573,8 @@ int caro_step(caro_engine* h, const double* uniforms, int32_t* actions, int32_t*
   DISPATCH(h->var, hipLaunchKernelGGL(k_step<GEO>, dim3(h->v.G), dim3(64), 0, (hipStream_t)stream, h->v, uniforms,
                                       actions, done, result));
   prof_end(h, p0, (hipStream_t)stream);
+  if (h->v.ntab == 2)  // drop the nodes the move made unreachable
+    DISPATCH(h->var, hipLaunchKernelGGL(k_evict<GEO>, dim3(h->v.G), dim3(256), 0, (hipStream_t)stream, h->v));
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -110,6 +110,18 @@ struct C4Rules {
     const int mine = cell(s, c, r) == who_move;
     return (p == 0 ? mine : !mine) ? 1.0f : 0.0f;
   }
+  // every stone of `root` is also on `node` (a position reachable from root contains it): per column the
+  // node is at least as high and agrees on the root's occupied rows
+  static CR_HD bool contains(const GameParams&, const Board& node, const Board& root) {
+    const uint64_t a = node.w[0], r = root.w[0];
+    for (int c = 0; c < 7; ++c) {
+      const int hr = height(r, c);
+      if (height(a, c) < hr) return false;
+      const uint64_t col_mask = ((1ULL << hr) - 1ULL) << (62 - (6 * c + hr - 1));  // rows 0..hr-1 of column c
+      if (hr > 0 && ((a ^ r) & col_mask)) return false;
+    }
+    return true;
+  }
   static CR_HD uint64_t hash(const Board& b) {
     uint64_t z = b.w[0] * 0x9E3779B97F4A7C15ULL;
     z ^= z >> 29;
@@ -187,6 +199,11 @@ struct MnkRules {
   // tictactoe.py:164-176: plane 0 = who_move's tokens, plane 1 = the other token; no row flip
   static CR_HD float plane(const GameParams&, const Board& b, int who_move, int p, int i) {
     return bit(b, p == 0 ? who_move : 1 - who_move, i) ? 1.0f : 0.0f;
+  }
+  static CR_HD bool contains(const GameParams&, const Board& node, const Board& root) {
+    bool ok = true;
+    for (int i = 0; i < KW; ++i) ok = ok && ((node.w[i] & root.w[i]) == root.w[i]);
+    return ok;
   }
   static CR_HD uint64_t hash(const Board& b) {
     uint64_t z = 0x243F6A8885A308D3ULL;

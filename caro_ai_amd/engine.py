@@ -51,7 +51,7 @@ class SelfPlayEngine:
     def __init__(self, game, n_games, net1=None, net2=None, evaluators=None, n_stores=1, max_batch=None,
                  node_cap=None, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, first_player_mode=2,
                  c_puct=cfg.C_PUCT, alpha=cfg.ALPHA, explore=cfg.EXPLORE, seed=0, uid_base=0, uid_stride=None,
-                 device="cuda:0", searches_hint=cfg.MCTS_SEARCHES, inference="hip"):
+                 device="cuda:0", searches_hint=cfg.MCTS_SEARCHES, inference="hip", evict=False):
         if not torch.cuda.is_available():
             raise _lib.CaroError("SelfPlayEngine needs a GPU (torch.cuda.is_available() is False); "
                                  "there is no CPU fallback")
@@ -87,6 +87,7 @@ class SelfPlayEngine:
         c.seed, c.uid_base = seed, uid_base
         c.uid_stride = uid_stride if uid_stride is not None else self.G
         c.device_id = self.device.index or 0
+        c.evict = 1 if evict else 0
         self.cfg = c
         self.n_stores = n_stores
         torch.cuda.set_device(self.device)

@@ -61,7 +61,8 @@ typedef struct caro_config {
   uint64_t uid_base;          /* uid of this engine's game 0 (rank offset in multi-GPU runs) */
   uint64_t uid_stride;        /* uid += uid_stride each time a game slot is recycled (total games in flight) */
   int32_t device_id;
-  int32_t reserved;
+  int32_t evict;              /* 1: after every move drop the nodes that can no longer be reached (boards that do
+                                 not contain the new root).  Result-neutral; node_cap then bounds the LIVE nodes. */
 } caro_config;
 
 const char* caro_last_error(void);

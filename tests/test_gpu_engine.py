@@ -291,3 +291,46 @@ def test_full_size_1024_games_invariants():
             assert not won
         assert game.from_key(keys[gidx]) == s
     eng.close()
+
+
+# ------------------------------------------------------------------ node eviction is result-neutral
+def _check_evict(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base, cap):
+    game = _game_of(d)
+    eng = _engine(game, G, [_synth(game)], n_stores=n_stores, max_batch=B, steps_before_tau_0=sbt0, seed=seed,
+                  uid_base=uid_base, node_cap=cap, evict=True)
+    tuples, games = eng.play_until(S, B, n_finished=n_finish)
+    c = eng.counters()
+    eng.close()
+    assert c["overflows"] == 0
+    ref = _oracle_games(d, games[:, 0], seed, sbt0, S, B, n_stores)
+    exp_total = 0
+    for uid, first, result, steps in games.tolist():
+        r = ref[uid]
+        assert (first, result, steps) == (r["first"], r["result"], r["steps"]), uid
+    PI_all = np.concatenate([t["pi"] for t in tuples])
+    off = 0
+    for uid in games[:, 0].tolist():
+        r = ref[uid]
+        assert np.array_equal(PI_all[off:off + r["plies"]], r["pi"][::-1]), uid
+        off += r["plies"]
+    return c
+
+
+def test_eviction_connect4_small_cap():
+    """cap 1024 live nodes per tree is far below what a whole game creates (~600-2600) once trees are shared
+    across 20+ plies without eviction: with eviction nothing overflows and every game still equals the oracle."""
+    _check_evict({"kind": "c4"}, 32, 48, 10, 25, 8, 1, seed=31, uid_base=0, cap=1024)
+    _check_evict({"kind": "c4"}, 8, 8, 0, 10, 16, 2, seed=32, uid_base=100, cap=512)
+
+
+def test_eviction_gomoku15_and_ttt():
+    _check_evict({"kind": "mnk", "n": 15, "k": 5}, 4, 4, 6, 6, 8, 1, seed=33, uid_base=0, cap=256)
+    _check_evict({"kind": "mnk", "n": 3, "k": 3}, 32, 64, 2, 25, 4, 1, seed=34, uid_base=0, cap=128)
+
+
+def test_without_eviction_the_small_cap_overflows():
+    game = _game_of({"kind": "c4"})
+    eng = _engine(game, 8, [_synth(game)], max_batch=8, steps_before_tau_0=10, seed=31, node_cap=128)
+    eng.play_until(25, 8, max_moves=12, recycle=False)
+    assert eng.counters()["overflows"] > 0  # counted, never silent
+    eng.close()
