@@ -105,6 +105,8 @@ def main():
                     help="BASELINE config 5: best_026 vs best_025, one tree per player, tau = 0 from move 0 "
                          "(use with --games 512 --searches 100)")
     ap.add_argument("--node-cap", type=int, default=0, help="nodes per tree (0 = searches*batch*cells bound)")
+    ap.add_argument("--evict", type=int, default=-1,
+                    help="drop unreachable nodes after every move (result-neutral); default: on for gomoku15")
     ap.add_argument("--weights", default=os.path.join(ROOT, "tests", "golden", "weights", "best_026_12000.dat"))
     ap.add_argument("--net", default="hip", choices=["hip", "gemm", "folded", "net"],
                     help="inference form of lib/model.py Net: fused HIP fp32 MFMA kernel (default), torch gather+GEMM, "
@@ -137,6 +139,10 @@ def main():
     extra = {}
     if args.node_cap:
         extra["node_cap"] = args.node_cap
+    evict = args.evict if args.evict >= 0 else int(args.game == "gomoku15")
+    if evict:
+        extra["evict"] = True
+        extra.setdefault("node_cap", 4096)
     if args.arena:
         assert args.game == "c4" and args.net == "hip"
         sbt0 = 0
@@ -259,7 +265,7 @@ def main():
             "net_rows_per_s": rows_all / dt_max, "mean_depth": levels_all / max(1.0, sims_all),
             "expansions_per_sim": exp_all / max(1.0, sims_all),
             "algorithmic_GBps": (levels_all * bytes_per_level + exp_all * bytes_per_exp) / dt_max / 1e9,
-            "overflows": delta["overflows"],
+            "overflows": delta["overflows"], "evict": bool(evict),
             "roofline": roofline,
             "roofline_tree": roofline_tree,
         }
