@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Self-play -> train -> arena loop, the drop-in for the reference's train.py:165-217
+on top of the batched HIP engine.
+
+Same stages, names, hyper-parameters (caro_ai_amd/config.py == config.py) and
+artefacts as the reference:
+
+  self_play          train.py:25-59    N concurrent games on the GPU instead of PLAY_EPISODES serial ones;
+                                       `speed_nodes` / `speed_steps` keep their meaning (train.py:49-54)
+  train_neural_net   train.py:62-117   TRAIN_ROUNDS batches of BATCH_SIZE sampled without replacement,
+                                       loss = MSE(v, z) + mean(-sum(log_softmax(logits) * pi)), SGD(0.1, 0.9);
+                                       the replay buffer lives on the device (tuples never visit the host)
+  evaluate           train.py:120-149  EVALUATION_ROUNDS arena games, 20 x 16 sims, tau = 0; win ratio
+  checkpoints        train.py:210-217  best_%03d_%05d.dat = torch.save(net.state_dict()) when the ratio > 0.60
+
+Declared deviations: a fresh tree per game instead of one store shared across games,
+eval-mode batch-norm during search.  Multi-GPU: games are sharded (caro_ai_amd.parallel), tuples are
+all-gathered, rank 0 trains and broadcasts the weights.
+
+    python -m caro_ai_amd.train -n run -g 0 --cuda --games 256 --iterations 50
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+
+from caro_ai_amd import _lib, parallel
+from caro_ai_amd import config as cfg
+from caro_ai_amd.lib.game import game_provider
+from caro_ai_amd.lib.model import Net, NetWrapper
+
+
+class DeviceReplayBuffer:
+    """`collections.deque(maxlen=REPLAY_BUFFER)` of (state, player, pi, z) tuples (train.py:184) as a ring of
+    device tensors.  States are kept packed (the engine's key words); NN planes are produced on the device
+    by the batched rules kernel when a batch is sampled."""
+
+    def __init__(self, game, capacity=cfg.REPLAY_BUFFER, device="cuda:0"):
+        self.game = game
+        self.capacity = int(capacity)
+        self.device = torch.device(device)
+        self.KW, self.A = game.key_words, game.action_space
+        self.states = torch.zeros((self.capacity, self.KW), dtype=torch.int64, device=self.device)
+        self.players = torch.zeros(self.capacity, dtype=torch.int32, device=self.device)
+        self.pi = torch.zeros((self.capacity, self.A), dtype=torch.float32, device=self.device)
+        self.z = torch.zeros(self.capacity, dtype=torch.float32, device=self.device)
+        self.size = 0
+        self.head = 0  # next write position
+
+    def __len__(self):
+        return self.size
+
+    def extend(self, tuples):
+        """append a drain's tuples (dict of device tensors) in order; the oldest entries fall out (deque maxlen)"""
+        n = int(tuples["z"].shape[0])
+        if n == 0:
+            return
+        if n > self.capacity:
+            tuples = {k: v[-self.capacity:] for k, v in tuples.items()}
+            n = self.capacity
+        idx = (torch.arange(n, device=self.device) + self.head) % self.capacity
+        self.states[idx] = tuples["states"].to(self.device)
+        self.players[idx] = tuples["players"].to(self.device, dtype=torch.int32)
+        self.pi[idx] = tuples["pi"].to(self.device, dtype=torch.float32)
+        self.z[idx] = tuples["z"].to(self.device, dtype=torch.float32)
+        self.head = (self.head + n) % self.capacity
+        self.size = min(self.capacity, self.size + n)
+
+    def sample(self, batch_size, generator=None):
+        """random.sample(replay_buffer, BATCH_SIZE) (train.py:77): without replacement"""
+        assert self.size >= batch_size
+        perm = torch.randperm(self.size, device=self.device, generator=generator)[:batch_size]
+        return self.states[perm], self.players[perm], self.pi[perm], self.z[perm]
+
+    def planes(self, states, players):
+        """game.states_to_training_batch on the device (lib/game rules kernel)"""
+        n = states.shape[0]
+        out = torch.empty((n,) + tuple(self.game.obs_shape), dtype=torch.float32, device=self.device)
+        if self.device.type == "cuda":
+            L = _lib.load()
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(L.caro_rules_encode_batch(self.game.kind, self.game.n, self.game.k, n,
+                                                 states.contiguous().data_ptr(), players.contiguous().data_ptr(),
+                                                 out.data_ptr(), st))
+        else:  # CPU tensors (tests of the training arithmetic): host-side rules helper
+            ints = self.game.from_keys(states.cpu().numpy().view(np.uint64))
+            out.copy_(torch.from_numpy(self.game.states_to_training_batch(ints, players.cpu().tolist())))
+        return out
+
+
+def loss_terms(out_logits, out_values, probs, values):
+    """train.py:98-106"""
+    loss_value = F.mse_loss(out_values.squeeze(-1), values)
+    loss_policy = (-F.log_softmax(out_logits, dim=1) * probs).sum(dim=1).mean()
+    return loss_policy + loss_value, loss_value, loss_policy
+
+
+def train_neural_net(game, replay_buffer, net, optimizer, device="cuda:0", train_rounds=cfg.TRAIN_ROUNDS,
+                     batch_size=cfg.BATCH_SIZE, generator=None):
+    """TRAIN_ROUNDS SGD steps on batches sampled from the replay buffer; returns the mean losses
+    (what train.py:113-117 sends to TensorBoard as loss_total / loss_value / loss_policy)."""
+    net.train()
+    sums = np.zeros(3)
+    for _ in range(train_rounds):
+        states, players, probs, values = replay_buffer.sample(batch_size, generator)
+        x = replay_buffer.planes(states, players)
+        optimizer.zero_grad()
+        out_logits, out_values = net(x)
+        loss, loss_value, loss_policy = loss_terms(out_logits, out_values, probs, values)
+        loss.backward()
+        optimizer.step()
+        sums += [loss.item(), loss_value.item(), loss_policy.item()]
+    sums /= train_rounds
+    return {"loss_total": sums[0], "loss_value": sums[1], "loss_policy": sums[2]}
+
+
+def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0, searches=cfg.MCTS_SEARCHES,
+              batch=cfg.MCTS_BATCH_SIZE, concurrent=None):
+    """Play n_games with the (best) net against itself, tuples appended on the device.
+    Returns speed_steps, speed_nodes, steps, nodes (train.py:49-58)."""
+    from caro_ai_amd.engine import SelfPlayEngine
+    rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
+    G = int(concurrent or n_games)
+    eng = SelfPlayEngine(game, G, net1=net, max_batch=batch, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, seed=seed,
+                         device=device, searches_hint=searches, uid_base=uid_base + rank * G, uid_stride=world * G)
+    t0 = time.time()
+    finished = steps = 0
+    while finished < n_games:
+        eng.search(searches, batch)
+        eng.step()
+        d = eng.drain(recycle=finished + eng.G < n_games)
+        ng = int(d["games"].shape[0])
+        if ng:
+            finished += ng
+            steps += int(d["games"][:, 3].sum().item())
+            if parallel.is_dist():
+                d = parallel.gather_tuples(d, pi_dtype=torch.float32)
+            replay_buffer.extend(d)
+        elif eng.live_games() == 0:
+            break
+    c = eng.counters()
+    dt = time.time() - t0
+    eng.close()
+    return {"speed_steps": steps / dt, "speed_nodes": c["expansions"] / dt, "steps": steps,
+            "nodes": c["expansions"], "games": finished}
+
+
+def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="cuda:0", seed=0):
+    """challenger (net1) vs champion (net2): `rounds` games, 20 x 16 sims, tau = 0 from move 0, one tree per
+    player; returns challenger_win / (wins + losses + draws)  (train.py:120-149)"""
+    from caro_ai_amd.lib.utils import play_games
+    res = play_games(game, rounds, None, challenger, champion, steps_before_tau_0=0, mcts_searches=20,
+                     mcts_batch_size=16, concurrent=rounds, seed=seed, device=device)
+    wins, losses, draws = res.count(1), res.count(-1), res.count(0)
+    return wins / max(1, wins + losses + draws)
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+
+def _writer(name):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(comment="-" + name)
+    except Exception:
+        return _NullWriter()
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("-n", "--name", required=True, help="Name of the run")
+    p.add_argument("--cuda", default=False, action="store_true", help="Enable CUDA (the HIP engine needs it)")
+    game_provider.add_game_argument(p)
+    p.add_argument("--games", type=int, default=256, help="self-play games per iteration (reference: PLAY_EPISODES=1)")
+    p.add_argument("--iterations", type=int, default=0, help="stop after this many iterations (0 = run for ever)")
+    p.add_argument("--saves", default="saves")
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    rank, local_rank, world = parallel.init()
+    device = "cuda:%d" % local_rank
+    saves_path = os.path.join(args.saves, args.name)
+    if rank == 0:
+        os.makedirs(saves_path, exist_ok=True)
+    writer = _writer(args.name) if rank == 0 else _NullWriter()
+    game = game_provider.get_game(args)
+    net = Net(input_shape=game.obs_shape, actions_n=game.action_space).to(device)
+    parallel.broadcast_weights(net)
+    best_net = NetWrapper(net)
+    optimizer = optim.SGD(net.parameters(), lr=cfg.LEARNING_RATE, momentum=0.9)
+    replay_buffer = DeviceReplayBuffer(game, cfg.REPLAY_BUFFER, device)
+    step_idx = best_idx = 0
+    while args.iterations == 0 or step_idx < args.iterations:
+        sp = self_play(game, replay_buffer, best_net.target_model, args.games, device=device, seed=step_idx,
+                       uid_base=step_idx * args.games * world)
+        step_idx += 1
+        writer.add_scalar("speed_steps", sp["speed_steps"], step_idx)
+        writer.add_scalar("speed_nodes", sp["speed_nodes"], step_idx)
+        if rank == 0:
+            print("Step %d, steps %3d, leaves %4d, steps/s %5.2f, leaves/s %6.2f, best_idx %d, replay %d" % (
+                step_idx, sp["steps"], sp["nodes"], sp["speed_steps"], sp["speed_nodes"], best_idx,
+                len(replay_buffer)), flush=True)
+        if len(replay_buffer) < cfg.MIN_REPLAY_TO_TRAIN:
+            continue
+        if rank == 0:
+            losses = train_neural_net(game, replay_buffer, net, optimizer, device)
+            for k, v in losses.items():
+                writer.add_scalar(k, v, step_idx)
+        parallel.broadcast_weights(net)
+        if step_idx % cfg.EVALUATE_EVERY_STEP == 0:
+            win_ratio = evaluate(game, net, best_net.target_model, rounds=cfg.EVALUATION_ROUNDS, device=device,
+                                 seed=step_idx)
+            if rank == 0:
+                print("Net evaluated, win ratio = %.2f" % win_ratio)
+            writer.add_scalar("eval_win_ratio", win_ratio, step_idx)
+            if win_ratio > cfg.BEST_NET_WIN_RATIO:
+                if rank == 0:
+                    print("Net is better than cur best, sync")
+                best_net.sync()
+                best_idx += 1
+                if rank == 0:
+                    torch.save(net.state_dict(), os.path.join(saves_path, "best_%03d_%05d.dat" % (best_idx, step_idx)))
+    writer.close()
+
+
+if __name__ == "__main__":
+    main()

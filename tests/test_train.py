@@ -1,0 +1,138 @@
+"""Training side of the loop: device replay ring == deque(maxlen), the loss of
+train.py:98-106, one SGD step equal to a plain restatement, checkpoint naming; GPU: a short end-to-end run."""
+import collections
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from caro_ai_amd import config as cfg
+
+
+def _tuples(n, start, KW=2, A=9):
+    return {"states": torch.arange(start, start + n, dtype=torch.int64).reshape(n, 1).repeat(1, KW),
+            "players": torch.arange(start, start + n, dtype=torch.int32) % 2,
+            "pi": torch.full((n, A), 1.0 / A, dtype=torch.float64),
+            "z": (torch.arange(start, start + n) % 3 - 1).to(torch.int32)}
+
+
+def test_replay_ring_matches_deque_maxlen():
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.train import DeviceReplayBuffer
+    g = TicTacToe()
+    rb = DeviceReplayBuffer(g, capacity=10, device="cpu")
+    dq = collections.deque(maxlen=10)
+    start = 0
+    for n in (3, 4, 6, 1, 12, 2):
+        t = _tuples(n, start)
+        rb.extend(t)
+        dq.extend(range(start, start + n))
+        start += n
+        assert len(rb) == len(dq)
+        assert sorted(rb.states[:len(rb), 0].tolist()) == sorted(dq)
+    s, p, pi, z = rb.sample(5, torch.Generator().manual_seed(0))
+    assert len(set(s[:, 0].tolist())) == 5 and set(s[:, 0].tolist()) <= set(dq)  # without replacement
+    assert pi.dtype == torch.float32 and z.dtype == torch.float32
+
+
+def test_loss_is_the_references_formula():
+    from caro_ai_amd.train import loss_terms
+    torch.manual_seed(0)
+    logits, values = torch.randn(8, 7), torch.randn(8, 1)
+    probs = torch.softmax(torch.randn(8, 7), 1)
+    z = torch.tensor([1., -1, 0, 1, 1, -1, 0, 0])
+    total, lv, lp = loss_terms(logits, values, probs, z)
+    lv_ref = ((values[:, 0] - z) ** 2).mean()
+    lp_ref = -(torch.log_softmax(logits, 1) * probs).sum(1).mean()
+    assert torch.allclose(lv, lv_ref) and torch.allclose(lp, lp_ref) and torch.allclose(total, lv_ref + lp_ref)
+
+
+def test_train_step_equals_plain_restatement_cpu():
+    """one train_neural_net round on CPU tensors == SGD(0.1, 0.9) on the same batch, written out by hand"""
+    import copy
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.lib.model import Net
+    from caro_ai_amd.train import DeviceReplayBuffer, train_neural_net
+    g = TicTacToe()
+    torch.manual_seed(1)
+    rb = DeviceReplayBuffer(g, capacity=64, device="cpu")
+    states, s = [], g.initial_state
+    rng = np.random.default_rng(0)
+    pl = 0
+    for _ in range(40):
+        legal = g.possible_moves(s)
+        if not legal:
+            s, pl = g.initial_state, 0
+            legal = g.possible_moves(s)
+        states.append((s, pl))
+        s2, won = g.move(s, int(rng.choice(legal)), pl)
+        s, pl = (g.initial_state, 0) if won else (s2, 1 - pl)
+    pi = torch.softmax(torch.randn(40, 9), 1)
+    rb.extend({"states": torch.from_numpy(g.to_keys([a for a, _ in states]).view(np.int64)),
+               "players": torch.tensor([b for _, b in states], dtype=torch.int32), "pi": pi.double(),
+               "z": torch.randint(-1, 2, (40,), dtype=torch.int32)})
+    net = Net(g.obs_shape, 9)
+    net2 = copy.deepcopy(net)
+    opt = torch.optim.SGD(net.parameters(), lr=cfg.LEARNING_RATE, momentum=0.9)
+    out = train_neural_net(g, rb, net, opt, device="cpu", train_rounds=1, batch_size=16,
+                           generator=torch.Generator().manual_seed(5))
+    # restatement (train.py:77-108)
+    perm = torch.randperm(40, generator=torch.Generator().manual_seed(5))[:16]
+    x = torch.from_numpy(g.states_to_training_batch([states[i][0] for i in perm], [states[i][1] for i in perm]))
+    opt2 = torch.optim.SGD(net2.parameters(), lr=0.1, momentum=0.9)
+    net2.train()
+    opt2.zero_grad()
+    lg, vl = net2(x)
+    lv = torch.nn.functional.mse_loss(vl.squeeze(-1), rb.z[perm])
+    lp = (-torch.log_softmax(lg, 1) * rb.pi[perm]).sum(1).mean()
+    (lv + lp).backward()
+    opt2.step()
+    assert abs(out["loss_total"] - (lv + lp).item()) < 1e-6
+    for a, b in zip(net.state_dict().values(), net2.state_dict().values()):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_short_training_run_end_to_end(tmp_path, monkeypatch):
+    """TicTacToe: self-play on the engine -> device replay -> SGD -> arena gate -> .dat checkpoint that the
+    reference's loader accepts (play.py:31-33)."""
+    from caro_ai_amd import train
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.lib.model import Net
+    monkeypatch.setattr(cfg, "MIN_REPLAY_TO_TRAIN", 300)
+    monkeypatch.setattr(cfg, "EVALUATE_EVERY_STEP", 2)
+    monkeypatch.setattr(cfg, "BEST_NET_WIN_RATIO", -1.0)   # always promote: exercises sync + save
+    monkeypatch.setattr(cfg, "EVALUATION_ROUNDS", 8)
+    monkeypatch.setattr(cfg, "BATCH_SIZE", 64)
+    monkeypatch.setattr(cfg, "TRAIN_ROUNDS", 3)
+    train.main(["-n", "t", "-g", "1", "--cuda", "--games", "128", "--iterations", "4", "--saves", str(tmp_path)])
+    files = sorted(os.listdir(tmp_path / "t"))
+    assert files and all(f.startswith("best_") and f.endswith(".dat") for f in files)
+    assert files[0] == "best_001_00002.dat"
+    g = TicTacToe()
+    net = Net(g.obs_shape, g.action_space)
+    net.load_state_dict(torch.load(str(tmp_path / "t" / files[-1]), map_location=lambda storage, loc: storage))
+    for v in net.state_dict().values():
+        assert torch.isfinite(v.float()).all()
+
+
+@pytest.mark.gpu
+def test_evaluate_ratio_and_device_planes():
+    from caro_ai_amd import train
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    from tests.conftest import GOLDEN
+    g = ConnectFour()
+    a, b = Net(g.obs_shape, 7), Net(g.obs_shape, 7)
+    a.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", "best_026_12000.dat"), map_location="cpu"))
+    torch.manual_seed(0)
+    r = train.evaluate(g, a.cuda(), b.cuda(), rounds=16)   # trained net vs random init
+    assert 0.0 <= r <= 1.0 and r >= 0.75
+    rb = train.DeviceReplayBuffer(g, 32, "cuda:0")
+    s0 = g.initial_state
+    s1, _ = g.move(s0, 3, 1)
+    keys = torch.from_numpy(g.to_keys([s0, s1]).view(np.int64)).cuda()
+    pl = torch.tensor([0, 0], dtype=torch.int32).cuda()
+    x = rb.planes(keys, pl).cpu().numpy()
+    np.testing.assert_array_equal(x, g.states_to_training_batch([s0, s1], [0, 0]))
