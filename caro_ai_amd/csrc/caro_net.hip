@@ -13,17 +13,17 @@
 //   row (3x3 padding).  Activations X[row][64] float32 stay in LDS for the whole
 //   trunk in ONE 64 KiB buffer (XOR-swizzled 16-byte granules) that is updated in
 //   place: a layer's outputs live in the MFMA accumulators until every wave has
-//   finished reading the layer's input, then overwrite it.  80 KiB of LDS and
-//   240 VGPRs per SIMD per workgroup leave room on the CU for a second net
-//   workgroup or for the tree kernels of another stream.  The
+//   finished reading the layer's input, then overwrite it.  The
 //   3x3 convolutions are implicit GEMMs on v_mfma_f32_32x32x2_f32:
 //       M = 256 rows (8 row tiles), N = 64 (2 col tiles), K = 9 taps x 64 channels,
 //   wave w owns row tile w x both col tiles (2 accumulators of 16 regs).
 //   K order inside a tap: MFMA k-half h = lane>>5 carries channel 32h + j, so a
 //   lane's A operands for 4 consecutive k-steps are one ds_read_b128.
-//   Weights stream from L2 one tap (64x64 floats = 16 KiB) at a time through a
-//   single LDS buffer: global loads for tap t+1 are issued before the MFMAs of
-//   tap t and written to LDS after them (issue-early / write-late).
+//   Weights stream from L2 in chunks of two taps (2 x 64x64 floats = 32 KiB)
+//   through a double-buffered LDS stage: global loads for chunk c+1 are issued
+//   before the MFMAs of chunk c and written to the other buffer after them
+//   (issue-early / write-late), so there is one workgroup barrier per chunk
+//   plus two per layer around the in-place epilogue.
 //   conv_in (K = 18), the 1x1 heads, the two FC heads, tanh and the softmax
 //   run on the VALU in the same kernel.
 // float32 throughout: MFMA f32 is an exact fma chain in k order.
@@ -44,7 +44,10 @@ constexpr int ZROW = 255;       // permanent zero row
 constexpr int ACT = 256 * NF;   // floats per activation buffer
 constexpr int WCHUNK = 64 * 64; // floats per tap chunk
 constexpr int NRES = 5;
-constexpr int LDS_FLOATS = ACT + WCHUNK;
+constexpr int TPC = 2;                          // taps per weight chunk
+constexpr int NTAPS = NRES * 9;                 // 45
+constexpr int NCHUNK = (NTAPS + TPC - 1) / TPC; // 23
+constexpr int LDS_FLOATS = ACT + 2 * TPC * WCHUNK;
 
 struct NetParams {
   int H, W, HW, A, TB;
@@ -70,7 +73,7 @@ __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? 
 
 constexpr int NT = 512;  // threads per workgroup
 
-__global__ __launch_bounds__(NT, 4) void k_net_forward(NetParams p, const float* __restrict__ planes,
+__global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float* __restrict__ planes,
                                                          const int32_t* __restrict__ counts, int which,
                                                          float* __restrict__ probs, float* __restrict__ values) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -130,11 +133,11 @@ __global__ __launch_bounds__(NT, 4) void k_net_forward(NetParams p, const float*
   }
   __syncthreads();
 
-  // ---- stage weights of (layer 0, tap 0)
+  // ---- stage weight chunk 0 (taps 0 and 1 of layer 0)
   {
     const float4* src = reinterpret_cast<const float4*>(p.w_res);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) reinterpret_cast<float4*>(wbuf)[tid + NT * m] = src[tid + NT * m];
+    for (int m = 0; m < 2 * TPC; ++m) reinterpret_cast<float4*>(wbuf)[tid + NT * m] = src[tid + NT * m];
   }
   __syncthreads();
 
@@ -146,87 +149,93 @@ __global__ __launch_bounds__(NT, 4) void k_net_forward(NetParams p, const float*
   const int ry = rcell / p.W, rx = rcell - ry * p.W;
   const int bswz = (i >> 1) & 7;
 
-  float* const in = act;
-  float* const out = act;  // in place: see the barrier before the epilogue
-  for (int layer = 0; layer < NRES; ++layer) {
-    f32x16 acc0, acc1;
+  f32x16 acc0, acc1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      acc0[e] = 0.f;
-      acc1[e] = 0.f;
-    }
-    for (int tap = 0; tap < 9; ++tap) {
-      const int chunk = layer * 9 + tap;
-      const bool has_next = chunk + 1 < NRES * 9;
-      float4 wn[2];
-      if (has_next) {
-        const float4* src = reinterpret_cast<const float4*>(p.w_res + (size_t)(chunk + 1) * WCHUNK);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) wn[m] = src[tid + NT * m];
-      }
-      const int ny = ry + tap / 3 - 1, nx = rx + tap % 3 - 1;
-      const bool ok = rvalid && ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
-      const int nrow = ok ? rbi * HW + ny * p.W + nx : ZROW;
-      const float* abase = in + nrow * NF;
-      const int aswz = nrow & 15;
-      const float* bbase0 = wbuf + (h * 64 + i) * 32;
-      const float* bbase1 = wbuf + (h * 64 + 32 + i) * 32;
-      // software pipeline: operands of group q+1 are read while the MFMAs of group q issue
-      float4 a = *reinterpret_cast<const float4*>(abase + (((h * 8) ^ aswz) << 2));
-      float4 b0 = *reinterpret_cast<const float4*>(bbase0 + (bswz << 2));
-      float4 b1 = *reinterpret_cast<const float4*>(bbase1 + (bswz << 2));
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float4 an, b0n, b1n;
-        if (q < 7) {
-          an = *reinterpret_cast<const float4*>(abase + (((h * 8 + q + 1) ^ aswz) << 2));
-          b0n = *reinterpret_cast<const float4*>(bbase0 + (((q + 1) ^ bswz) << 2));
-          b1n = *reinterpret_cast<const float4*>(bbase1 + (((q + 1) ^ bswz) << 2));
-        }
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
-        if (q < 7) {
-          a = an;
-          b0 = b0n;
-          b1 = b1n;
-        }
-      }
-      __syncthreads();  // every wave is done reading wbuf and (tap 8) this layer's input activations
-      if (has_next) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) reinterpret_cast<float4*>(wbuf)[tid + NT * m] = wn[m];
-      }
-      if (tap == 8) {
-        // epilogue: v = v + leaky(conv(v) + b)   (lib/model.py:85-89)
-        const float* bias = p.b_res + layer * NF;
-        const float bc0 = bias[i], bc1 = bias[32 + i];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (row < R) {
-            const int o0 = aoff(row, i), o1 = aoff(row, 32 + i);
-            out[o0] = in[o0] + leaky(acc0[e] + bc0, p.slope);
-            out[o1] = in[o1] + leaky(acc1[e] + bc1, p.slope);
-          }
-        }
-      }
-      __syncthreads();  // wbuf (and, after tap 8, the new activations) visible to every wave
-    }
+  for (int e = 0; e < 16; ++e) {
+    acc0[e] = 0.f;
+    acc1[e] = 0.f;
   }
-  // `act` now holds the trunk output; the weight buffer is free scratch (4096 floats)
+  float4 wn[2 * TPC];  // next weight chunk in flight (lives across the taps of a chunk)
+  for (int ft = 0; ft < NTAPS; ++ft) {  // flat tap index over the five residual layers
+    const int c = ft / TPC, within = ft % TPC, cur = c & 1;
+    const int layer = ft / 9, tap = ft % 9;
+    const bool last_in_chunk = within == TPC - 1 || ft == NTAPS - 1;
+    const bool has_next = c + 1 < NCHUNK;
+    if (within == 0 && has_next) {  // issue early
+      const float4* src = reinterpret_cast<const float4*>(p.w_res + (size_t)(c + 1) * TPC * WCHUNK);
+      const int nvalid = min(TPC, NTAPS - (c + 1) * TPC) * 2;  // float4 per thread actually present
+#pragma unroll
+      for (int m = 0; m < 2 * TPC; ++m)
+        if (m < nvalid) wn[m] = src[tid + NT * m];
+    }
+    const float* wcur = wbuf + cur * TPC * WCHUNK + within * WCHUNK;
+    const int ny = ry + tap / 3 - 1, nx = rx + tap % 3 - 1;
+    const bool ok = rvalid && ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
+    const int nrow = ok ? rbi * HW + ny * p.W + nx : ZROW;
+    const float* abase = act + nrow * NF;
+    const int aswz = nrow & 15;
+    const float* bbase0 = wcur + (h * 64 + i) * 32;
+    const float* bbase1 = wcur + (h * 64 + 32 + i) * 32;
+    // software pipeline: operands of group q+1 are read while the MFMAs of group q issue
+    float4 a = *reinterpret_cast<const float4*>(abase + (((h * 8) ^ aswz) << 2));
+    float4 b0 = *reinterpret_cast<const float4*>(bbase0 + (bswz << 2));
+    float4 b1 = *reinterpret_cast<const float4*>(bbase1 + (bswz << 2));
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float4 an, b0n, b1n;
+      if (q < 7) {
+        an = *reinterpret_cast<const float4*>(abase + (((h * 8 + q + 1) ^ aswz) << 2));
+        b0n = *reinterpret_cast<const float4*>(bbase0 + (((q + 1) ^ bswz) << 2));
+        b1n = *reinterpret_cast<const float4*>(bbase1 + (((q + 1) ^ bswz) << 2));
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+      if (q < 7) {
+        a = an;
+        b0 = b0n;
+        b1 = b1n;
+      }
+    }
+    if (last_in_chunk && has_next) {  // write late: the other buffer was last read one chunk ago
+      float4* dst = reinterpret_cast<float4*>(wbuf + (cur ^ 1) * TPC * WCHUNK);
+      const int nvalid = min(TPC, NTAPS - (c + 1) * TPC) * 2;
+#pragma unroll
+      for (int m = 0; m < 2 * TPC; ++m)
+        if (m < nvalid) dst[tid + NT * m] = wn[m];
+    }
+    if (tap == 8) {
+      __syncthreads();  // every wave has read this layer's input activations: they may be overwritten
+      // epilogue, in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89)
+      const float* bias = p.b_res + layer * NF;
+      const float bc0 = bias[i], bc1 = bias[32 + i];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < R) {
+          const int o0 = aoff(row, i), o1 = aoff(row, 32 + i);
+          act[o0] = act[o0] + leaky(acc0[e] + bc0, p.slope);
+          act[o1] = act[o1] + leaky(acc1[e] + bc1, p.slope);
+        }
+        acc0[e] = 0.f;
+        acc1[e] = 0.f;
+      }
+    }
+    if (last_in_chunk || tap == 8) __syncthreads();  // staged weights / new activations visible to every wave
+  }
+  // `act` now holds the trunk output; the weight stage is free scratch
   float* feat = wbuf;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
   {
     const int r = tid;
     if (r < R) {
       float s0 = p.b_head[0], s1 = p.b_head[1], s2 = p.b_head[2];
       for (int g = 0; g < 16; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(in + r * NF + ((g ^ (r & 15)) << 2));
+        const float4 v = *reinterpret_cast<const float4*>(act + r * NF + ((g ^ (r & 15)) << 2));
         const int c = g * 4;
         s0 = fmaf(v.x, p.w_head[c], s0); s0 = fmaf(v.y, p.w_head[c + 1], s0);
         s0 = fmaf(v.z, p.w_head[c + 2], s0); s0 = fmaf(v.w, p.w_head[c + 3], s0);
