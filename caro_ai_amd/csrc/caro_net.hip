@@ -105,25 +105,20 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
       const int bi = r / HW, cell = r - bi * HW;
       const int y = cell / p.W, x = cell - y * p.W;
       const float* pl = planes + (size_t)(row0 + board0 + bi) * 2 * HW;
-      float in[18];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int ny = y + t / 3 - 1, nx = x + t % 3 - 1;
-        const bool ok = ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
-        in[2 * t] = ok ? pl[ny * p.W + nx] : 0.f;
-        in[2 * t + 1] = ok ? pl[HW + ny * p.W + nx] : 0.f;
-      }
       for (int c4 = chalf * 8; c4 < chalf * 8 + 8; ++c4) {
         float o[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = p.b_in[c4 * 4 + u];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) {
-          const float4 w = *reinterpret_cast<const float4*>(wbuf + k * NF + c4 * 4);
-          o[0] = fmaf(in[k], w.x, o[0]);
-          o[1] = fmaf(in[k], w.y, o[1]);
-          o[2] = fmaf(in[k], w.z, o[2]);
-          o[3] = fmaf(in[k], w.w, o[3]);
+        for (int t = 0; t < 9; ++t) {  // the 18 inputs are re-read per channel group (L1 hits): no per-thread array
+          const int ny = y + t / 3 - 1, nx = x + t % 3 - 1;
+          const bool ok = ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
+          const float i0 = ok ? pl[ny * p.W + nx] : 0.f;
+          const float i1 = ok ? pl[HW + ny * p.W + nx] : 0.f;
+          const float4 w0 = *reinterpret_cast<const float4*>(wbuf + (2 * t) * NF + c4 * 4);
+          const float4 w1 = *reinterpret_cast<const float4*>(wbuf + (2 * t + 1) * NF + c4 * 4);
+          o[0] = fmaf(i0, w0.x, o[0]); o[1] = fmaf(i0, w0.y, o[1]); o[2] = fmaf(i0, w0.z, o[2]); o[3] = fmaf(i0, w0.w, o[3]);
+          o[0] = fmaf(i1, w1.x, o[0]); o[1] = fmaf(i1, w1.y, o[1]); o[2] = fmaf(i1, w1.z, o[2]); o[3] = fmaf(i1, w1.w, o[3]);
         }
         float4 out = make_float4(leaky(o[0], p.slope), leaky(o[1], p.slope), leaky(o[2], p.slope),
                                  leaky(o[3], p.slope));
@@ -155,18 +150,21 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
     acc0[e] = 0.f;
     acc1[e] = 0.f;
   }
-  float4 wn[2 * TPC];  // next weight chunk in flight (lives across the taps of a chunk)
+  static_assert(TPC == 2, "the staging registers below are written out for two taps per chunk");
+  float4 wn0, wn1, wn2, wn3;  // next weight chunk in flight (lives across the taps of a chunk)
+  wn0 = wn1 = wn2 = wn3 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int ft = 0; ft < NTAPS; ++ft) {  // flat tap index over the five residual layers
     const int c = ft / TPC, within = ft % TPC, cur = c & 1;
     const int layer = ft / 9, tap = ft % 9;
     const bool last_in_chunk = within == TPC - 1 || ft == NTAPS - 1;
     const bool has_next = c + 1 < NCHUNK;
     if (within == 0 && has_next) {  // issue early
+      // the last chunk holds one tap only; its second half reads the zero padding behind the packed weights
       const float4* src = reinterpret_cast<const float4*>(p.w_res + (size_t)(c + 1) * TPC * WCHUNK);
-      const int nvalid = min(TPC, NTAPS - (c + 1) * TPC) * 2;  // float4 per thread actually present
-#pragma unroll
-      for (int m = 0; m < 2 * TPC; ++m)
-        if (m < nvalid) wn[m] = src[tid + NT * m];
+      wn0 = src[tid];
+      wn1 = src[tid + NT];
+      wn2 = src[tid + 2 * NT];
+      wn3 = src[tid + 3 * NT];
     }
     const float* wcur = wbuf + cur * TPC * WCHUNK + within * WCHUNK;
     const int ny = ry + tap / 3 - 1, nx = rx + tap % 3 - 1;
@@ -204,10 +202,10 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
     }
     if (last_in_chunk && has_next) {  // write late: the other buffer was last read one chunk ago
       float4* dst = reinterpret_cast<float4*>(wbuf + (cur ^ 1) * TPC * WCHUNK);
-      const int nvalid = min(TPC, NTAPS - (c + 1) * TPC) * 2;
-#pragma unroll
-      for (int m = 0; m < 2 * TPC; ++m)
-        if (m < nvalid) dst[tid + NT * m] = wn[m];
+      dst[tid] = wn0;
+      dst[tid + NT] = wn1;
+      dst[tid + 2 * NT] = wn2;
+      dst[tid + 3 * NT] = wn3;
     }
     if (tap == 8) {
       __syncthreads();  // every wave has read this layer's input activations: they may be overwritten
@@ -330,11 +328,13 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   if (hipSetDevice(device_id) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
   caro_net* n = new caro_net();
   n->device = device_id;
-  if (hipMalloc((void**)&n->dev, n_floats * sizeof(float)) != hipSuccess) {
+  const size_t pad = (size_t)cnet::TPC * cnet::WCHUNK;  // k_net_forward reads one chunk past the last tap
+  if (hipMalloc((void**)&n->dev, (n_floats + pad) * sizeof(float)) != hipSuccess) {
     delete n;
     return nfail(CARO_E_NOMEM, "hipMalloc failed");
   }
-  if (hipMemcpy(n->dev, packed_host, n_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+  if (hipMemset(n->dev + n_floats, 0, pad * sizeof(float)) != hipSuccess ||
+      hipMemcpy(n->dev, packed_host, n_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(n->dev);
     delete n;
     return nfail(CARO_E_HIP, "hipMemcpy failed");
