@@ -75,7 +75,8 @@ constexpr int NT = 512;  // threads per workgroup
 
 __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float* __restrict__ planes,
                                                          const int32_t* __restrict__ counts, int which,
-                                                         float* __restrict__ probs, float* __restrict__ values) {
+                                                         float* __restrict__ probs, float* __restrict__ values,
+                                                         unsigned long long* __restrict__ stamps) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* act = lds;
   float* wbuf = lds + ACT;
@@ -84,6 +85,12 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
   const int row0 = which ? counts[0] : 0;
   const int board0 = blockIdx.x * p.TB;
   if (board0 >= L) return;
+  // diagnostic only (stamps == nullptr in every product launch): shader clock vs 100 MHz wall clock
+  unsigned long long t_c0 = 0, t_r0 = 0;
+  if (stamps) {
+    t_c0 = __builtin_amdgcn_s_memtime();
+    t_r0 = __builtin_amdgcn_s_memrealtime();
+  }
   const int nb = min(p.TB, L - board0);
   const int HW = p.HW;
   const int R = nb * HW;  // real rows
@@ -289,6 +296,10 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
     const int bi = k / p.A;
     probs[(size_t)(row0 + board0) * p.A + k] = __expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
   }
+  if (stamps && tid == 0) {
+    stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
+    stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
+  }
 }
 
 }  // namespace cnet
@@ -375,7 +386,19 @@ int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts
   if (max_rows <= 0) return 0;
   const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
   hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, planes_dev,
-                     counts_dev, which, probs_dev, values_dev);
+                     counts_dev, which, probs_dev, values_dev, (unsigned long long*)nullptr);
+  if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
+  return 0;
+}
+
+/* diagnostic: same launch, and per workgroup (shader cycles, 100 MHz ticks) into stamps_dev u64[2*grid] */
+int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which,
+                             int64_t max_rows, float* probs_dev, float* values_dev, uint64_t* stamps_dev,
+                             void* stream) {
+  if (!n || !stamps_dev) return nfail(CARO_E_INVAL, "null argument");
+  const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
+  hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, planes_dev,
+                     counts_dev, which, probs_dev, values_dev, (unsigned long long*)stamps_dev);
   if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
   return 0;
 }

@@ -219,6 +219,11 @@ int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts
  * (hipExtStreamCreateWithCUMask): independent engines on such streams run side by side on disjoint CUs. */
 int caro_stream_create_partition(int device_id, int part, int nparts, void** stream_out);
 int caro_stream_destroy(void* stream);
+/* diagnostic form: also writes per workgroup (shader cycles, 100 MHz wall ticks) to stamps_dev u64[2*grid],
+ * grid = ceil(max_rows / caro_net_boards_per_workgroup); used by tools/probe_clock.py only */
+int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which,
+                             int64_t max_rows, float* probs_dev, float* values_dev, uint64_t* stamps_dev,
+                             void* stream);
 /* MCTS.search_batch (lib/mcts.py:162-176) for every live game with the fused net(s): `searches` x
  * (caro_select -> caro_net_forward per net -> caro_expand_backup) enqueued on `stream` from one call, no host
  * synchronisation.  noise_dev: f64[searches, G, batch, A] or NULL (generated); buffers as for caro_select /

@@ -1,0 +1,28 @@
+"""In-kernel clock of k_net_forward: per-workgroup shader cycles / 100 MHz ticks, after warm-up."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from caro_ai_amd import _lib
+from caro_ai_amd.lib.model import Net
+from caro_ai_amd.net_hip import HipNet
+L = _lib.load()
+net = Net((2, 6, 7), 7); net.load_state_dict(torch.load("tests/golden/weights/best_026_12000.dat", map_location="cpu"))
+hn = HipNet(net, "cuda:0")
+for rows in (1434, 600):
+    x = (torch.rand((rows, 2, 6, 7), device="cuda") < 0.3).float()
+    counts = torch.tensor([rows, 0], dtype=torch.int32, device="cuda")
+    probs = torch.empty((rows, 7), device="cuda"); vals = torch.empty(rows, device="cuda")
+    grid = (rows + 5) // 6
+    stamps = torch.zeros(2 * grid, dtype=torch.int64, device="cuda")
+    for _ in range(2000):   # ~0.5 s of back-to-back launches
+        hn.forward_dev(x, counts.data_ptr(), 0, rows, probs, vals, None)
+    _lib.check(L.caro_net_forward_stamped(hn.h, x.data_ptr(), counts.data_ptr(), 0, rows, probs.data_ptr(),
+                                          vals.data_ptr(), stamps.data_ptr(), None))
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy().reshape(-1, 2).astype(np.float64)
+    cyc, rt = s[:, 0], s[:, 1]
+    ghz = cyc / (rt * 10.0)
+    print("rows %d: workgroups %d, cycles median %.0f, wall us median %.1f, clock GHz median %.3f (min %.3f max %.3f)" % (
+        rows, grid, np.median(cyc), np.median(rt) / 100.0, np.median(ghz), ghz.min(), ghz.max()))
+    print("   MFMA-bound cycles per workgroup = 23040 MFMA x 64 / 4 SIMD = 368640 -> %.1f %% of the measured cycles" % (
+        100 * 368640 / np.median(cyc)))
