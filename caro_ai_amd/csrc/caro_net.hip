@@ -83,10 +83,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
 
   const int L = counts[which];
   const int row0 = which ? counts[0] : 0;
-  // persistent grid: at most one workgroup per CU, each strides over the tiles of TB boards (every wave of
-  // the workgroup sees the same L, so the trip count is workgroup-uniform and the barriers inside are safe)
-  for (int tile = blockIdx.x; tile * p.TB < L; tile += gridDim.x) {
-  const int board0 = tile * p.TB;
+  const int board0 = blockIdx.x * p.TB;
+  if (board0 >= L) return;
   // diagnostic only (stamps == nullptr in every product launch): shader clock vs 100 MHz wall clock
   unsigned long long t_c0 = 0, t_r0 = 0;
   if (stamps) {
@@ -299,11 +297,9 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
     probs[(size_t)(row0 + board0) * p.A + k] = __expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
   }
   if (stamps && tid == 0) {
-    stamps[2 * tile] = __builtin_amdgcn_s_memtime() - t_c0;
-    stamps[2 * tile + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
+    stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
+    stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
   }
-  __syncthreads();  // the LDS buffers are re-initialised by the next tile
-  }  // tile loop
 }
 
 }  // namespace cnet
@@ -315,7 +311,6 @@ struct caro_net {
   cnet::NetParams p;
   float* dev;
   int device;
-  int n_cu;
 };
 
 static int nfail(int code, const std::string& m) {
@@ -344,11 +339,6 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   if (hipSetDevice(device_id) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
   caro_net* n = new caro_net();
   n->device = device_id;
-  {
-    hipDeviceProp_t prop;
-    n->n_cu = hipGetDeviceProperties(&prop, device_id) == hipSuccess ? prop.multiProcessorCount : 256;
-    if (n->n_cu < 1) n->n_cu = 256;
-  }
   const size_t pad = (size_t)cnet::TPC * cnet::WCHUNK;  // k_net_forward reads one chunk past the last tap
   if (hipMalloc((void**)&n->dev, (n_floats + pad) * sizeof(float)) != hipSuccess) {
     delete n;
@@ -394,8 +384,7 @@ int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts
   if (!n || !planes_dev || !counts_dev || !probs_dev || !values_dev) return nfail(CARO_E_INVAL, "null argument");
   if (which != 0 && which != 1) return nfail(CARO_E_INVAL, "which must be 0 or 1");
   if (max_rows <= 0) return 0;
-  const int64_t tiles = (max_rows + n->p.TB - 1) / n->p.TB;
-  const unsigned grid = (unsigned)(tiles < n->n_cu ? tiles : n->n_cu);  // persistent: one workgroup per CU
+  const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
   hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, planes_dev,
                      counts_dev, which, probs_dev, values_dev, (unsigned long long*)nullptr);
   if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
@@ -407,8 +396,7 @@ int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t
                              int64_t max_rows, float* probs_dev, float* values_dev, uint64_t* stamps_dev,
                              void* stream) {
   if (!n || !stamps_dev) return nfail(CARO_E_INVAL, "null argument");
-  const int64_t tiles = (max_rows + n->p.TB - 1) / n->p.TB;
-  const unsigned grid = (unsigned)(tiles < n->n_cu ? tiles : n->n_cu);
+  const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
   hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, planes_dev,
                      counts_dev, which, probs_dev, values_dev, (unsigned long long*)stamps_dev);
   if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");

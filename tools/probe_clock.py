@@ -12,7 +12,7 @@ for rows in (1434, 600):
     x = (torch.rand((rows, 2, 6, 7), device="cuda") < 0.3).float()
     counts = torch.tensor([rows, 0], dtype=torch.int32, device="cuda")
     probs = torch.empty((rows, 7), device="cuda"); vals = torch.empty(rows, device="cuda")
-    grid = (rows + 5) // 6   # tiles
+    grid = (rows + 5) // 6
     stamps = torch.zeros(2 * grid, dtype=torch.int64, device="cuda")
     for _ in range(2000):   # ~0.5 s of back-to-back launches
         hn.forward_dev(x, counts.data_ptr(), 0, rows, probs, vals, None)
