@@ -1549,8 +1549,8 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
     int rc = caro_select(h, batch, mb, noise ? noise + (size_t)mb * noise_stride : nullptr, planes, leaf_keys, stream);
     if (rc) { h->prof_gate = 1; return rc; }
     const int p0 = prof_begin(h, PK_NET, (hipStream_t)stream);
-    rc = caro_net_forward(net0, planes, h->v.leaf_count, 0, max_rows, probs, values, stream);
-    if (!rc && h->v.n_nets == 2) rc = caro_net_forward(net1, planes, h->v.leaf_count, 1, max_rows, probs, values, stream);
+    if (h->v.n_nets == 2) rc = caro_net_forward_pair(net0, net1, planes, h->v.leaf_count, max_rows, probs, values, stream);
+    else rc = caro_net_forward(net0, planes, h->v.leaf_count, 0, max_rows, probs, values, stream);
     prof_end(h, p0, (hipStream_t)stream);
     if (!rc) rc = caro_expand_backup(h, probs, values, stream);
     if (rc) { h->prof_gate = 1; return rc; }

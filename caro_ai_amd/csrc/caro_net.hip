@@ -73,7 +73,9 @@ __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? 
 
 constexpr int NT = 512;  // threads per workgroup
 
-__global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float* __restrict__ planes,
+// `which` = 0 / 1: rows of that net only (p0 is used).  `which` = 2: both nets in ONE launch -- tiles
+// [0, ceil(L0/TB)) run net 0 on rows [0, L0), the following tiles run net 1 (p1) on rows [L0, L0+L1).
+__global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p1, const float* __restrict__ planes,
                                                          const int32_t* __restrict__ counts, int which,
                                                          float* __restrict__ probs, float* __restrict__ values,
                                                          unsigned long long* __restrict__ stamps) {
@@ -81,10 +83,22 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p, const float*
   float* act = lds;
   float* wbuf = lds + ACT;
 
-  const int L = counts[which];
-  const int row0 = which ? counts[0] : 0;
-  const int board0 = blockIdx.x * p.TB;
+  int L, row0, board0;
+  bool second = false;
+  if (which < 2) {
+    L = counts[which];
+    row0 = which ? counts[0] : 0;
+    board0 = blockIdx.x * p0.TB;
+  } else {
+    const int L0 = counts[0];
+    const int t0 = (L0 + p0.TB - 1) / p0.TB;
+    second = (int)blockIdx.x >= t0;
+    L = second ? counts[1] : L0;
+    row0 = second ? L0 : 0;
+    board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
+  }
   if (board0 >= L) return;
+  const NetParams& p = second ? p1 : p0;
   // diagnostic only (stamps == nullptr in every product launch): shader clock vs 100 MHz wall clock
   unsigned long long t_c0 = 0, t_r0 = 0;
   if (stamps) {
@@ -385,8 +399,21 @@ int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts
   if (which != 0 && which != 1) return nfail(CARO_E_INVAL, "which must be 0 or 1");
   if (max_rows <= 0) return 0;
   const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
-  hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, planes_dev,
+  hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p, planes_dev,
                      counts_dev, which, probs_dev, values_dev, (unsigned long long*)nullptr);
+  if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
+  return 0;
+}
+
+/* both nets of an arena in one launch: rows [0, L0) through n0, rows [L0, L0+L1) through n1 */
+int caro_net_forward_pair(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
+                          int64_t max_rows, float* probs_dev, float* values_dev, void* stream) {
+  if (!n0 || !n1 || !planes_dev || !counts_dev || !probs_dev || !values_dev) return nfail(CARO_E_INVAL, "null argument");
+  if (n0->p.H != n1->p.H || n0->p.W != n1->p.W || n0->p.A != n1->p.A) return nfail(CARO_E_INVAL, "nets differ in shape");
+  if (max_rows <= 0) return 0;
+  const unsigned grid = (unsigned)((max_rows + n0->p.TB - 1) / n0->p.TB + 1);  // +1: each class rounds up
+  hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n0->p, n1->p, planes_dev,
+                     counts_dev, 2, probs_dev, values_dev, (unsigned long long*)nullptr);
   if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
   return 0;
 }
@@ -397,7 +424,7 @@ int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t
                              void* stream) {
   if (!n || !stamps_dev) return nfail(CARO_E_INVAL, "null argument");
   const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
-  hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, planes_dev,
+  hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p, planes_dev,
                      counts_dev, which, probs_dev, values_dev, (unsigned long long*)stamps_dev);
   if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
   return 0;

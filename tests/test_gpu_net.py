@@ -83,3 +83,28 @@ def test_hip_net_device_count_and_second_net_offset():
     # same boards, different position inside the workgroup tile: same arithmetic, same bits
     assert torch.allclose(probs[20:50], p_all[20:50], atol=1e-6) and torch.allclose(values[20:50], v_all[20:50], atol=1e-6)
     hn.close()
+
+
+def test_pair_launch_equals_two_single_launches():
+    """arena: one launch serving both nets gives the same bits as one launch per net"""
+    from caro_ai_amd import _lib
+    from caro_ai_amd.net_hip import HipNet
+    L = _lib.load()
+    n0 = HipNet(_net((2, 6, 7), 7, "best_026_12000.dat"), "cuda:0")
+    n1 = HipNet(_net((2, 6, 7), 7, "best_025_10600.dat"), "cuda:0")
+    for l0, l1 in [(13, 22), (0, 9), (6, 0), (12, 12), (1, 1)]:
+        rows = l0 + l1
+        x = torch.zeros((64, 2, 6, 7), device="cuda:0")
+        x[:rows] = _boards(rows, (2, 6, 7), rows + 1).to("cuda:0")
+        counts = torch.tensor([l0, l1], dtype=torch.int32, device="cuda:0")
+        pa = torch.full((64, 7), -1.0, device="cuda:0"); va = torch.full((64,), -9.0, device="cuda:0")
+        pb = torch.full((64, 7), -1.0, device="cuda:0"); vb = torch.full((64,), -9.0, device="cuda:0")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.caro_net_forward_pair(n0.h, n1.h, x.data_ptr(), counts.data_ptr(), 64, pa.data_ptr(),
+                                           va.data_ptr(), st))
+        n0.forward_dev(x, counts.data_ptr(), 0, 64, pb, vb, st)
+        n1.forward_dev(x, counts.data_ptr(), 1, 64, pb, vb, st)
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(va, vb), (l0, l1)
+        assert (pa[rows:] == -1).all()
+    n0.close(); n1.close()
