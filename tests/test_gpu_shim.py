@@ -261,3 +261,32 @@ def test_real_weights_gpu_net_tolerance(inference):
         eng.close()
     print("%s: identical root-N plies %d / %d, max |dpi| on the others %.4f" % (inference, same, total, max_dpi))
     assert total >= 10 and same / total >= 0.8 and max_dpi <= 0.15
+
+
+def test_play_cli_round_robin(capsys):
+    """play.py drop-in: two checkpoints, every ordered pair, W/L/D bookkeeping adds up (play.py:40-76)."""
+    from caro_ai_amd import play
+    a = os.path.join(GOLDEN, "weights", "best_026_12000.dat")
+    b = os.path.join(GOLDEN, "weights", "best_025_10600.dat")
+    agents, pairs = play.main(["-g", "0", "--cuda", a, b, "-r", "8"])
+    out = capsys.readouterr().out
+    assert "Leaderboard:" in out and out.count(" vs ") == 2
+    assert sum(pairs[(a, b)]) == 8 and sum(pairs[(b, a)]) == 8
+    wa, la, da = agents[a]
+    wb, lb, db = agents[b]
+    assert (wa, la, da) == (lb, wb, db) and wa + la + da == 16
+
+
+def test_play_session_bot_moves():
+    """lib/play_session.py: the bot answers a human move; state, legality and the value read-out behave."""
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.play_session import Session
+    np.random.seed(0)
+    g = ConnectFour()
+    s = Session(g, os.path.join(GOLDEN, "weights", "best_026_12000.dat"), player_moves_first=True)
+    assert s.is_valid_move(3) and not s.is_draw()
+    assert s.move_player(3) is False
+    won = s.move_bot()
+    assert won is False and len(s.moves) == 2 and s.moves[1] in range(7)
+    assert s.value is not None and "<pre>" in s.render()
+    assert len(s.mcts_store) > 10
