@@ -99,6 +99,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
   }
   if (board0 >= L) return;
   const NetParams& p = second ? p1 : p0;
+  const float slope = p.slope;
   // diagnostic only (stamps == nullptr in every product launch): shader clock vs 100 MHz wall clock
   unsigned long long t_c0 = 0, t_r0 = 0;
   if (stamps) {
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
           o[0] = fmaf(i0, w0.x, o[0]); o[1] = fmaf(i0, w0.y, o[1]); o[2] = fmaf(i0, w0.z, o[2]); o[3] = fmaf(i0, w0.w, o[3]);
           o[0] = fmaf(i1, w1.x, o[0]); o[1] = fmaf(i1, w1.y, o[1]); o[2] = fmaf(i1, w1.z, o[2]); o[3] = fmaf(i1, w1.w, o[3]);
         }
-        float4 out = make_float4(leaky(o[0], p.slope), leaky(o[1], p.slope), leaky(o[2], p.slope),
-                                 leaky(o[3], p.slope));
+        float4 out = make_float4(leaky(o[0], slope), leaky(o[1], slope), leaky(o[2], slope),
+                                 leaky(o[3], slope));
         *reinterpret_cast<float4*>(act + r * NF + ((c4 ^ (r & 15)) << 2)) = out;
       }
     }
@@ -230,17 +231,25 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
     }
     if (tap == 8) {
       __syncthreads();  // every wave has read this layer's input activations: they may be overwritten
-      // epilogue, in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89)
+      // epilogue, in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89).  Branch-free: rows >= R (dummy
+      // rows and the zero row) are rewritten with zeros; all 32 residual reads are issued before the first use.
       const float* bias = p.b_res + layer * NF;
       const float bc0 = bias[i], bc1 = bias[32 + i];
+      float old0[16], old1[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < R) {
-          const int o0 = aoff(row, i), o1 = aoff(row, 32 + i);
-          act[o0] = act[o0] + leaky(acc0[e] + bc0, p.slope);
-          act[o1] = act[o1] + leaky(acc1[e] + bc1, p.slope);
-        }
+        old0[e] = act[aoff(row, i)];
+        old1[e] = act[aoff(row, 32 + i)];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const bool real = row < R;
+        const float n0 = old0[e] + leaky(acc0[e] + bc0, slope);
+        const float n1 = old1[e] + leaky(acc1[e] + bc1, slope);
+        act[aoff(row, i)] = real ? n0 : 0.f;
+        act[aoff(row, 32 + i)] = real ? n1 : 0.f;
         acc0[e] = 0.f;
         acc1[e] = 0.f;
       }
@@ -263,9 +272,9 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
         s2 = fmaf(v.x, p.w_head[2 * NF + c], s2); s2 = fmaf(v.y, p.w_head[2 * NF + c + 1], s2);
         s2 = fmaf(v.z, p.w_head[2 * NF + c + 2], s2); s2 = fmaf(v.w, p.w_head[2 * NF + c + 3], s2);
       }
-      feat[r] = leaky(s0, p.slope);
-      feat[256 + r] = leaky(s1, p.slope);
-      feat[512 + r] = leaky(s2, p.slope);
+      feat[r] = leaky(s0, slope);
+      feat[256 + r] = leaky(s1, slope);
+      feat[512 + r] = leaky(s2, slope);
     }
   }
   __syncthreads();
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
     const float* w = p.w_v1 + u * HW;
     const float* f = feat + bi * HW;
     for (int c = 0; c < HW; ++c) s = fmaf(f[c], w[c], s);
-    hid[k] = leaky(s, p.slope);
+    hid[k] = leaky(s, slope);
   }
   // policy head: Linear(2*HW, A) on the (c, y, x)-flattened planes
   for (int k = tid; k < nb * p.A; k += NT) {
