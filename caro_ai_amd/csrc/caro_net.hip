@@ -19,7 +19,7 @@
 //   wave w owns row tile w x both col tiles (2 accumulators of 16 regs).
 //   K order inside a tap: MFMA k-half h = lane>>5 carries channel 32h + j, so a
 //   lane's A operands for 4 consecutive k-steps are one ds_read_b128.
-//   Weights stream from L2 in chunks of two taps (2 x 64x64 floats = 32 KiB)
+//   Weights stream from L2 in chunks of three taps (3 x 64x64 floats = 48 KiB)
 //   through a double-buffered LDS stage: global loads for chunk c+1 are issued
 //   before the MFMAs of chunk c and written to the other buffer after them
 //   (issue-early / write-late), so there is one workgroup barrier per chunk
@@ -44,9 +44,9 @@ constexpr int ZROW = 255;       // permanent zero row
 constexpr int ACT = 256 * NF;   // floats per activation buffer
 constexpr int WCHUNK = 64 * 64; // floats per tap chunk
 constexpr int NRES = 5;
-constexpr int TPC = 2;                          // taps per weight chunk
+constexpr int TPC = 3;                          // taps per weight chunk (3 chunks per layer)
 constexpr int NTAPS = NRES * 9;                 // 45
-constexpr int NCHUNK = (NTAPS + TPC - 1) / TPC; // 23
+constexpr int NCHUNK = (NTAPS + TPC - 1) / TPC; // 15
 constexpr int LDS_FLOATS = ACT + 2 * TPC * WCHUNK;
 
 struct NetParams {
@@ -150,6 +150,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
   }
   __syncthreads();
 
+  unsigned long long t_trunk0 = 0;
+  if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
   // ---- stage weight chunk 0 (taps 0 and 1 of layer 0)
   {
     const float4* src = reinterpret_cast<const float4*>(p.w_res);
@@ -172,9 +174,9 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
     acc0[e] = 0.f;
     acc1[e] = 0.f;
   }
-  static_assert(TPC == 2, "the staging registers below are written out for two taps per chunk");
-  float4 wn0, wn1, wn2, wn3;  // next weight chunk in flight (lives across the taps of a chunk)
-  wn0 = wn1 = wn2 = wn3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  static_assert(TPC == 3, "the staging registers below are written out for three taps per chunk");
+  float4 wn0, wn1, wn2, wn3, wn4, wn5;  // next weight chunk in flight (lives across the taps of a chunk)
+  wn0 = wn1 = wn2 = wn3 = wn4 = wn5 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int ft = 0; ft < NTAPS; ++ft) {  // flat tap index over the five residual layers
     const int c = ft / TPC, within = ft % TPC, cur = c & 1;
     const int layer = ft / 9, tap = ft % 9;
@@ -187,6 +189,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
       wn1 = src[tid + NT];
       wn2 = src[tid + 2 * NT];
       wn3 = src[tid + 3 * NT];
+      wn4 = src[tid + 4 * NT];
+      wn5 = src[tid + 5 * NT];
     }
     const float* wcur = wbuf + cur * TPC * WCHUNK + within * WCHUNK;
     const int ny = ry + tap / 3 - 1, nx = rx + tap % 3 - 1;
@@ -196,38 +200,47 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
     const int aswz = nrow & 15;
     const float* bbase0 = wcur + (h * 64 + i) * 32;
     const float* bbase1 = wcur + (h * 64 + 32 + i) * 32;
-    // software pipeline: operands of group q+1 are read while the MFMAs of group q issue
-    float4 a = *reinterpret_cast<const float4*>(abase + (((h * 8) ^ aswz) << 2));
-    float4 b0 = *reinterpret_cast<const float4*>(bbase0 + (bswz << 2));
-    float4 b1 = *reinterpret_cast<const float4*>(bbase1 + (bswz << 2));
+    // software pipeline with two explicit operand register sets: the reads of group q+1 are ISSUED before the
+    // eight MFMAs of group q (sched_barrier keeps hipcc from sinking them next to their consumers, which it
+    // otherwise does to save registers and which exposes one LDS latency per group)
+#define CARO_LOAD_SET(A_, B0_, B1_, Q_)                                                             \
+  A_ = *reinterpret_cast<const float4*>(abase + (((h * 8 + (Q_)) ^ aswz) << 2));                    \
+  B0_ = *reinterpret_cast<const float4*>(bbase0 + (((Q_) ^ bswz) << 2));                            \
+  B1_ = *reinterpret_cast<const float4*>(bbase1 + (((Q_) ^ bswz) << 2));
+#define CARO_MFMA_SET(A_, B0_, B1_)                                                \
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.x, B0_.x, acc0, 0, 0, 0);        \
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.x, B1_.x, acc1, 0, 0, 0);        \
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.y, B0_.y, acc0, 0, 0, 0);        \
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.y, B1_.y, acc1, 0, 0, 0);        \
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.z, B0_.z, acc0, 0, 0, 0);        \
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.z, B1_.z, acc1, 0, 0, 0);        \
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.w, B0_.w, acc0, 0, 0, 0);        \
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.w, B1_.w, acc1, 0, 0, 0);
+    float4 xa, xb0, xb1, ya, yb0, yb1;
+    CARO_LOAD_SET(xa, xb0, xb1, 0)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float4 an, b0n, b1n;
-      if (q < 7) {
-        an = *reinterpret_cast<const float4*>(abase + (((h * 8 + q + 1) ^ aswz) << 2));
-        b0n = *reinterpret_cast<const float4*>(bbase0 + (((q + 1) ^ bswz) << 2));
-        b1n = *reinterpret_cast<const float4*>(bbase1 + (((q + 1) ^ bswz) << 2));
+    for (int q = 0; q < 8; q += 2) {
+      CARO_LOAD_SET(ya, yb0, yb1, q + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      CARO_MFMA_SET(xa, xb0, xb1)
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 2 < 8) {
+        CARO_LOAD_SET(xa, xb0, xb1, q + 2)
       }
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
-      if (q < 7) {
-        a = an;
-        b0 = b0n;
-        b1 = b1n;
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      CARO_MFMA_SET(ya, yb0, yb1)
+      __builtin_amdgcn_sched_barrier(0);
     }
+#undef CARO_LOAD_SET
+#undef CARO_MFMA_SET
     if (last_in_chunk && has_next) {  // write late: the other buffer was last read one chunk ago
       float4* dst = reinterpret_cast<float4*>(wbuf + (cur ^ 1) * TPC * WCHUNK);
       dst[tid] = wn0;
       dst[tid + NT] = wn1;
       dst[tid + 2 * NT] = wn2;
       dst[tid + 3 * NT] = wn3;
+      dst[tid + 4 * NT] = wn4;
+      dst[tid + 5 * NT] = wn5;
     }
     if (tap == 8) {
       __syncthreads();  // every wave has read this layer's input activations: they may be overwritten
@@ -256,6 +269,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
     }
     if (last_in_chunk || tap == 8) __syncthreads();  // staged weights / new activations visible to every wave
   }
+  unsigned long long t_trunk1 = 0;
+  if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
   // `act` now holds the trunk output; the weight stage is free scratch
   float* feat = wbuf;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
   {
@@ -320,8 +335,10 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
     probs[(size_t)(row0 + board0) * p.A + k] = __expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
   }
   if (stamps && tid == 0) {
-    stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
-    stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
+    stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
+    stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
+    stamps[4 * blockIdx.x + 2] = t_trunk0 - t_c0;
+    stamps[4 * blockIdx.x + 3] = t_trunk1 - t_c0;
   }
 }
 
@@ -427,7 +444,7 @@ int caro_net_forward_pair(caro_net* n0, caro_net* n1, const float* planes_dev, c
   return 0;
 }
 
-/* diagnostic: same launch, and per workgroup (shader cycles, 100 MHz ticks) into stamps_dev u64[2*grid] */
+/* diagnostic: same launch, and per workgroup (total cycles, 100 MHz ticks, cycles at trunk start, at trunk end) into stamps_dev u64[4*grid] */
 int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which,
                              int64_t max_rows, float* probs_dev, float* values_dev, uint64_t* stamps_dev,
                              void* stream) {

@@ -222,7 +222,7 @@ int caro_stream_destroy(void* stream);
 /* both nets of an arena in ONE launch: rows [0, L0) through n0, rows [L0, L0+L1) through n1 */
 int caro_net_forward_pair(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
                           int64_t max_rows, float* probs_dev, float* values_dev, void* stream);
-/* diagnostic form: also writes per workgroup (shader cycles, 100 MHz wall ticks) to stamps_dev u64[2*grid],
+/* diagnostic form: also writes per workgroup (total shader cycles, 100 MHz wall ticks, cycles at trunk start, at trunk end) to stamps_dev u64[4*grid],
  * grid = ceil(max_rows / caro_net_boards_per_workgroup); used by tools/probe_clock.py only */
 int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which,
                              int64_t max_rows, float* probs_dev, float* values_dev, uint64_t* stamps_dev,

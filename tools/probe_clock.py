@@ -13,16 +13,18 @@ for rows in (1434, 600):
     counts = torch.tensor([rows, 0], dtype=torch.int32, device="cuda")
     probs = torch.empty((rows, 7), device="cuda"); vals = torch.empty(rows, device="cuda")
     grid = (rows + 5) // 6
-    stamps = torch.zeros(2 * grid, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(4 * grid, dtype=torch.int64, device="cuda")
     for _ in range(2000):   # ~0.5 s of back-to-back launches
         hn.forward_dev(x, counts.data_ptr(), 0, rows, probs, vals, None)
     _lib.check(L.caro_net_forward_stamped(hn.h, x.data_ptr(), counts.data_ptr(), 0, rows, probs.data_ptr(),
                                           vals.data_ptr(), stamps.data_ptr(), None))
     torch.cuda.synchronize()
-    s = stamps.cpu().numpy().reshape(-1, 2).astype(np.float64)
+    s = stamps.cpu().numpy().reshape(-1, 4).astype(np.float64)
     cyc, rt = s[:, 0], s[:, 1]
     ghz = cyc / (rt * 10.0)
     print("rows %d: workgroups %d, cycles median %.0f, wall us median %.1f, clock GHz median %.3f (min %.3f max %.3f)" % (
         rows, grid, np.median(cyc), np.median(rt) / 100.0, np.median(ghz), ghz.min(), ghz.max()))
+    print("   phases (cycles, median): zero+conv_in %.0f | trunk (45 taps + 5 epilogues) %.0f | heads+softmax %.0f" % (
+        np.median(s[:, 2]), np.median(s[:, 3] - s[:, 2]), np.median(s[:, 0] - s[:, 3])))
     print("   MFMA-bound cycles per workgroup = 23040 MFMA x 64 / 4 SIMD = 368640 -> %.1f %% of the measured cycles" % (
         100 * 368640 / np.median(cyc)))
