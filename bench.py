@@ -151,7 +151,8 @@ def main():
 
     rank, local_rank, world = parallel.init()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; CARO_SHARE_GPU=1 maps every rank to cuda:0 (rehearsal of the N > 1 path on a 1-GPU box)
+    device = torch.device("cuda", 0 if os.environ.get("CARO_SHARE_GPU") else local_rank)
     torch.cuda.set_device(device)
 
     if args.game == "c4":
@@ -201,6 +202,7 @@ def main():
         n_tuples += int(d["z"].shape[0])
 
     def barrier():
+        torch.cuda.synchronize(device)
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(device)

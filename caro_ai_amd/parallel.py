@@ -31,7 +31,8 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # CARO_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
+            backend = os.environ.get("CARO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -44,20 +45,32 @@ def shard(n_games_per_rank, rank, world):
     return {"uid_base": rank * n_games_per_rank, "uid_stride": world * n_games_per_rank}
 
 
+def _via_host(t):
+    """gloo collectives run on host memory; nccl (RCCL) takes the device tensors as they are"""
+    return dist.get_backend() == "gloo" and t.is_cuda
+
+
 def is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def allreduce_sum(t):
+def _allreduce(t, op):
     if is_dist():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if _via_host(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
     return t
+
+
+def allreduce_sum(t):
+    return _allreduce(t, dist.ReduceOp.SUM)
 
 
 def allreduce_max(t):
-    if is_dist():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return t
+    return _allreduce(t, dist.ReduceOp.MAX)
 
 
 def gather_tuples(tuples, pi_dtype=torch.float32):
@@ -69,6 +82,9 @@ def gather_tuples(tuples, pi_dtype=torch.float32):
         return {"states": tuples["states"], "players": tuples["players"], "pi": tuples["pi"].to(pi_dtype),
                 "z": tuples["z"]}
     world = dist.get_world_size()
+    out_dev = tuples["states"].device
+    if _via_host(tuples["states"]):
+        tuples = {k: v.cpu() for k, v in tuples.items()}
     dev = tuples["states"].device
     n = tuples["states"].shape[0]
     KW, A = tuples["states"].shape[1], tuples["pi"].shape[1]
@@ -93,12 +109,17 @@ def gather_tuples(tuples, pi_dtype=torch.float32):
     dist.all_gather_into_tensor(all_f, flt)
     keep = torch.cat([torch.arange(r * m, r * m + c, device=dev) for r, c in enumerate(counts_h)])
     all_i, all_f = all_i[keep], all_f[keep]
-    return {"states": all_i[:, :KW].contiguous(), "players": all_i[:, KW].to(torch.int32),
-            "pi": all_f, "z": all_i[:, KW + 1].to(torch.int32)}
+    return {"states": all_i[:, :KW].contiguous().to(out_dev), "players": all_i[:, KW].to(torch.int32).to(out_dev),
+            "pi": all_f.to(out_dev), "z": all_i[:, KW + 1].to(torch.int32).to(out_dev)}
 
 
 def broadcast_weights(net, src=0):
     if is_dist():
         for t in net.state_dict().values():
-            dist.broadcast(t, src=src)
+            if _via_host(t):
+                h = t.cpu()
+                dist.broadcast(h, src=src)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=src)
     return net
