@@ -36,8 +36,12 @@ def init(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             # binding the process group to its GPU up front makes barrier() / the first collective use it
-            dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            except TypeError:  # a torch without the device_id argument
+                if not dist.is_initialized():
+                    dist.init_process_group(backend=backend, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
