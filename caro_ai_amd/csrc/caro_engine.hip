@@ -538,7 +538,24 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
       }
     }
   }
-  // flatten the backup queue (lane 0; the queue is a handful of entries)
+  // Flatten the backup queue, lane-parallel.  Queue order (reference): terminals by sim index, then new
+  // leaves by first-seen index; inside one backup from the leaf upwards.  Lane b first loads descent b's
+  // record (one memory latency for all), a scan over the queue order gives every descent its entry offset,
+  // then lane j loads path entry j (one more latency for all).
+  __shared__ int q_len[MAXB], q_off[MAXB], q_b[MAXB];   // queue position -> length, entry offset, descent
+  __shared__ float q_val[MAXB];
+  __shared__ unsigned char q_strong[MAXB];
+  __shared__ int s_nq;
+  int my_st = ST_DROPPED, my_len = 0, my_local = 0;
+  float my_val = 0.f;
+  if (lane < B) {
+    const size_t di = (size_t)g * v.maxB + lane;
+    my_st = v.d_status[di];
+    my_len = v.path_len[di];
+    my_local = v.d_local[di];
+    if (my_st == ST_TERMINAL) my_val = v.d_value[di];
+    else if (my_st == ST_LEAF && !overflow) my_val = values[off + my_local];
+  }
   if (lane == 0) {
     unsigned long long* ctr = v.counters + (size_t)g * C_N;
     if (overflow) {
@@ -548,44 +565,56 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
       v.n_created[t] += nleaf;
       ctr[C_EXPANSIONS] += (unsigned long long)nleaf;
     }
-    // total queue length first: a queue that does not fit the LDS list is applied sequentially, in order
-    int total = 0;
-    for (int b = 0; b < B; ++b) {
-      const size_t di = (size_t)g * v.maxB + b;
-      const int st = v.d_status[di];
-      if (st == ST_TERMINAL || (st == ST_LEAF && !overflow)) total += v.path_len[di];
+  }
+  // queue position of descent `lane`: terminals keep their sim order, leaves follow in first-seen order
+  const unsigned long long m_term = __ballot(lane < B && my_st == ST_TERMINAL);
+  const unsigned long long m_leaf = __ballot(lane < B && my_st == ST_LEAF && !overflow);
+  const int n_term = __popcll(m_term);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int qpos = -1;
+  if (lane < B && my_st == ST_TERMINAL) qpos = __popcll(m_term & below);
+  else if (lane < B && my_st == ST_LEAF && !overflow) qpos = n_term + __popcll(m_leaf & below);
+  if (qpos >= 0) {
+    q_len[qpos] = my_len;
+    q_b[qpos] = lane;
+    q_val[qpos] = my_val;
+    q_strong[qpos] = my_st == ST_LEAF;
+  }
+  if (lane == 0) s_nq = n_term + __popcll(m_leaf);
+  __syncthreads();
+  const int nq = s_nq;
+  if (lane == 0) {  // exclusive scan over at most B queue items
+    int acc = 0;
+    for (int k = 0; k < nq; ++k) {
+      q_off[k] = acc;
+      acc += q_len[k];
     }
-    const bool fits = total <= MAXE;
-    int n = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass == 1 && overflow) break;
-      for (int b = 0; b < B; ++b) {
-        const size_t di = (size_t)g * v.maxB + b;
-        const int st = v.d_status[di];
-        if (st != (pass == 0 ? ST_TERMINAL : ST_LEAF)) continue;
-        const float value = pass == 0 ? v.d_value[di] : values[off + v.d_local[di]];
-        const int len = v.path_len[di];
-        const int32_t* pn = v.path_node + di * v.maxd;
-        const int32_t* pa = v.path_act + di * v.maxd;
-        if (!fits) {
-          backup_path<AP>(v, t, value, pass == 1, pn, pa, len);
-          continue;
-        }
-        float cur = -value;  // mcts.py:238
-        for (int i = len - 1; i >= 0; --i) {
-          e_node[n] = pn[i];
-          e_act[n] = (short)pa[i];
-          e_val[n] = cur;
-          e_strong[n] = (unsigned char)pass;
-          ++n;
-          cur = -cur;
-        }
-      }
-    }
-    s_total = n;
+    s_total = acc;
   }
   __syncthreads();
-  const int n = s_total;
+  const int total = s_total;
+  if (total > MAXE) {  // queue does not fit the LDS list: apply sequentially, in order (never at B*depth <= 512)
+    if (lane == 0)
+      for (int k = 0; k < nq; ++k) {
+        const size_t di = (size_t)g * v.maxB + q_b[k];
+        backup_path<AP>(v, t, q_val[k], q_strong[k] != 0, v.path_node + di * v.maxd, v.path_act + di * v.maxd, q_len[k]);
+      }
+    return;
+  }
+  for (int j = lane; j < total; j += blockDim.x) {
+    int k = 0;
+    while (k + 1 < nq && q_off[k + 1] <= j) ++k;  // queue item of entry j
+    const int r = j - q_off[k];                    // r-th entry of that backup, counted from the leaf
+    const int len = q_len[k];
+    const int i = len - 1 - r;
+    const size_t di = (size_t)g * v.maxB + q_b[k];
+    e_node[j] = v.path_node[di * v.maxd + i];
+    e_act[j] = (short)v.path_act[di * v.maxd + i];
+    e_val[j] = (r & 1) ? q_val[k] : -q_val[k];     // cur = -value at the leaf's parent, sign flips each ply (mcts.py:238,246)
+    e_strong[j] = q_strong[k];
+  }
+  __syncthreads();
+  const int n = total;
   for (int j = lane; j < n; j += blockDim.x) {
     const int node = e_node[j], a = e_act[j];
     bool owner = true;
