@@ -334,3 +334,49 @@ def test_without_eviction_the_small_cap_overflows():
     eng.play_until(25, 8, max_moves=12, recycle=False)
     assert eng.counters()["overflows"] > 0  # counted, never silent
     eng.close()
+
+
+# ------------------------------------------------------------------ sharding does not change the games
+def test_games_do_not_depend_on_sharding():
+    """8 slots in one engine == 2 'ranks' of 4 slots (parallel.shard layout) == StreamedSelfPlay with 2 parts:
+    every uid gives the same game (result, steps, tuples), whatever plays it."""
+    from caro_ai_amd import parallel
+    from caro_ai_amd.engine import StreamedSelfPlay
+    game = _game_of({"kind": "c4"})
+    S, B, seed = 10, 8, 41
+
+    def collect(tuples, games):
+        out, off = {}, 0
+        PI = np.concatenate([t["pi"] for t in tuples]); ST = np.concatenate([t["states"] for t in tuples])
+        for uid, first, result, steps in games.tolist():
+            n = steps + 1
+            out[uid] = (first, result, steps, ST[off:off + n].tobytes(), PI[off:off + n].tobytes())
+            off += n
+        return out
+
+    eng = _engine(game, 8, [_synth(game)], max_batch=B, seed=seed)
+    t, g = eng.play_until(S, B, n_finished=16)
+    eng.close()
+    ref = collect(t, g)
+    got = {}
+    for rank in range(2):
+        e = _engine(game, 4, [_synth(game)], max_batch=B, seed=seed, **parallel.shard(4, rank, 2))
+        t, g = e.play_until(S, B, n_finished=8)
+        e.close()
+        got.update(collect(t, g))
+    common = set(ref) & set(got)
+    assert len(common) >= 12
+    for uid in common:
+        assert ref[uid] == got[uid], uid
+    sp = StreamedSelfPlay(game, 8, lambda: [_synth(game)], n_streams=2, max_batch=B, seed=seed)
+    seen = {}
+    for _ in range(40):
+        sp.search(S, B); sp.step()
+        d = sp.drain()
+        if d["games"].shape[0]:
+            seen.update(collect([{k: v.cpu().numpy() for k, v in d.items() if k != "games"}], d["games"].cpu().numpy()))
+    sp.close()
+    common = set(ref) & set(seen)
+    assert len(common) >= 8
+    for uid in common:
+        assert ref[uid] == seen[uid], uid
