@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="split the games of a GPU over this many engines on separate HIP streams (tree kernels of "
                          "one part overlap the net kernel of another)")
+    ap.add_argument("--stream-mask", type=int, default=1, help="with --streams > 1: confine each part to its own CU slice")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="host cores for the CPU baseline (0 = all, capped at 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,7 +185,8 @@ def main():
         make_evaluators = lambda: [torch_evaluator(fnet, form="net")]
     n_streams = args.streams if args.net == "hip" else 1
     if n_streams > 1:
-        eng = StreamedSelfPlay(game, G, make_evaluators, n_streams=n_streams, max_batch=B, steps_before_tau_0=sbt0,
+        eng = StreamedSelfPlay(game, G, make_evaluators, n_streams=n_streams, partition_cus=bool(args.stream_mask),
+                               max_batch=B, steps_before_tau_0=sbt0,
                                seed=0, device=str(device), searches_hint=S, **extra, **parallel.shard(G, rank, world))
     else:
         eng = SelfPlayEngine(game, G, evaluators=make_evaluators(), max_batch=B, steps_before_tau_0=sbt0,
