@@ -196,14 +196,21 @@ def main():
 
     def one_step():
         nonlocal n_tuples
-        eng.search(S, B)
-        eng.step()
-        d = eng.drain(recycle=True)
+        if n_streams > 1:
+            d = eng.move(S, B)      # host-pipelined over the parts: drains the previous move of each part
+            if d is None:
+                return
+        else:
+            eng.search(S, B)
+            eng.step()
+            d = eng.drain(recycle=True)
         if world > 1:
             d = parallel.gather_tuples(d)
         n_tuples += int(d["z"].shape[0])
 
     def barrier():
+        if n_streams > 1:
+            eng.flush()             # the last enqueued move of every part belongs to the timed region
         torch.cuda.synchronize(device)
         if world > 1:
             torch.distributed.barrier()

@@ -358,6 +358,35 @@ class StreamedSelfPlay:
             st.synchronize()
         return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
 
+    def move(self, searches, batch, recycle=True):
+        """One move of every part, software-pipelined on the host: for each part in turn, drain its PREVIOUS
+        move (the only host sync) and immediately enqueue its next search + step, so the other parts keep the
+        GPU busy while this one is being waited for.  Returns the tuples drained this call (those of the
+        previous move; the first call returns none)."""
+        outs = []
+        for e, st in self._each():
+            with torch.cuda.stream(st):
+                if getattr(e, "_primed", False):
+                    outs.append(e.drain(recycle=recycle))
+                e.search(searches, batch)
+                e.step()
+                e._primed = True
+        if not outs:
+            return None
+        return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+
+    def flush(self, recycle=True):
+        """drain the last enqueued move of every part"""
+        outs = []
+        for e, st in self._each():
+            with torch.cuda.stream(st):
+                if getattr(e, "_primed", False):
+                    outs.append(e.drain(recycle=recycle))
+                    e._primed = False
+        for st in self.streams:
+            st.synchronize()
+        return {k: torch.cat([o[k] for o in outs]) for k in outs[0]} if outs else None
+
     def counters(self):
         tot = {}
         for e, st in self._each():
