@@ -380,3 +380,114 @@ def test_games_do_not_depend_on_sharding():
     assert len(common) >= 8
     for uid in common:
         assert ref[uid] == seen[uid], uid
+
+
+# ------------------------------------------------------------------ searches from recorded mid / late game positions
+def _search_from_positions(d, recs, S, B, seed):
+    """One engine slot per recorded position (set_roots on empty trees), S x B sims, then root N / W / Q /
+    strong flag / tree size / pi against the oracle searching the same position with the same noise key."""
+    from oracle.oracle import Oracle
+    game = _game_of(d)
+    states = [int(r["s2"]) for r in recs]
+    players = [1 - r["p"] for r in recs]
+    G = len(states)
+    eng = _engine(game, G, [_synth(game)], max_batch=B, steps_before_tau_0=10, seed=seed, uid_base=0,
+                  node_cap=S * B + 8)
+    eng.set_roots(states, players)
+    eng.search(S, B)
+    nd = eng.lookup(list(range(G)), [0] * G, states)
+    sizes = eng.tree_sizes()[:, 0]
+    pi = eng.policy()[0].cpu().numpy()
+    assert eng.counters()["overflows"] == 0
+    eng.close()
+    o = _oracle_of(d)
+    o.use_synth_net()
+    checked = terminal_roots = 0
+    for g in range(G):
+        if not game.possible_moves(states[g]):
+            continue  # a full board is never searched by play_game
+        o.clear()
+        o.set_stream(seed, g)
+        o.search_batch(S, B, states[g], players[g], ply=0)
+        ref = o.get_node(states[g])
+        assert nd["found"][g] == 1
+        assert nd["N"][g].tolist() == ref["N"].tolist(), (g, states[g])
+        assert nd["W"][g].astype(np.float64).tolist() == ref["W"].tolist(), g
+        assert nd["strong"][g].tolist() == ref["W_is_f32"].tolist(), g
+        for a in range(game.action_space):
+            if ref["W_is_f32"][a]:
+                assert float(nd["Q"][g][a]) == ref["Q"][a]
+            else:
+                assert np.float32(ref["Q"][a]) == nd["Q"][g][a]
+        assert sizes[g] == o.store_len(0), g
+        if ref["N"].sum() > 0:
+            assert pi[g].tolist() == o.get_policy(states[g], 1).tolist()
+        checked += 1
+        terminal_roots += int(o.counters()["terminals"] > 0)
+    return checked, terminal_roots
+
+
+def test_connect4_search_from_2000_recorded_positions():
+    d = load_golden("rules_c4.json.gz")
+    recs = [r for r in d["recs"] if not r["won"]][:2000]
+    checked, with_terminals = _search_from_positions({"kind": "c4"}, recs, 6, 8, seed=51)
+    assert checked >= 1900 and with_terminals > 200  # late-game roots: wins, full columns and draws inside the search
+
+
+def test_tictactoe_and_gomoku_search_from_recorded_positions():
+    d = load_golden("rules_ttt3.json.gz")
+    recs = [r for r in d["recs"] if not r["won"]]
+    checked, with_terminals = _search_from_positions({"kind": "mnk", "n": 3, "k": 3}, recs, 8, 4, seed=52)
+    assert checked > 700 and with_terminals > 300
+    d = load_golden("rules_mnk15.json.gz")
+    recs = [r for r in d["recs"] if not r["won"]][::4]
+    checked, _ = _search_from_positions({"kind": "mnk", "n": 15, "k": 5}, recs, 3, 8, seed=53)
+    assert checked > 100
+    d = load_golden("rules_mnk5.json.gz")
+    recs = [r for r in d["recs"] if not r["won"]]
+    checked, with_terminals = _search_from_positions({"kind": "mnk", "n": 5, "k": 4}, recs, 5, 8, seed=54)
+    assert checked > 500 and with_terminals > 20
+
+
+@pytest.mark.parametrize("B", [1, 2, 16, 64])
+def test_batch_size_edge_cases_connect4(B):
+    """mcts_batch_size from 1 (TicTacToe plumbing config) to 64 (the kernel's block = 64 x 8 lanes)"""
+    _check_against_oracle({"kind": "c4"}, 8, 8, 4, 200 // B if B <= 16 else 3, B, 1, seed=60 + B, uid_base=0)
+
+
+@pytest.mark.parametrize("n,k", [(4, 3), (8, 5), (11, 5), (12, 6), (4, 4)])
+def test_mnk_geometry_variants(n, k):
+    """every lane geometry: A = 16 (no padding lanes), 64 (full wave), 121 / 144 (2 and 4 actions per lane), k = n"""
+    _check_against_oracle({"kind": "mnk", "n": n, "k": k}, 4, 4, 3, 5, 8, 1, seed=70 + n, uid_base=0)
+
+
+def test_capi_rejects_bad_arguments():
+    import ctypes as C
+    from caro_ai_amd import _lib
+    L = _lib.load()
+    h = C.c_void_p()
+
+    def cfg(**kw):
+        c = _lib.CaroConfig()
+        c.game_kind, c.n, c.k, c.n_games, c.n_stores, c.n_nets, c.max_batch, c.node_cap = 0, 0, 0, 4, 1, 1, 8, 64
+        c.c_puct, c.alpha, c.explore = 1.0, 0.3, 0.25
+        for a, b in kw.items():
+            setattr(c, a, b)
+        return c
+
+    for bad in (dict(n_games=0), dict(n_stores=3), dict(n_nets=0), dict(max_batch=0), dict(max_batch=200),
+                dict(game_kind=1, n=16, k=5), dict(game_kind=1, n=5, k=6), dict(game_kind=7), dict(device_id=99)):
+        c = cfg(**bad)
+        assert L.caro_engine_create(C.byref(c), C.byref(h)) == -22, bad  # CARO_E_INVAL
+        assert L.caro_last_error()
+    c = cfg()
+    assert L.caro_engine_create(C.byref(c), C.byref(h)) == 0
+    planes = torch.zeros((32, 2, 6, 7), device=DEV)
+    assert L.caro_select(h, 9, 0, None, planes.data_ptr(), None, None) == -22       # batch > max_batch
+    assert L.caro_expand_backup(h, planes.data_ptr(), planes.data_ptr(), None) == -71  # no pending select
+    assert L.caro_select(h, 8, 0, None, planes.data_ptr(), None, None) == 0
+    assert L.caro_select(h, 8, 1, None, planes.data_ptr(), None, None) == -71       # select twice
+    assert L.caro_step(h, None, None, None, None, None) == -71
+    assert L.caro_select_cancel(h) == 0
+    torch.cuda.synchronize()
+    L.caro_engine_destroy(h)
