@@ -49,12 +49,50 @@ def pack_net(net: Net) -> np.ndarray:
     return out
 
 
+def _bf16_rne(x32: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 bits, round to nearest even (the rounding of k_net_forward_3x's bf16_rne)"""
+    u = x32.view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+
+
+def split3(x32: np.ndarray):
+    """exact three-way split x = hi + mid + lo (+ <= 2^-27 |x|) into bf16 bit patterns"""
+    x32 = np.ascontiguousarray(x32, dtype=np.float32)
+    hi = _bf16_rne(x32)
+    r = x32 - (hi << 16).astype(np.uint32).view(np.float32)
+    mid = _bf16_rne(r)
+    r = r - (mid << 16).astype(np.uint32).view(np.float32)
+    lo = _bf16_rne(r)
+    return hi.astype(np.uint16), mid.astype(np.uint16), lo.astype(np.uint16)
+
+
+def pack_net_3x(net: Net) -> np.ndarray:
+    """uint16[45 * 1536 * 8]: per tap the [split][co][k] bf16 rows of the folded 3x3 weights in the LDS image
+    order of k_net_forward_3x (granule g = k >> 3 of row (split, co) sits at ((s*64+co)*8 + (g ^ ((co>>1)&7))))."""
+    net = net.eval()
+    co = np.arange(64)[:, None]
+    k = np.arange(64)[None, :]
+    gran = (co * 8 + ((k >> 3) ^ ((co >> 1) & 7)))          # granule of (co, k) inside one split
+    idx = (gran * 8 + (k & 7))                               # u16 index inside one split
+    out = np.zeros((5, 9, 3, 64 * 64), np.uint16)
+    for li, blk in enumerate(net.residual_blocks()):
+        w, _ = _fold(blk)
+        w = w.cpu().numpy()                                   # [co, ci, ky, kx]
+        for tap in range(9):
+            parts = split3(w[:, :, tap // 3, tap % 3])        # each [co, ci=k]
+            for s_, part in enumerate(parts):
+                out[li, tap, s_, idx.reshape(-1)] = part.reshape(-1)
+    return out.reshape(-1)
+
+
 class HipNet:
-    """Device-resident packed weights + the forward launch."""
+    """Device-resident packed weights + the forward launch.
+    mode "f32": v_mfma_f32_32x32x2_f32 (exact float32, the default).
+    mode "3xbf16": opt-in, 3x3 convolutions on the bf16 MFMA pipe with three-way split operands."""
 
     device_counts = True  # the engine may call forward_dev without knowing L on the host
 
-    def __init__(self, net: Net, device="cuda:0", negative_slope=0.01):
+    def __init__(self, net: Net, device="cuda:0", negative_slope=0.01, mode="f32"):
         self.L = _lib.load()
         self.device = torch.device(device)
         self.H, self.W = net.input_shape[1], net.input_shape[2]
@@ -65,6 +103,12 @@ class HipNet:
         _lib.check(self.L.caro_net_create(self.H, self.W, self.A, negative_slope, packed.ctypes.data, packed.size,
                                           self.device.index or 0, C.byref(h)))
         self.h = h
+        self.mode = mode
+        if mode == "3xbf16":
+            w3 = pack_net_3x(net)
+            _lib.check(self.L.caro_net_enable_3xbf16(self.h, w3.ctypes.data, w3.size))
+        else:
+            assert mode == "f32", mode
 
     def close(self):
         if getattr(self, "h", None):

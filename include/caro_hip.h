@@ -208,6 +208,10 @@ typedef struct caro_net caro_net;
 int64_t caro_net_packed_size(int H, int W, int A);
 int caro_net_create(int H, int W, int A, float negative_slope, const float* packed_host, int64_t n_floats,
                     int device_id, caro_net** out);
+/* opt-in: evaluate the 3x3 convolutions of this net on the bf16 MFMA pipe with every float32 operand split into
+ * three bf16 terms (six MFMAs per k-block, float32 accumulate; product error below float32 rounding).
+ * w3_host: 45 taps x 1536 granules x 8 bf16 in the kernel's LDS image order (caro_ai_amd/net_hip.py packs it). */
+int caro_net_enable_3xbf16(caro_net* n, const uint16_t* w3_host, int64_t n_u16);
 void caro_net_destroy(caro_net* n);
 int caro_net_boards_per_workgroup(const caro_net* n);
 /* rows [row0, row0 + L) of planes_dev f32[max_rows,2,H,W] -> probs_dev f32[.,A] (softmaxed), values_dev f32[.]

@@ -14,8 +14,16 @@ with torch.no_grad():
     lg64, vl64 = net.double()(x.double()); p64 = torch.softmax(lg64, 1); net.float()
     gn = GemmNet(net).cuda().eval(); lgg, vlg = gn(x.cuda()); pg = torch.softmax(lgg, 1).cpu(); vlg = vlg.cpu()
 hn = HipNet(net, "cuda:0"); ph, vh = hn(x.cuda()); torch.cuda.synchronize(); ph, vh = ph.cpu(), vh.cpu()
+h3 = HipNet(net, "cuda:0", mode="3xbf16"); p3, v3 = h3(x.cuda()); torch.cuda.synchronize(); p3, v3 = p3.cpu(), v3.cpu()
 def rep(name, p, v):
     dp = (p.double() - p64).abs(); dv = (v.double().reshape(-1) - vl64.reshape(-1)).abs()
     print("%-12s |dP| max %.3e mean %.3e   |dv| max %.3e mean %.3e" % (name, dp.max(), dp.mean(), dv.max(), dv.mean()))
-rep("cpu fp32", p32, vl); rep("gemm gpu", pg, vlg); rep("hip", ph, vh)
+rep("cpu fp32", p32, vl); rep("gemm gpu", pg, vlg); rep("hip f32", ph, vh); rep("hip 3xbf16", p3, v3)
+import time
+xs = x.cuda()[:600].repeat(3, 1, 1, 1)[:1430].contiguous()
+for name, n_ in (("hip f32", hn), ("hip 3xbf16", h3)):
+    for _ in range(50): n_(xs)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(200): n_(xs)
+    torch.cuda.synchronize(); print("%-12s %.1f us per forward of 1430 leaves" % (name, (time.perf_counter() - t0) / 200 * 1e6))
 print("logit range", lg64.min().item(), lg64.max().item())
