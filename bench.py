@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
+MFMA_BF16_PEAK_TFS = 2500.0 # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 
 
 def load_pmc():
@@ -123,9 +124,10 @@ def main():
     ap.add_argument("--evict", type=int, default=-1,
                     help="drop unreachable nodes after every move (result-neutral); default: on for gomoku15")
     ap.add_argument("--weights", default=os.path.join(ROOT, "tests", "golden", "weights", "best_026_12000.dat"))
-    ap.add_argument("--net", default="hip", choices=["hip", "gemm", "folded", "net"],
-                    help="inference form of lib/model.py Net: fused HIP fp32 MFMA kernel (default), torch gather+GEMM, "
-                         "BN-folded conv2d, or the module as is")
+    ap.add_argument("--net", default="hip", choices=["hip", "hip3x", "gemm", "folded", "net"],
+                    help="inference form of lib/model.py Net: fused HIP fp32 MFMA kernel (default); hip3x = the same kernel "
+                         "with the 3x3 convs on the bf16 MFMA pipe via three-way split operands (opt-in); torch "
+                         "gather+GEMM; BN-folded conv2d; or the module as is")
     ap.add_argument("--streams", type=int, default=1,
                     help="split the games of a GPU over this many engines on separate HIP streams (tree kernels of "
                          "one part overlap the net kernel of another)")
@@ -170,20 +172,22 @@ def main():
         extra["evict"] = True
         extra.setdefault("node_cap", 4096)
     if args.arena:
-        assert args.game == "c4" and args.net == "hip"
+        assert args.game == "c4" and args.net in ("hip", "hip3x")
         sbt0 = 0
         net2, wtag2 = load_net(game, device, os.path.join(os.path.dirname(weights), "best_025_10600.dat"))
         wtag = wtag + " vs " + wtag2
         extra.update(n_stores=2, first_player_mode=2)
-    if args.net == "hip":
+    is_hip = args.net in ("hip", "hip3x")
+    if is_hip:
         from caro_ai_amd.net_hip import HipNet
-        hipnet = HipNet(net, str(device))
-        hipnets = [hipnet] + ([HipNet(net2, str(device))] if args.arena else [])
+        mode = "3xbf16" if args.net == "hip3x" else "f32"
+        hipnet = HipNet(net, str(device), mode=mode)
+        hipnets = [hipnet] + ([HipNet(net2, str(device), mode=mode)] if args.arena else [])
         make_evaluators = lambda: list(hipnets)
     else:
         fnet = {"gemm": GemmNet, "folded": FoldedNet, "net": lambda n: n}[args.net](net).to(device).eval()
         make_evaluators = lambda: [torch_evaluator(fnet, form="net")]
-    n_streams = args.streams if args.net == "hip" else 1
+    n_streams = args.streams if is_hip else 1
     if n_streams > 1:
         eng = StreamedSelfPlay(game, G, make_evaluators, n_streams=n_streams, partition_cus=bool(args.stream_mask),
                                max_batch=B, steps_before_tau_0=sbt0,
@@ -272,8 +276,11 @@ def main():
             # the net is timed on a sample of the launches; one net launch per select launch
             leaves_per_launch = delta["expansions"] / (args.steps * S * n_streams)
             achieved = leaves_per_launch * flops_per_leaf / avg_s / 1e12
-            roofline = {"bound": "mfma", "kernel": "k_net_forward", "achieved": achieved, "peak": MFMA_F32_PEAK_TFS,
-                        "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFS, "traffic": pmc.get("k_net_forward"),
+            # hip3x issues 6 bf16 MFMA flops per algorithmic flop: priced against the dense bf16 peak / 6
+            peak = MFMA_F32_PEAK_TFS if args.net != "hip3x" else MFMA_BF16_PEAK_TFS / 6.0
+            roofline = {"bound": "mfma", "kernel": "k_net_forward" if args.net != "hip3x" else "k_net_forward_3x",
+                        "achieved": achieved, "peak": peak,
+                        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc.get("k_net_forward"),
                         "avg_launch_us": avg_s * 1e6, "launches_timed": n, "leaves_per_launch": leaves_per_launch,
                         "flops_per_leaf": flops_per_leaf}
         if roofline is None:  # torch evaluators: the net is not our kernel; the tree walk is the dominant own kernel
@@ -286,13 +293,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.net != "hip3x" else "f32 (3x3 conv products as 3-way split bf16, f32 accumulate)",
             "data": "synthetic (self-play from empty boards; net weights: %s)" % wtag,
             "config": {"workload": "%s %d concurrent %s/GPU, %dx%d = %d sims/move, tau=1 for %d plies"
                                    % ("Connect4 6x7" if args.game == "c4" else "m,n,k 15x15 k=5", G,
                                       "arena matches (two nets, one tree per player)" if args.arena else "self-play games",
                                       S, B, S * B, sbt0),
-                       "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py Net, %s fp32" % {"hip": "fused HIP MFMA kernel", "gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net],
+                       "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py Net, %s fp32" % {"hip": "fused HIP MFMA kernel", "hip3x": "fused HIP kernel, 3x3 convs as 3-way split bf16 MFMA with f32 accumulate,", "gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net],
                        "streams_per_gpu": n_streams,
                        "parallelism": "games sharded x%d, all-gather of tuples per step" % world},
             "per_gpu": exp_all / dt_max / world,

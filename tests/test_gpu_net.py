@@ -37,7 +37,8 @@ def _boards(L, shape, seed):
 @pytest.mark.parametrize("shape,A,weights", [((2, 6, 7), 7, "best_026_12000.dat"), ((2, 3, 3), 9, "best_005_00900.dat"),
                                              ((2, 15, 15), 225, None), ((2, 5, 5), 25, None), ((2, 10, 10), 100, None)])
 @pytest.mark.parametrize("L", [1, 5, 6, 7, 29, 300])
-def test_hip_net_matches_torch_fp32(shape, A, weights, L):
+@pytest.mark.parametrize("mode", ["f32", "3xbf16"])
+def test_hip_net_matches_torch_fp32(shape, A, weights, L, mode):
     from caro_ai_amd.net_hip import HipNet
     net = _net(shape, A, weights)
     x = _boards(L, shape, L)
@@ -47,11 +48,11 @@ def test_hip_net_matches_torch_fp32(shape, A, weights, L):
         lg64, vl64 = net.double()(x.double())
         p64 = torch.softmax(lg64, dim=1)
     net.float()
-    hn = HipNet(net, "cuda:0")
+    hn = HipNet(net, "cuda:0", mode=mode)
     p, v = hn(x.to("cuda:0"))
     torch.cuda.synchronize()
     p, v = p.cpu(), v.cpu()
-    # stated tolerance: float32 re-association only (trained logits reach |x| ~ 15, so 1e-6 relative on a
+    # stated tolerance (both modes: the split-bf16 products are below float32 rounding): float32 re-association only (trained logits reach |x| ~ 15, so 1e-6 relative on a
     # logit is ~1e-5 on P): |dP| < 1e-4 absolute (P in [0,1]), |dv| < 1e-4
     assert (p - p_ref).abs().max().item() < 1e-4, (p - p_ref).abs().max().item()
     assert (v - vl[:, 0]).abs().max().item() < 1e-4
