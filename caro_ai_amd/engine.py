@@ -66,9 +66,10 @@ class SelfPlayEngine:
         self.max_batch = int(max_batch or cfg.MCTS_BATCH_SIZE)
         if evaluators is None:
             nets = [net1] if net2 is None or net2 is net1 else [net1, net2]
-            if inference == "hip":
+            if inference in ("hip", "hip3x"):
                 from caro_ai_amd.net_hip import HipNet
-                evaluators = [HipNet(n, str(self.device)) for n in nets]
+                mode = "3xbf16" if inference == "hip3x" else "f32"
+                evaluators = [HipNet(n, str(self.device), mode=mode) for n in nets]
             else:
                 evaluators = [torch_evaluator(n.to(self.device), form=inference) for n in nets]
         self.evaluators = list(evaluators)
