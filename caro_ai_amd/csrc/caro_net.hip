@@ -326,14 +326,14 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
     float mx = -3.4e38f;
     for (int a = 0; a < p.A; ++a) mx = fmaxf(mx, logit[tid * p.A + a]);
     float sum = 0.f;
-    for (int a = 0; a < p.A; ++a) sum += __expf(logit[tid * p.A + a] - mx);
+    for (int a = 0; a < p.A; ++a) sum += expf(logit[tid * p.A + a] - mx);
     stat[2 * tid] = mx;
     stat[2 * tid + 1] = sum;
   }
   __syncthreads();
   for (int k = tid; k < nb * p.A; k += NT) {
     const int bi = k / p.A;
-    probs[(size_t)(row0 + board0) * p.A + k] = __expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
+    probs[(size_t)(row0 + board0) * p.A + k] = expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
   }
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
@@ -631,14 +631,14 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParam
     float mx = -3.4e38f;
     for (int a = 0; a < p.A; ++a) mx = fmaxf(mx, logit[tid * p.A + a]);
     float sum = 0.f;
-    for (int a = 0; a < p.A; ++a) sum += __expf(logit[tid * p.A + a] - mx);
+    for (int a = 0; a < p.A; ++a) sum += expf(logit[tid * p.A + a] - mx);
     stat[2 * tid] = mx;
     stat[2 * tid + 1] = sum;
   }
   __syncthreads();
   for (int k = tid; k < nb * p.A; k += NT) {
     const int bi = k / p.A;
-    probs[(size_t)(row0 + board0) * p.A + k] = __expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
+    probs[(size_t)(row0 + board0) * p.A + k] = expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
   }
 }
 

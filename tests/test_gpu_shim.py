@@ -231,7 +231,7 @@ def test_real_weights_gpu_net_tolerance(inference):
     PUCT argmax is discontinuous: a 1e-6 difference in a prior can move one of 200 sims to another child, and
     because the tree persists across plies (Q2) every later ply of that game then differs.  Stated tolerance:
     >= 80 % of all compared plies with an identical root visit vector, max |d pi| <= 0.15 on the rest.
-    Measured round 1: see DESIGN.md section 7."""
+    Measured round 1: 33/33 for all three forms (with the fast-math __expf in the softmax it was 29/33)."""
     from caro_ai_amd.engine import SelfPlayEngine
     from caro_ai_amd.lib.game.connect_four import ConnectFour
     from caro_ai_amd.lib.model import Net
