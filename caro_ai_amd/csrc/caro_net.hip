@@ -128,16 +128,23 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
       const int bi = r / HW, cell = r - bi * HW;
       const int y = cell / p.W, x = cell - y * p.W;
       const float* pl = planes + (size_t)(row0 + board0 + bi) * 2 * HW;
-      for (int c4 = chalf * 8; c4 < chalf * 8 + 8; ++c4) {
+      float in0[9], in1[9];  // the 18 inputs of this row (statically indexed: stays in registers)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ny = y + t / 3 - 1, nx = x + t % 3 - 1;
+        const bool ok = ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
+        in0[t] = ok ? pl[ny * p.W + nx] : 0.f;
+        in1[t] = ok ? pl[HW + ny * p.W + nx] : 0.f;
+      }
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const int c4 = chalf * 8 + cc;
         float o[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = p.b_in[c4 * 4 + u];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {  // the 18 inputs are re-read per channel group (L1 hits): no per-thread array
-          const int ny = y + t / 3 - 1, nx = x + t % 3 - 1;
-          const bool ok = ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
-          const float i0 = ok ? pl[ny * p.W + nx] : 0.f;
-          const float i1 = ok ? pl[HW + ny * p.W + nx] : 0.f;
+        for (int t = 0; t < 9; ++t) {
+          const float i0 = in0[t], i1 = in1[t];
           const float4 w0 = *reinterpret_cast<const float4*>(wbuf + (2 * t) * NF + c4 * 4);
           const float4 w1 = *reinterpret_cast<const float4*>(wbuf + (2 * t + 1) * NF + c4 * 4);
           o[0] = fmaf(i0, w0.x, o[0]); o[1] = fmaf(i0, w0.y, o[1]); o[2] = fmaf(i0, w0.z, o[2]); o[3] = fmaf(i0, w0.w, o[3]);
@@ -434,16 +441,23 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParam
       const int bi = r / HW, cell = r - bi * HW;
       const int y = cell / p.W, x = cell - y * p.W;
       const float* pl = planes + (size_t)(row0 + board0 + bi) * 2 * HW;
-      for (int c4 = chalf * 8; c4 < chalf * 8 + 8; ++c4) {
+      float in0[9], in1[9];  // the 18 inputs of this row (statically indexed: stays in registers)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ny = y + t / 3 - 1, nx = x + t % 3 - 1;
+        const bool ok = ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
+        in0[t] = ok ? pl[ny * p.W + nx] : 0.f;
+        in1[t] = ok ? pl[HW + ny * p.W + nx] : 0.f;
+      }
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const int c4 = chalf * 8 + cc;
         float o[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = p.b_in[c4 * 4 + u];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const int ny = y + t / 3 - 1, nx = x + t % 3 - 1;
-          const bool ok = ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
-          const float i0 = ok ? pl[ny * p.W + nx] : 0.f;
-          const float i1 = ok ? pl[HW + ny * p.W + nx] : 0.f;
+          const float i0 = in0[t], i1 = in1[t];
           const float4 w0 = *reinterpret_cast<const float4*>(wf + (2 * t) * NF + c4 * 4);
           const float4 w1 = *reinterpret_cast<const float4*>(wf + (2 * t + 1) * NF + c4 * 4);
           o[0] = fmaf(i0, w0.x, o[0]); o[1] = fmaf(i0, w0.y, o[1]); o[2] = fmaf(i0, w0.z, o[2]); o[3] = fmaf(i0, w0.w, o[3]);
