@@ -74,6 +74,8 @@ _SIGNATURES = {
     "caro_drain_tuples": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     "caro_counters": (C.c_int, [_P, _P, _P]),
     "caro_live_games": (C.c_int, [_P, _P, _P]),
+    "caro_debug_stamps": (C.c_int, [_P, C.c_int]),
+    "caro_debug_read": (C.c_int, [_P, _P, C.c_int64, _P]),
     "caro_profile_enable": (C.c_int, [_P, C.c_int]),
     "caro_profile_read": (C.c_int, [_P, _P, _P, C.c_int]),
     "caro_profile_begin": (C.c_int, [_P, C.c_int, _P]),

@@ -88,6 +88,7 @@ struct View {
   int32_t* leaf_count;  // [4]: L0, L1, batch of the pending minibatch, -
   unsigned long long* counters;  // [G][C_N] per-game tallies (no atomics on the hot path), summed on read
   unsigned long long* counters_sum;  // [C_N]
+  unsigned long long* dbg;           // diagnostic stamps [G][8] or null (never set in product runs)
   // drain scratch
   int32_t* dr_off;
   int32_t* dr_gidx;
@@ -228,6 +229,8 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
     }
     return;
   }
+  unsigned long long st0 = 0, st_rows = 0, st_noise = 0, st_loop = 0;
+  if (v.dbg) st0 = __builtin_amdgcn_s_memtime();
   const Board root = load_board<R>(v.root + (size_t)g * KW);
   const int player0 = v.player[g];
   const int t = g * v.n_stores + (v.n_stores == 2 ? player0 : 0);
@@ -285,6 +288,7 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
       }
     }
     if (node < 0) break;  // not in the tree: this is the leaf (mcts.py:123)
+    if (v.dbg && depth == 0) st_rows = __builtin_amdgcn_s_memtime();
     int nsum = 0;
 #pragma unroll
     for (int j = 0; j < APL; ++j) nsum += (int)(nraw[j] & NMASK);
@@ -305,6 +309,7 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
         const uint64_t key = caro_noise_key(v.seed, uid, ply, (uint32_t)(mb_index * B + b));
         noise_group<LPD, APL>(key, l, A, v.alpha, nz);
       }
+      if (v.dbg) st_noise = __builtin_amdgcn_s_memtime();
       const float keepf = (float)(1.0 - v.explore);
 #pragma unroll
       for (int j = 0; j < APL; ++j) {
@@ -371,6 +376,7 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
     slot = home_slot<R>(v, cur);
   }
 
+  if (v.dbg) st_loop = __builtin_amdgcn_s_memtime();
   if (l == 0) {
 #pragma unroll
     for (int w = 0; w < KW; ++w) s_key[b][w] = cur.w[w];
@@ -418,6 +424,13 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
     v.g_nleaf[g] = nleaf;
     v.g_tree[g] = t;
     v.g_class[g] = v.n_nets == 2 ? player0 : 0;
+    if (v.dbg) {  // cycles since kernel start: root rows arrived | noise generated | descents done | end; max depth
+      unsigned long long* d = v.dbg + (size_t)g * 8;
+      int maxd = 0;
+      for (int bb = 0; bb < B; ++bb) maxd = s_depth[bb] > maxd ? s_depth[bb] : maxd;
+      d[0] = st_rows - st0; d[1] = st_noise - st0; d[2] = st_loop - st0;
+      d[3] = __builtin_amdgcn_s_memtime() - st0; d[4] = (unsigned long long)maxd;
+    }
     unsigned long long* ctr = v.counters + (size_t)g * C_N;  // this block is the only writer of game g's row
     ctr[C_SIMS] += (unsigned long long)B;
     ctr[C_LEVELS] += (unsigned long long)levels;
@@ -1659,6 +1672,28 @@ int caro_stream_create_partition(int device_id, int part, int nparts, void** str
 }
 int caro_stream_destroy(void* stream) {
   if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+
+/* diagnostic: allocate (on != 0) or drop the per-game stamp buffer of k_select; read it back with caro_debug_read */
+int caro_debug_stamps(caro_engine* h, int on) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  if (on && !h->v.dbg) {
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, (size_t)h->v.G * 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(q, 0, (size_t)h->v.G * 8 * sizeof(unsigned long long)));
+    h->allocs.push_back(q);
+    h->v.dbg = (unsigned long long*)q;
+  } else if (!on) {
+    h->v.dbg = nullptr;  // the buffer stays owned by the engine
+  }
+  return 0;
+}
+int caro_debug_read(caro_engine* h, uint64_t* out_host, int64_t n_u64, void* stream) {
+  if (!h || !out_host || !h->v.dbg) return fail(CARO_E_INVAL, "no stamp buffer");
+  if (n_u64 > (int64_t)h->v.G * 8) n_u64 = (int64_t)h->v.G * 8;
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipMemcpy(out_host, h->v.dbg, n_u64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -173,6 +173,9 @@ int caro_profile_enable(caro_engine* h, int on);
 int caro_profile_begin(caro_engine* h, int kind, void* stream); /* returns a slot, or -1 when profiling is off */
 void caro_profile_end(caro_engine* h, int slot, void* stream);
 int caro_profile_read(caro_engine* h, double ms[8], int64_t launches[8], int reset);
+/* diagnostics (tools/probe_select.py): per-game cycle stamps of k_select's phases; off unless enabled */
+int caro_debug_stamps(caro_engine* h, int on);
+int caro_debug_read(caro_engine* h, uint64_t* out_host, int64_t n_u64, void* stream);
 /* number of live (unfinished) games; synchronises */
 int caro_live_games(caro_engine* h, int32_t* live, void* stream);
 

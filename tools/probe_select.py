@@ -1,36 +1,30 @@
-"""Where does k_select's time go?  Variants: generated vs explicit noise, node_cap, G."""
-import os, sys, time
+"""Phase stamps of k_select (diagnostic mode): where a wave's time goes, per game, in steady state."""
+import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from caro_ai_amd import _lib
 from caro_ai_amd.engine import SelfPlayEngine
 from caro_ai_amd.lib.game.connect_four import ConnectFour
 from caro_ai_amd.lib.model import Net
 from caro_ai_amd.net_hip import HipNet
-
 g = ConnectFour()
 net = Net(g.obs_shape, 7); net.load_state_dict(torch.load("tests/golden/weights/best_026_12000.dat", map_location="cpu"))
-hn = HipNet(net, "cuda:0")
-
-def run(G, cap, explicit, moves=12):
-    eng = SelfPlayEngine(g, G, evaluators=[hn], max_batch=8, node_cap=cap, seed=0)
-    nz = torch.full((G, 8, 7), 1.0 / 7, dtype=torch.float64, device="cuda:0") if explicit else None
-    for _ in range(6):
-        eng.search(25, 8, None if nz is None else [nz] * 25); eng.step(); eng.drain()
-    eng.profile(True); eng.profile_read()
-    c0 = eng.counters(); torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(moves):
-        eng.search(25, 8, None if nz is None else [nz] * 25); eng.step(); eng.drain()
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    c1 = eng.counters(); pr = eng.profile_read(); eng.profile(False)
-    us = {k: round(v[0] * 1e3 / max(1, v[1]), 1) for k, v in pr.items()}
-    print("G=%5d cap=%6d noise=%-8s  exp/s %.2fM  depth %.2f  us/launch %s" % (
-        G, cap, "explicit" if explicit else "device", (c1["expansions"] - c0["expansions"]) / dt / 1e6,
-        (c1["levels"] - c0["levels"]) / (c1["sims"] - c0["sims"]), us), flush=True)
-    eng.close()
-
-run(1024, 8464, False)
-run(1024, 8464, True)
-run(1024, 3072, False)
-run(256, 8464, False)
-run(2048, 8464, False)
-run(4096, 8464, False)
+G = 1024
+eng = SelfPlayEngine(g, G, evaluators=[HipNet(net, "cuda:0")], max_batch=8, seed=0)
+for _ in range(20):
+    eng.search(25, 8); eng.step(); eng.drain()
+L = _lib.load()
+_lib.check(L.caro_debug_stamps(eng.h, 1))
+eng.search(25, 8)
+out = np.zeros(G * 8, np.uint64)
+_lib.check(L.caro_debug_read(eng.h, out.ctypes.data, out.size, None))
+d = out.reshape(G, 8).astype(np.float64)
+rows, noise, loop, end, maxd = d[:, 0], d[:, 1], d[:, 2], d[:, 3], d[:, 4]
+q = lambda x: np.percentile(x, [50, 90, 100]).round(0)
+print("cycles since kernel start (median / p90 / max over %d waves), last minibatch of a move:" % G)
+print("  root rows + key arrived", q(rows))
+print("  noise generated        ", q(noise), " -> noise gen alone", q(noise - rows))
+print("  all descents done      ", q(loop), " -> descent loop after the root level", q(loop - noise))
+print("  end of kernel          ", q(end), " -> dedupe + result writes", q(end - loop))
+print("  max depth in the wave  ", q(maxd), " cycles per level after the root (median)", np.median((loop - noise) / np.maximum(1, maxd - 1)).round(0))
+eng.close()
