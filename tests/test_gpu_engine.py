@@ -491,3 +491,57 @@ def test_capi_rejects_bad_arguments():
     assert L.caro_select_cancel(h) == 0
     torch.cuda.synchronize()
     L.caro_engine_destroy(h)
+
+
+# ------------------------------------------------------------------ G1 at scale: 1e5 random plies, device rules vs oracle
+@pytest.mark.parametrize("d,n_games", [({"kind": "c4"}, 3000), ({"kind": "mnk", "n": 3, "k": 3}, 2500),
+                                       ({"kind": "mnk", "n": 7, "k": 4}, 300), ({"kind": "mnk", "n": 15, "k": 5}, 60)])
+def test_rules_kernels_vs_oracle_random_playouts(d, n_games):
+    """Random playouts generated with the oracle's rules (CPU); every transition is then replayed through the
+    batched device kernels: next state, won, board-full, legal mask and NN planes must all agree."""
+    from caro_ai_amd import _lib
+    L = _lib.load()
+    game = _game_of(d)
+    o = _oracle_of(d)
+    rng = np.random.default_rng(99)
+    S, M_, P_, S2, WON, FULL = [], [], [], [], [], []
+    for _ in range(n_games):
+        s, p = o.initial_state, int(rng.integers(2))
+        while True:
+            legal = o.possible_moves(s)
+            if not legal:
+                break
+            m = int(legal[int(rng.integers(len(legal)))])
+            s2, won = o.move(s, m, p)
+            S.append(s); M_.append(m); P_.append(p); S2.append(s2); WON.append(won)
+            FULL.append(len(o.possible_moves(s2)) == 0)
+            if won:
+                break
+            s, p = s2, 1 - p
+    M = len(S)
+    A, HW = game.action_space, game.obs_shape[1] * game.obs_shape[2]
+    keys = torch.from_numpy(game.to_keys(S).view(np.int64)).to(DEV)
+    moves = torch.tensor(M_, dtype=torch.int32, device=DEV)
+    players = torch.tensor(P_, dtype=torch.int32, device=DEV)
+    legal = torch.zeros((M, A), dtype=torch.uint8, device=DEV)
+    _lib.check(L.caro_rules_legal_batch(game.kind, game.n, game.k, M, keys.data_ptr(), legal.data_ptr(), None))
+    won = torch.zeros(M, dtype=torch.int32, device=DEV)
+    full = torch.zeros(M, dtype=torch.int32, device=DEV)
+    _lib.check(L.caro_rules_move_batch(game.kind, game.n, game.k, M, keys.data_ptr(), moves.data_ptr(),
+                                       players.data_ptr(), won.data_ptr(), full.data_ptr(), None))
+    who = (1 - players).contiguous()
+    planes = torch.zeros((M, 2 * HW), dtype=torch.float32, device=DEV)
+    _lib.check(L.caro_rules_encode_batch(game.kind, game.n, game.k, M, keys.data_ptr(), who.data_ptr(),
+                                         planes.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(keys.cpu().numpy().view(np.uint64), game.to_keys(S2))
+    assert won.cpu().numpy().astype(bool).tolist() == WON
+    assert full.cpu().numpy().astype(bool).tolist() == FULL
+    lg = legal.cpu().numpy()
+    pl = planes.cpu().numpy()
+    idx = rng.choice(M, size=min(M, 3000), replace=False)  # the per-state oracle calls are the slow part
+    for i in idx:
+        assert np.flatnonzero(lg[i]).tolist() == o.possible_moves(S[i])
+        ref = o.states_to_training_batch([S2[i]], [1 - P_[i]])[0].reshape(-1)
+        assert np.array_equal(pl[i], ref)
+    assert M > (50000 if d["kind"] == "c4" else 3000)
