@@ -124,9 +124,10 @@ def main():
     ap.add_argument("--evict", type=int, default=-1,
                     help="drop unreachable nodes after every move (result-neutral); default: on for gomoku15")
     ap.add_argument("--weights", default=os.path.join(ROOT, "tests", "golden", "weights", "best_026_12000.dat"))
-    ap.add_argument("--net", default="hip", choices=["hip", "hip3x", "gemm", "folded", "net"],
-                    help="inference form of lib/model.py Net: fused HIP fp32 MFMA kernel (default); hip3x = the same kernel "
-                         "with the 3x3 convs on the bf16 MFMA pipe via three-way split operands (opt-in); torch "
+    ap.add_argument("--net", default="hipw", choices=["hip", "hipw", "hip3x", "gemm", "folded", "net"],
+                    help="inference form of lib/model.py Net: hipw = fused HIP fp32 MFMA kernel, 3x3 convs in row-Winograd "
+                         "F(2,3) form (default); hip = the same with direct 3x3 convs; hip3x = direct convs on the bf16 "
+                         "MFMA pipe via three-way split operands (opt-in); torch "
                          "gather+GEMM; BN-folded conv2d; or the module as is")
     ap.add_argument("--streams", type=int, default=1,
                     help="split the games of a GPU over this many engines on separate HIP streams (tree kernels of "
@@ -172,15 +173,15 @@ def main():
         extra["evict"] = True
         extra.setdefault("node_cap", 4096)
     if args.arena:
-        assert args.game == "c4" and args.net in ("hip", "hip3x")
+        assert args.game == "c4" and args.net in ("hip", "hipw", "hip3x")
         sbt0 = 0
         net2, wtag2 = load_net(game, device, os.path.join(os.path.dirname(weights), "best_025_10600.dat"))
         wtag = wtag + " vs " + wtag2
         extra.update(n_stores=2, first_player_mode=2)
-    is_hip = args.net in ("hip", "hip3x")
+    is_hip = args.net in ("hip", "hipw", "hip3x")
     if is_hip:
         from caro_ai_amd.net_hip import HipNet
-        mode = "3xbf16" if args.net == "hip3x" else "f32"
+        mode = {"hip": "f32", "hipw": "f32w", "hip3x": "3xbf16"}[args.net]
         hipnet = HipNet(net, str(device), mode=mode)
         hipnets = [hipnet] + ([HipNet(net2, str(device), mode=mode)] if args.arena else [])
         make_evaluators = lambda: list(hipnets)
@@ -278,7 +279,8 @@ def main():
             achieved = leaves_per_launch * flops_per_leaf / avg_s / 1e12
             # hip3x issues 6 bf16 MFMA flops per algorithmic flop: priced against the dense bf16 peak / 6
             peak = MFMA_F32_PEAK_TFS if args.net != "hip3x" else MFMA_BF16_PEAK_TFS / 6.0
-            roofline = {"bound": "mfma", "kernel": "k_net_forward" if args.net != "hip3x" else "k_net_forward_3x",
+            roofline = {"bound": "mfma", "kernel": {"hip": "k_net_forward", "hipw": "k_net_forward_w",
+                                                    "hip3x": "k_net_forward_3x"}[args.net],
                         "achieved": achieved, "peak": peak,
                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc.get("k_net_forward"),
                         "avg_launch_us": avg_s * 1e6, "launches_timed": n, "leaves_per_launch": leaves_per_launch,
@@ -299,7 +301,7 @@ def main():
                                    % ("Connect4 6x7" if args.game == "c4" else "m,n,k 15x15 k=5", G,
                                       "arena matches (two nets, one tree per player)" if args.arena else "self-play games",
                                       S, B, S * B, sbt0),
-                       "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py Net, %s fp32" % {"hip": "fused HIP MFMA kernel", "hip3x": "fused HIP kernel, 3x3 convs as 3-way split bf16 MFMA with f32 accumulate,", "gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net],
+                       "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py Net, %s fp32" % {"hip": "fused HIP MFMA kernel", "hipw": "fused HIP MFMA kernel, 3x3 convs in row-Winograd F(2,3) form,", "hip3x": "fused HIP kernel, 3x3 convs as 3-way split bf16 MFMA with f32 accumulate,", "gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net],
                        "streams_per_gpu": n_streams,
                        "parallelism": "games sharded x%d, all-gather of tuples per step" % world},
             "per_gpu": exp_all / dt_max / world,

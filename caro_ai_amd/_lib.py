@@ -11,6 +11,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcaro_hip.so")
+if os.environ.get("CARO_HIP_LIB"):  # kernel experiments: another build of the same library
+    LIB_PATH = os.environ["CARO_HIP_LIB"]
 
 GAME_CONNECT4, GAME_MNK = 0, 1
 
@@ -59,6 +61,7 @@ _SIGNATURES = {
     "caro_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int64, C.c_int, _P]),
     "caro_net_destroy": (None, [_P]),
     "caro_net_enable_3xbf16": (C.c_int, [_P, _P, C.c_int64]),
+    "caro_net_enable_winograd": (C.c_int, [_P, _P, C.c_int64]),
     "caro_net_boards_per_workgroup": (C.c_int, [_P]),
     "caro_net_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P]),
     "caro_stream_create_partition": (C.c_int, [C.c_int, C.c_int, C.c_int, _P]),

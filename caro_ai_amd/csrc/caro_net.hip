@@ -29,6 +29,7 @@
 // float32 throughout: MFMA f32 is an exact fma chain in k order.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -65,6 +66,8 @@ struct NetParams {
   const float* w_p;     // [A][2*HW]
   const float* b_p;     // [A]
   const uint4* w3;      // 3xbf16 mode: [45 taps][1536 granules] LDS image of the split residual weights, or null
+  const float* ww;      // f32w mode: [5][4 p][3 dx][4096] transformed residual weights (LDS image order), or null
+  const uint32_t* wtab; // f32w mode: [128] tile of MFMA row (row tile, lane): board | ty << 8 | x << 16 | valid << 24
 };
 
 __device__ __forceinline__ int aoff(int row, int c) {
@@ -73,6 +76,118 @@ __device__ __forceinline__ int aoff(int row, int c) {
 __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
 
 constexpr int NT = 512;  // threads per workgroup
+
+// conv_in on the VALU (lib/model.py:24-28 folded): two threads per row, 32 output channels each.
+// `pl0` = planes of this workgroup's first board, `win` = the [9][2][64] weights staged in LDS.
+__device__ __forceinline__ void conv_in_f32(const NetParams& p, const float* __restrict__ pl0, float* act,
+                                            const float* win, int R, int tid) {
+  const int HW = p.HW;
+  const float slope = p.slope;
+  const int r = tid & 255;
+  const int chalf = tid >> 8;
+  if (r < R) {
+    const int bi = r / HW, cell = r - bi * HW;
+    const int y = cell / p.W, x = cell - y * p.W;
+    const float* pl = pl0 + (size_t)bi * 2 * HW;
+    float in0[9], in1[9];  // the 18 inputs of this row (statically indexed: stays in registers)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ny = y + t / 3 - 1, nx = x + t % 3 - 1;
+      const bool ok = ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
+      in0[t] = ok ? pl[ny * p.W + nx] : 0.f;
+      in1[t] = ok ? pl[HW + ny * p.W + nx] : 0.f;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int c4 = chalf * 8 + cc;
+      float o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[u] = p.b_in[c4 * 4 + u];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float i0 = in0[t], i1 = in1[t];
+        const float4 w0 = *reinterpret_cast<const float4*>(win + (2 * t) * NF + c4 * 4);
+        const float4 w1 = *reinterpret_cast<const float4*>(win + (2 * t + 1) * NF + c4 * 4);
+        o[0] = fmaf(i0, w0.x, o[0]); o[1] = fmaf(i0, w0.y, o[1]); o[2] = fmaf(i0, w0.z, o[2]); o[3] = fmaf(i0, w0.w, o[3]);
+        o[0] = fmaf(i1, w1.x, o[0]); o[1] = fmaf(i1, w1.y, o[1]); o[2] = fmaf(i1, w1.z, o[2]); o[3] = fmaf(i1, w1.w, o[3]);
+      }
+      float4 out = make_float4(leaky(o[0], slope), leaky(o[1], slope), leaky(o[2], slope), leaky(o[3], slope));
+      *reinterpret_cast<float4*>(act + r * NF + ((c4 ^ (r & 15)) << 2)) = out;
+    }
+  }
+}
+
+// 1x1 heads, the two FC heads, tanh and the softmax (lib/model.py:44-67, lib/mcts.py:216) from the trunk
+// output in `act`; `scratch` = the (now free) weight stage.  probs / values point at this workgroup's first board.
+__device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, float* scratch,
+                                          float* __restrict__ probs, float* __restrict__ values, int nb, int R,
+                                          int tid) {
+  const int HW = p.HW;
+  const float slope = p.slope;
+  float* feat = scratch;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
+  {
+    const int r = tid;
+    if (r < R) {
+      float s0 = p.b_head[0], s1 = p.b_head[1], s2 = p.b_head[2];
+      for (int g = 0; g < 16; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(act + r * NF + ((g ^ (r & 15)) << 2));
+        const int c = g * 4;
+        s0 = fmaf(v.x, p.w_head[c], s0); s0 = fmaf(v.y, p.w_head[c + 1], s0);
+        s0 = fmaf(v.z, p.w_head[c + 2], s0); s0 = fmaf(v.w, p.w_head[c + 3], s0);
+        s1 = fmaf(v.x, p.w_head[NF + c], s1); s1 = fmaf(v.y, p.w_head[NF + c + 1], s1);
+        s1 = fmaf(v.z, p.w_head[NF + c + 2], s1); s1 = fmaf(v.w, p.w_head[NF + c + 3], s1);
+        s2 = fmaf(v.x, p.w_head[2 * NF + c], s2); s2 = fmaf(v.y, p.w_head[2 * NF + c + 1], s2);
+        s2 = fmaf(v.z, p.w_head[2 * NF + c + 2], s2); s2 = fmaf(v.w, p.w_head[2 * NF + c + 3], s2);
+      }
+      feat[r] = leaky(s0, slope);
+      feat[256 + r] = leaky(s1, slope);
+      feat[512 + r] = leaky(s2, slope);
+    }
+  }
+  __syncthreads();
+  float* hid = feat + 768;              // [TB][20]
+  float* logit = feat + 768 + 20 * 32;  // [TB * A] (TB * A <= 1024, see caro_net_create)
+  // value head: Linear(HW,20) + LeakyReLU
+  for (int k = tid; k < nb * 20; k += NT) {
+    const int bi = k / 20, u = k - bi * 20;
+    float s = p.b_v1[u];
+    const float* w = p.w_v1 + u * HW;
+    const float* f = feat + bi * HW;
+    for (int c = 0; c < HW; ++c) s = fmaf(f[c], w[c], s);
+    hid[k] = leaky(s, slope);
+  }
+  // policy head: Linear(2*HW, A) on the (c, y, x)-flattened planes
+  for (int k = tid; k < nb * p.A; k += NT) {
+    const int bi = k / p.A, a = k - bi * p.A;
+    float s = p.b_p[a];
+    const float* w = p.w_p + (size_t)a * 2 * HW;
+    const float* f0 = feat + 256 + bi * HW;
+    const float* f1 = feat + 512 + bi * HW;
+    for (int c = 0; c < HW; ++c) s = fmaf(f0[c], w[c], s);
+    for (int c = 0; c < HW; ++c) s = fmaf(f1[c], w[HW + c], s);
+    logit[k] = s;
+  }
+  __syncthreads();
+  // Linear(20,1) + tanh; softmax statistics per board
+  float* stat = logit + 256 * 4;  // [TB][2] max, sum  (logit region sized 1024 floats)
+  if (tid < nb) {
+    float s = p.b_v2[0];
+    for (int u = 0; u < 20; ++u) s = fmaf(hid[tid * 20 + u], p.w_v2[u], s);
+    values[tid] = tanhf(s);
+    float mx = -3.4e38f;
+    for (int a = 0; a < p.A; ++a) mx = fmaxf(mx, logit[tid * p.A + a]);
+    float sum = 0.f;
+    for (int a = 0; a < p.A; ++a) sum += expf(logit[tid * p.A + a] - mx);
+    stat[2 * tid] = mx;
+    stat[2 * tid + 1] = sum;
+  }
+  __syncthreads();
+  for (int k = tid; k < nb * p.A; k += NT) {
+    const int bi = k / p.A;
+    probs[k] = expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
+  }
+}
+
 
 // `which` = 0 / 1: rows of that net only (p0 is used).  `which` = 2: both nets in ONE launch -- tiles
 // [0, ceil(L0/TB)) run net 0 on rows [0, L0), the following tiles run net 1 (p1) on rows [L0, L0+L1).
@@ -99,7 +214,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
     board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
   }
   if (board0 >= L) return;
-  const NetParams& p = second ? p1 : p0;
+  const NetParams p = second ? p1 : p0;
   const float slope = p.slope;
   // diagnostic only (stamps == nullptr in every product launch): shader clock vs 100 MHz wall clock
   unsigned long long t_c0 = 0, t_r0 = 0;
@@ -120,42 +235,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
   for (int k = tid; k < 9 * 2 * NF; k += NT) wbuf[k] = p.w_in[k];
   __syncthreads();
 
-  // ---- conv_in on the VALU: two threads per row, 32 output channels each
-  {
-    const int r = tid & 255;
-    const int chalf = tid >> 8;
-    if (r < R) {
-      const int bi = r / HW, cell = r - bi * HW;
-      const int y = cell / p.W, x = cell - y * p.W;
-      const float* pl = planes + (size_t)(row0 + board0 + bi) * 2 * HW;
-      float in0[9], in1[9];  // the 18 inputs of this row (statically indexed: stays in registers)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int ny = y + t / 3 - 1, nx = x + t % 3 - 1;
-        const bool ok = ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
-        in0[t] = ok ? pl[ny * p.W + nx] : 0.f;
-        in1[t] = ok ? pl[HW + ny * p.W + nx] : 0.f;
-      }
-#pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        const int c4 = chalf * 8 + cc;
-        float o[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) o[u] = p.b_in[c4 * 4 + u];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const float i0 = in0[t], i1 = in1[t];
-          const float4 w0 = *reinterpret_cast<const float4*>(wbuf + (2 * t) * NF + c4 * 4);
-          const float4 w1 = *reinterpret_cast<const float4*>(wbuf + (2 * t + 1) * NF + c4 * 4);
-          o[0] = fmaf(i0, w0.x, o[0]); o[1] = fmaf(i0, w0.y, o[1]); o[2] = fmaf(i0, w0.z, o[2]); o[3] = fmaf(i0, w0.w, o[3]);
-          o[0] = fmaf(i1, w1.x, o[0]); o[1] = fmaf(i1, w1.y, o[1]); o[2] = fmaf(i1, w1.z, o[2]); o[3] = fmaf(i1, w1.w, o[3]);
-        }
-        float4 out = make_float4(leaky(o[0], slope), leaky(o[1], slope), leaky(o[2], slope),
-                                 leaky(o[3], slope));
-        *reinterpret_cast<float4*>(act + r * NF + ((c4 ^ (r & 15)) << 2)) = out;
-      }
-    }
-  }
+  conv_in_f32(p, planes + (size_t)(row0 + board0) * 2 * HW, act, wbuf, R, tid);
   __syncthreads();
 
   unsigned long long t_trunk0 = 0;
@@ -280,68 +360,249 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
   // `act` now holds the trunk output; the weight stage is free scratch
-  float* feat = wbuf;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
+  heads_f32(p, act, wbuf, probs + (size_t)(row0 + board0) * p.A, values + row0 + board0, nb, R, tid);
+  if (stamps && tid == 0) {
+    stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
+    stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
+    stamps[4 * blockIdx.x + 2] = t_trunk0 - t_c0;
+    stamps[4 * blockIdx.x + 3] = t_trunk1 - t_c0;
+  }
+}
+
+
+// ===================================================================================================
+// Winograd form F(2,3) along the board rows ("f32w"): the same float32 network function with one third fewer
+// MFMAs.  A 3x3 convolution is 3 column taps dx of a 3-tap convolution along y; for a pair of output rows
+// (2ty, 2ty+1) the latter needs 4 products per (dx, ci) instead of 6:
+//     d0..d3 = input rows 2ty-1 .. 2ty+2 (zero outside the board), g0..g2 = the kernel column
+//     m0 = (d0-d2) g0, m1 = (d1+d2)(g0+g1+g2)/2, m2 = (d2-d1)(g0-g1+g2)/2, m3 = (d1-d3) g2
+//     y(2ty) = m0+m1+m2,  y(2ty+1) = m1-m2-m3
+// GEMM rows are TILES t = board*TPB + ty*W + x (TPB = ceil(H/2)*W; 21 for connect four, so 6 boards = 126
+// of 128 rows), K = 4 transformed taps p x 3 dx x 64 channels, U[p][dx] = sum_ky G[p][ky] w[ky][dx] is
+// packed by the host (float64 sum, one rounding).  The transformed input d_a +- d_b is formed in registers
+// from two LDS reads when the A operand is loaded, so nothing but the activations themselves lives in LDS.
+// Wave w owns row tile w>>1 x col tile w&1 (32 tiles x 32 channels): accumulator M for the running p, and
+// Y0/Y1 for the two output rows, 48 accumulator registers.  Weight chunk = the 3 dx taps of one p.
+constexpr int WTAPS = NRES * 12;          // 60
+constexpr int WNCHUNK = WTAPS / TPC;      // 20
+
+__global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams p1,
+                                                           const float* __restrict__ planes,
+                                                           const int32_t* __restrict__ counts, int which,
+                                                           float* __restrict__ probs, float* __restrict__ values,
+                                                           unsigned long long* __restrict__ stamps) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float* act = lds;
+  float* wbuf = lds + ACT;
+
+  int L, row0, board0;
+  bool second = false;
+  if (which < 2) {
+    L = counts[which];
+    row0 = which ? counts[0] : 0;
+    board0 = blockIdx.x * p0.TB;
+  } else {
+    const int L0 = counts[0];
+    const int t0 = (L0 + p0.TB - 1) / p0.TB;
+    second = (int)blockIdx.x >= t0;
+    L = second ? counts[1] : L0;
+    row0 = second ? L0 : 0;
+    board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
+  }
+  if (board0 >= L) return;
+  const NetParams p = second ? p1 : p0;
+  const float slope = p.slope;
+  unsigned long long t_c0 = 0, t_r0 = 0;  // diagnostic only, as in k_net_forward
+  if (stamps) {
+    t_c0 = __builtin_amdgcn_s_memtime();
+    t_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  const int nb = min(p.TB, L - board0);
+  const int HW = p.HW;
+  const int R = nb * HW;  // real rows
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 31, h = lane >> 5;
+
+  for (int k = tid; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = tid; k < 9 * 2 * NF; k += NT) wbuf[k] = p.w_in[k];
+  __syncthreads();
+  conv_in_f32(p, planes + (size_t)(row0 + board0) * 2 * HW, act, wbuf, R, tid);
+  __syncthreads();
+  unsigned long long t_trunk0 = 0;
+  if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
   {
-    const int r = tid;
-    if (r < R) {
-      float s0 = p.b_head[0], s1 = p.b_head[1], s2 = p.b_head[2];
-      for (int g = 0; g < 16; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(act + r * NF + ((g ^ (r & 15)) << 2));
-        const int c = g * 4;
-        s0 = fmaf(v.x, p.w_head[c], s0); s0 = fmaf(v.y, p.w_head[c + 1], s0);
-        s0 = fmaf(v.z, p.w_head[c + 2], s0); s0 = fmaf(v.w, p.w_head[c + 3], s0);
-        s1 = fmaf(v.x, p.w_head[NF + c], s1); s1 = fmaf(v.y, p.w_head[NF + c + 1], s1);
-        s1 = fmaf(v.z, p.w_head[NF + c + 2], s1); s1 = fmaf(v.w, p.w_head[NF + c + 3], s1);
-        s2 = fmaf(v.x, p.w_head[2 * NF + c], s2); s2 = fmaf(v.y, p.w_head[2 * NF + c + 1], s2);
-        s2 = fmaf(v.z, p.w_head[2 * NF + c + 2], s2); s2 = fmaf(v.w, p.w_head[2 * NF + c + 3], s2);
+    const float4* src = reinterpret_cast<const float4*>(p.ww);
+#pragma unroll
+    for (int m = 0; m < 2 * TPC; ++m) reinterpret_cast<float4*>(wbuf)[tid + NT * m] = src[tid + NT * m];
+  }
+  __syncthreads();
+
+  const int rt = wave >> 1, ct = wave & 1;
+  // this lane's tile.  Which tile sits on which MFMA row is a host-built table: a ds_read_b128 is served in
+  // 16-lane groups, a group is conflict-free when its 16 activation rows differ mod 16 (the swizzle key), and the
+  // table picks the tiles of each group accordingly (caro_net_enable_winograd)
+  const uint32_t tent = p.wtab[rt * 32 + i];
+  const int tbi = tent & 0xFF, tty = (tent >> 8) & 0xFF, tx = (tent >> 16) & 0xFF;
+  const bool tvalid = (tent >> 24) != 0 && tbi < nb;
+  const int bswz = (i >> 1) & 7;
+  // output side: with the WEIGHTS as first MFMA operand a lane's 16 accumulator registers are 4 groups of 4
+  // consecutive channels (ct*32 + 8q + 4h + 0..3) of ITS tile, so the epilogue moves float4s
+  const int orow0 = tbi * HW + 2 * tty * p.W + tx;  // activation row of output row 2ty
+  const bool ovalid0 = tvalid, ovalid1 = tvalid && 2 * tty + 1 < p.H;
+  f32x16 accM, accY0, accY1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    accM[e] = 0.f;
+    accY0[e] = 0.f;
+    accY1[e] = 0.f;
+  }
+  // float offset of (row, granule 8h) with the row's swizzle key folded in, for the three dx taps of transformed tap
+  // pp; the granule index Q of a set is XORed in afterwards ((8h + Q) ^ key == ((8h) ^ key) ^ Q)
+  auto tap_offsets = [&](int pp, int* oa, int* ob) {
+    const int ja = pp == 0 ? 0 : (pp == 2 ? 2 : 1);
+    const int jb = pp == 0 ? 2 : (pp == 1 ? 2 : (pp == 2 ? 1 : 3));
+    const int ya = 2 * tty - 1 + ja, yb = 2 * tty - 1 + jb;
+    const bool oka = tvalid && ya >= 0 && ya < p.H, okb = tvalid && yb >= 0 && yb < p.H;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int nx = tx + d - 1;
+      const bool okx = nx >= 0 && nx < p.W;
+      const int rowa = oka && okx ? tbi * HW + ya * p.W + nx : ZROW;
+      const int rowb = okb && okx ? tbi * HW + yb * p.W + nx : ZROW;
+      oa[d] = rowa * NF + (((h * 8) ^ (rowa & 15)) << 2);
+      ob[d] = rowb * NF + (((h * 8) ^ (rowb & 15)) << 2);
+    }
+  };
+  const float* wlane = wbuf + (h * 64 + ct * 32 + i) * 32;
+  int offa[3], offb[3];
+  tap_offsets(0, offa, offb);
+  float4 xa, xs, xb, ya_, ys, yb_;
+  // The MFMA stream of a layer is ONE software pipeline over its 96 operand sets (4 p x 3 dx x 8 granules): the
+  // reads of set s+1 are issued before the four MFMAs of set s, across chunk boundaries too.  The two workgroup
+  // barriers a weight chunk needs sit inside the stream, where only the skew between waves is paid:
+  //   after tap 0: every wave has left the previous chunk -> its buffer is free -> write the staged next chunk
+  //   after tap 1: the next chunk is visible              -> its first operands can be prefetched during tap 2
+  for (int c = 0; c < WNCHUNK; ++c) {  // chunk = the three dx taps of one transformed tap p
+    const int cur = c & 1;
+    const int layer = c >> 2, pp = c & 3;
+    const bool has_next = c + 1 < WNCHUNK;
+    const float sg = pp == 1 ? 1.f : -1.f;
+    const float* wbase = wlane + cur * TPC * WCHUNK;
+    const float* wnext = wlane + (cur ^ 1) * TPC * WCHUNK;
+    int noffa[3], noffb[3];
+#define CARO_LOADW(A_, S_, B_, S)                                                                   \
+  A_ = *reinterpret_cast<const float4*>(act + (offa[(S) >> 3] ^ (((S) & 7) << 2)));                  \
+  S_ = *reinterpret_cast<const float4*>(act + (offb[(S) >> 3] ^ (((S) & 7) << 2)));                  \
+  B_ = *reinterpret_cast<const float4*>(wbase + ((S) >> 3) * WCHUNK + ((((S) & 7) ^ bswz) << 2));
+// the four transformed operands first, then the four MFMAs back to back: interleaving v_fma / v_mfma pairs costs
+// ~6 % of the trunk (each MFMA then waits on the VALU result just ahead of it)
+#define CARO_MFMAW(A_, S_, B_)                                                                        \
+  {                                                                                                  \
+    const float v0 = fmaf(sg, S_.x, A_.x), v1 = fmaf(sg, S_.y, A_.y), v2 = fmaf(sg, S_.z, A_.z),     \
+                v3 = fmaf(sg, S_.w, A_.w);                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    accM = __builtin_amdgcn_mfma_f32_32x32x2f32(B_.x, v0, accM, 0, 0, 0);                            \
+    accM = __builtin_amdgcn_mfma_f32_32x32x2f32(B_.y, v1, accM, 0, 0, 0);                            \
+    accM = __builtin_amdgcn_mfma_f32_32x32x2f32(B_.z, v2, accM, 0, 0, 0);                            \
+    accM = __builtin_amdgcn_mfma_f32_32x32x2f32(B_.w, v3, accM, 0, 0, 0);                            \
+  }
+    if (pp == 0) {  // first chunk of a layer: nothing was prefetched across the in-place epilogue
+      CARO_LOADW(xa, xs, xb, 0)
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 24; s_ += 2) {
+      CARO_LOADW(ya_, ys, yb_, s_ + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      CARO_MFMAW(xa, xs, xb)
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_ + 2 < 24) {
+        CARO_LOADW(xa, xs, xb, s_ + 2)
+      } else if (pp != 3) {  // set 0 of the next chunk (same layer: the activations do not change)
+        xa = *reinterpret_cast<const float4*>(act + noffa[0]);
+        xs = *reinterpret_cast<const float4*>(act + noffb[0]);
+        xb = *reinterpret_cast<const float4*>(wnext + (bswz << 2));
       }
-      feat[r] = leaky(s0, slope);
-      feat[256 + r] = leaky(s1, slope);
-      feat[512 + r] = leaky(s2, slope);
+      __builtin_amdgcn_sched_barrier(0);
+      CARO_MFMAW(ya_, ys, yb_)
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_ == 6) {
+        __syncthreads();  // every wave has left chunk c-1: the other buffer is free
+        if (has_next) {
+          // next chunk: global -> LDS directly (no staging registers); each wave instruction moves 1 KiB, the LDS
+          // image is the packed order.  The barrier after tap 1 waits for them (vmcnt(0)) and publishes them.
+          const float4* src = reinterpret_cast<const float4*>(p.ww + (size_t)(c + 1) * TPC * WCHUNK) + tid;
+          float* dstw = wbuf + (cur ^ 1) * TPC * WCHUNK + wave * 256;
+#pragma unroll
+          for (int m = 0; m < 2 * TPC; ++m)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + m * NT),
+                (__attribute__((address_space(3))) void*)(dstw + m * NT * 4), 16, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (s_ == 14) {
+        __syncthreads();  // chunk c+1 is visible to every wave
+        tap_offsets((pp + 1) & 3, noffa, noffb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#undef CARO_LOADW
+#undef CARO_MFMAW
+    // output transform: Y0 += {1,1,1,0}[p] * M,  Y1 += {0,1,-1,-1}[p] * M
+    const float c0 = pp == 3 ? 0.f : 1.f;
+    const float c1 = pp == 0 ? 0.f : (pp == 1 ? 1.f : -1.f);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      accY0[e] = fmaf(c0, accM[e], accY0[e]);
+      accY1[e] = fmaf(c1, accM[e], accY1[e]);
+      accM[e] = 0.f;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      offa[d] = noffa[d];
+      offb[d] = noffb[d];
+    }
+    if (pp == 3) {
+      __syncthreads();  // every wave has read this layer's input activations: they may be overwritten
+      // in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89); only real cells are written, the rest stay 0
+      const float* bias = p.b_res + layer * NF + ct * 32 + 4 * h;
+      const int g0 = ct * 8 + h;  // granule of group q is g0 + 2q
+      float* row0p = act + orow0 * NF;
+      float* row1p = row0p + p.W * NF;
+      const int k0 = orow0 & 15, k1 = (orow0 + p.W) & 15;
+      float4 old0[4], old1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        old0[q] = ovalid0 ? *reinterpret_cast<const float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        old1[q] = ovalid1 ? *reinterpret_cast<const float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bq = *reinterpret_cast<const float4*>(bias + 8 * q);
+        float4 n0, n1;
+        n0.x = old0[q].x + leaky(accY0[4 * q] + bq.x, slope);
+        n0.y = old0[q].y + leaky(accY0[4 * q + 1] + bq.y, slope);
+        n0.z = old0[q].z + leaky(accY0[4 * q + 2] + bq.z, slope);
+        n0.w = old0[q].w + leaky(accY0[4 * q + 3] + bq.w, slope);
+        n1.x = old1[q].x + leaky(accY1[4 * q] + bq.x, slope);
+        n1.y = old1[q].y + leaky(accY1[4 * q + 1] + bq.y, slope);
+        n1.z = old1[q].z + leaky(accY1[4 * q + 2] + bq.z, slope);
+        n1.w = old1[q].w + leaky(accY1[4 * q + 3] + bq.w, slope);
+        if (ovalid0) *reinterpret_cast<float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) = n0;
+        if (ovalid1) *reinterpret_cast<float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) = n1;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        accY0[e] = 0.f;
+        accY1[e] = 0.f;
+      }
+      __syncthreads();  // new activations visible to every wave
     }
   }
-  __syncthreads();
-  float* hid = feat + 768;      // [TB][20]
-  float* logit = feat + 768 + 20 * 32;  // [TB * A] (TB*A <= 255*... see host check)
-  // value head: Linear(HW,20) + LeakyReLU
-  for (int k = tid; k < nb * 20; k += NT) {
-    const int bi = k / 20, u = k - bi * 20;
-    float s = p.b_v1[u];
-    const float* w = p.w_v1 + u * HW;
-    const float* f = feat + bi * HW;
-    for (int c = 0; c < HW; ++c) s = fmaf(f[c], w[c], s);
-    hid[k] = leaky(s, slope);
-  }
-  // policy head: Linear(2*HW, A) on the (c, y, x)-flattened planes
-  for (int k = tid; k < nb * p.A; k += NT) {
-    const int bi = k / p.A, a = k - bi * p.A;
-    float s = p.b_p[a];
-    const float* w = p.w_p + (size_t)a * 2 * HW;
-    const float* f0 = feat + 256 + bi * HW;
-    const float* f1 = feat + 512 + bi * HW;
-    for (int c = 0; c < HW; ++c) s = fmaf(f0[c], w[c], s);
-    for (int c = 0; c < HW; ++c) s = fmaf(f1[c], w[HW + c], s);
-    logit[k] = s;
-  }
-  __syncthreads();
-  // Linear(20,1) + tanh; softmax statistics per board
-  float* stat = logit + 256 * 4;  // [TB][2] max, sum  (logit region sized 1024 floats)
-  if (tid < nb) {
-    float s = p.b_v2[0];
-    for (int u = 0; u < 20; ++u) s = fmaf(hid[tid * 20 + u], p.w_v2[u], s);
-    values[row0 + board0 + tid] = tanhf(s);
-    float mx = -3.4e38f;
-    for (int a = 0; a < p.A; ++a) mx = fmaxf(mx, logit[tid * p.A + a]);
-    float sum = 0.f;
-    for (int a = 0; a < p.A; ++a) sum += expf(logit[tid * p.A + a] - mx);
-    stat[2 * tid] = mx;
-    stat[2 * tid + 1] = sum;
-  }
-  __syncthreads();
-  for (int k = tid; k < nb * p.A; k += NT) {
-    const int bi = k / p.A;
-    probs[(size_t)(row0 + board0) * p.A + k] = expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
-  }
+  unsigned long long t_trunk1 = 0;
+  if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
+  heads_f32(p, act, wbuf, probs + (size_t)(row0 + board0) * p.A, values + row0 + board0, nb, R, tid);
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
     stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
@@ -419,7 +680,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParam
     board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
   }
   if (board0 >= L) return;
-  const NetParams& p = second ? p1 : p0;
+  const NetParams p = second ? p1 : p0;
   const float slope = p.slope;
   const int nb = min(p.TB, L - board0);
   const int HW = p.HW;
@@ -665,6 +926,8 @@ struct caro_net {
   cnet::NetParams p;
   float* dev;
   uint4* w3_dev;  // split residual weights (3xbf16 mode), or null
+  float* ww_dev;  // transformed residual weights (f32w mode), or null
+  uint32_t* wtab_dev;  // tile table (f32w mode), or null
   int device;
 };
 
@@ -695,6 +958,8 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   caro_net* n = new caro_net();
   n->device = device_id;
   n->w3_dev = nullptr;
+  n->ww_dev = nullptr;
+  n->wtab_dev = nullptr;
   const size_t pad = (size_t)cnet::TPC * cnet::WCHUNK;  // k_net_forward reads one chunk past the last tap
   if (hipMalloc((void**)&n->dev, (n_floats + pad) * sizeof(float)) != hipSuccess) {
     delete n;
@@ -724,6 +989,8 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   p.w_p = q;    q += (size_t)A * 2 * HW;
   p.b_p = q;    q += A;
   p.w3 = nullptr;
+  p.ww = nullptr;
+  p.wtab = nullptr;
   *out = n;
   return 0;
 }
@@ -742,9 +1009,75 @@ int caro_net_enable_3xbf16(caro_net* n, const uint16_t* w3_host, int64_t n_u16) 
   return 0;
 }
 
+/* f32w mode: upload the row-Winograd F(2,3) transformed residual weights ([5][4 p][3 dx] chunks of 4096 floats in
+ * the LDS image order of the plain residual weights, packed by caro_ai_amd/net_hip.py:pack_net_w); from then on the
+ * forward calls of this net run k_net_forward_w: float32 MFMA like the default, two thirds of the multiplies.
+ * The boards-per-workgroup figure may shrink (128 tiles of ceil(H/2) x W per workgroup). */
+int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats) {
+  if (!n || !ww_host) return nfail(CARO_E_INVAL, "null argument");
+  if (n->p.w3) return nfail(CARO_E_STATE, "net is already in 3xbf16 mode");
+  const int64_t want = (int64_t)cnet::WTAPS * cnet::WCHUNK;
+  if (n_floats != want) return nfail(CARO_E_INVAL, "transformed weight image has the wrong size");
+  if (hipSetDevice(n->device) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
+  if (!n->ww_dev && hipMalloc((void**)&n->ww_dev, want * sizeof(float)) != hipSuccess)
+    return nfail(CARO_E_NOMEM, "hipMalloc failed");
+  if (hipMemcpy(n->ww_dev, ww_host, want * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+    return nfail(CARO_E_HIP, "hipMemcpy failed");
+  const int H = n->p.H, W = n->p.W, HW = n->p.HW;
+  const int tpb = ((H + 1) / 2) * W;
+  if (tpb > 128) return nfail(CARO_E_INVAL, "board too large for the 128-tile workgroup");
+  const int tbw = 128 / tpb;
+  if (tbw < n->p.TB) n->p.TB = tbw;
+  // tile -> (row tile, lane) table.  ds_read_b128 lane groups (MI355X_MICROARCH.md, LDS): within a 32-lane half
+  // {0-3,12-15,20-27} and {4-11,16-19,28-31}; 4 row tiles x 2 groups = 8 groups of 16 MFMA rows.  A tile's
+  // activation rows are base + const with base = board*HW + 2*ty*W + x, so a group is conflict-free when its
+  // bases differ mod 16: residues are dealt to the groups most frequent first, what does not fit goes anywhere.
+  static const int kLanes[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+  std::vector<uint32_t> by_res[16], group[8], left;
+  bool has[8][16] = {};
+  for (int bi = 0; bi < n->p.TB; ++bi)
+    for (int ty = 0; ty < (H + 1) / 2; ++ty)
+      for (int x = 0; x < W; ++x)
+        by_res[(bi * HW + 2 * ty * W + x) & 15].push_back((uint32_t)bi | (uint32_t)ty << 8 | (uint32_t)x << 16 | 1u << 24);
+  int order[16];
+  for (int r = 0; r < 16; ++r) order[r] = r;
+  std::sort(order, order + 16, [&](int a, int b) { return by_res[a].size() > by_res[b].size(); });
+  for (int oi = 0; oi < 16; ++oi) {
+    const int r = order[oi];
+    for (uint32_t t : by_res[r]) {
+      int best = -1;
+      for (int g = 0; g < 8; ++g)
+        if (!has[g][r] && group[g].size() < 16 && (best < 0 || group[g].size() < group[best].size())) best = g;
+      if (best < 0) {
+        left.push_back(t);
+      } else {
+        has[best][r] = true;
+        group[best].push_back(t);
+      }
+    }
+  }
+  for (uint32_t t : left) {
+    int best = 0;
+    for (int g = 1; g < 8; ++g)
+      if (group[g].size() < group[best].size()) best = g;
+    group[best].push_back(t);
+  }
+  uint32_t tab[128] = {};
+  for (int g = 0; g < 8; ++g)
+    for (size_t k = 0; k < group[g].size(); ++k) tab[(g >> 1) * 32 + kLanes[g & 1][k]] = group[g][k];
+  if (!n->wtab_dev && hipMalloc((void**)&n->wtab_dev, sizeof(tab)) != hipSuccess) return nfail(CARO_E_NOMEM, "hipMalloc failed");
+  if (hipMemcpy(n->wtab_dev, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) return nfail(CARO_E_HIP, "hipMemcpy failed");
+  n->p.wtab = n->wtab_dev;
+  n->p.ww = n->ww_dev;
+  return 0;
+}
+
 void caro_net_destroy(caro_net* n) {
   if (!n) return;
   if (n->w3_dev) (void)hipFree(n->w3_dev);
+  if (n->ww_dev) (void)hipFree(n->ww_dev);
+  if (n->wtab_dev) (void)hipFree(n->wtab_dev);
   (void)hipFree(n->dev);
   delete n;
 }
@@ -760,6 +1093,9 @@ int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts
   if (n->p.w3)
     hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
                        planes_dev, counts_dev, which, probs_dev, values_dev);
+  else if (n->p.ww)
+    hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
+                       planes_dev, counts_dev, which, probs_dev, values_dev, (unsigned long long*)nullptr);
   else
     hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
                        planes_dev, counts_dev, which, probs_dev, values_dev, (unsigned long long*)nullptr);
@@ -773,11 +1109,15 @@ int caro_net_forward_pair(caro_net* n0, caro_net* n1, const float* planes_dev, c
   if (!n0 || !n1 || !planes_dev || !counts_dev || !probs_dev || !values_dev) return nfail(CARO_E_INVAL, "null argument");
   if (n0->p.H != n1->p.H || n0->p.W != n1->p.W || n0->p.A != n1->p.A) return nfail(CARO_E_INVAL, "nets differ in shape");
   if (max_rows <= 0) return 0;
-  if ((n0->p.w3 == nullptr) != (n1->p.w3 == nullptr)) return nfail(CARO_E_INVAL, "nets differ in arithmetic mode");
+  if ((n0->p.w3 == nullptr) != (n1->p.w3 == nullptr) || (n0->p.ww == nullptr) != (n1->p.ww == nullptr))
+    return nfail(CARO_E_INVAL, "nets differ in arithmetic mode");
   const unsigned grid = (unsigned)((max_rows + n0->p.TB - 1) / n0->p.TB + 1);  // +1: each class rounds up
   if (n0->p.w3)
     hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n0->p, n1->p,
                        planes_dev, counts_dev, 2, probs_dev, values_dev);
+  else if (n0->p.ww)
+    hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n0->p, n1->p,
+                       planes_dev, counts_dev, 2, probs_dev, values_dev, (unsigned long long*)nullptr);
   else
     hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n0->p, n1->p,
                        planes_dev, counts_dev, 2, probs_dev, values_dev, (unsigned long long*)nullptr);
@@ -791,8 +1131,13 @@ int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t
                              void* stream) {
   if (!n || !stamps_dev) return nfail(CARO_E_INVAL, "null argument");
   const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
-  hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p, planes_dev,
-                     counts_dev, which, probs_dev, values_dev, (unsigned long long*)stamps_dev);
+  if (n->p.w3) return nfail(CARO_E_STATE, "no stamps in 3xbf16 mode");
+  if (n->p.ww)
+    hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
+                       planes_dev, counts_dev, which, probs_dev, values_dev, (unsigned long long*)stamps_dev);
+  else
+    hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
+                       planes_dev, counts_dev, which, probs_dev, values_dev, (unsigned long long*)stamps_dev);
   if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
   return 0;
 }

@@ -25,6 +25,9 @@ from caro_ai_amd import config as cfg
 COUNTER_NAMES = ["sims", "levels", "expansions", "terminals", "dropped", "overflows", "plies", "finished"]
 
 
+# inference= values served by the fused HIP net kernel -> HipNet mode
+HIP_NET_MODES = {"hip": "f32", "hipw": "f32w", "hip3x": "3xbf16"}
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -51,7 +54,7 @@ class SelfPlayEngine:
     def __init__(self, game, n_games, net1=None, net2=None, evaluators=None, n_stores=1, max_batch=None,
                  node_cap=None, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, first_player_mode=2,
                  c_puct=cfg.C_PUCT, alpha=cfg.ALPHA, explore=cfg.EXPLORE, seed=0, uid_base=0, uid_stride=None,
-                 device="cuda:0", searches_hint=cfg.MCTS_SEARCHES, inference="hip", evict=False):
+                 device="cuda:0", searches_hint=cfg.MCTS_SEARCHES, inference="hipw", evict=False):
         if not torch.cuda.is_available():
             raise _lib.CaroError("SelfPlayEngine needs a GPU (torch.cuda.is_available() is False); "
                                  "there is no CPU fallback")
@@ -66,9 +69,9 @@ class SelfPlayEngine:
         self.max_batch = int(max_batch or cfg.MCTS_BATCH_SIZE)
         if evaluators is None:
             nets = [net1] if net2 is None or net2 is net1 else [net1, net2]
-            if inference in ("hip", "hip3x"):
+            if inference in HIP_NET_MODES:
                 from caro_ai_amd.net_hip import HipNet
-                mode = "3xbf16" if inference == "hip3x" else "f32"
+                mode = HIP_NET_MODES[inference]
                 evaluators = [HipNet(n, str(self.device), mode=mode) for n in nets]
             else:
                 evaluators = [torch_evaluator(n.to(self.device), form=inference) for n in nets]

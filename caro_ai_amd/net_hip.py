@@ -49,6 +49,37 @@ def pack_net(net: Net) -> np.ndarray:
     return out
 
 
+def _lds_image_index():
+    """index of weight (ci = 32h + j, co) inside one 4096-float tap chunk, and the matching (co, ci) lists"""
+    co = np.arange(64)[None, :, None]
+    h = np.arange(2)[:, None, None]
+    j = np.arange(32)[None, None, :]
+    idx = ((h * 64 + co) * 32 + ((((j >> 2) ^ ((co >> 1) & 7)) << 2) | (j & 3))).reshape(-1)
+    ci = np.broadcast_to(h * 32 + j, (2, 64, 32)).reshape(-1)
+    cc = np.broadcast_to(co, (2, 64, 32)).reshape(-1)
+    return idx, cc, ci
+
+
+# F(2,3) weight transform: rows p of G applied along ky
+_WINO_G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+
+
+def pack_net_w(net: Net) -> np.ndarray:
+    """float32[5 * 4 * 3 * 4096]: per residual layer the transformed taps U[p][dx] = sum_ky G[p][ky] w[:, :, ky, dx]
+    (float64 sum, rounded once), each in the LDS image order of the plain tap chunks (k_net_forward_w)."""
+    net = net.eval()
+    idx, cc, ci = _lds_image_index()
+    out = np.zeros((5, 4, 3, 4096), np.float32)
+    for li, blk in enumerate(net.residual_blocks()):
+        w, _ = _fold(blk)
+        w = w.cpu().numpy().astype(np.float64)                # [co, ci, ky, kx]
+        u = np.einsum("pk,oikx->pxoi", _WINO_G, w)            # [p, dx, co, ci]
+        for pp in range(4):
+            for dx in range(3):
+                out[li, pp, dx, idx] = u[pp, dx][cc, ci].astype(np.float32)
+    return out.reshape(-1)
+
+
 def _bf16_rne(x32: np.ndarray) -> np.ndarray:
     """float32 -> bf16 bits, round to nearest even (the rounding of k_net_forward_3x's bf16_rne)"""
     u = x32.view(np.uint32).astype(np.uint64)
@@ -88,6 +119,7 @@ def pack_net_3x(net: Net) -> np.ndarray:
 class HipNet:
     """Device-resident packed weights + the forward launch.
     mode "f32": v_mfma_f32_32x32x2_f32 (exact float32, the default).
+    mode "f32w": the same float32 MFMA arithmetic with the 3x3 convolutions in row-Winograd F(2,3) form.
     mode "3xbf16": opt-in, 3x3 convolutions on the bf16 MFMA pipe with three-way split operands."""
 
     device_counts = True  # the engine may call forward_dev without knowing L on the host
@@ -107,6 +139,9 @@ class HipNet:
         if mode == "3xbf16":
             w3 = pack_net_3x(net)
             _lib.check(self.L.caro_net_enable_3xbf16(self.h, w3.ctypes.data, w3.size))
+        elif mode == "f32w":
+            ww = pack_net_w(net)
+            _lib.check(self.L.caro_net_enable_winograd(self.h, ww.ctypes.data, ww.size))
         else:
             assert mode == "f32", mode
 

@@ -37,7 +37,7 @@ def _boards(L, shape, seed):
 @pytest.mark.parametrize("shape,A,weights", [((2, 6, 7), 7, "best_026_12000.dat"), ((2, 3, 3), 9, "best_005_00900.dat"),
                                              ((2, 15, 15), 225, None), ((2, 5, 5), 25, None), ((2, 10, 10), 100, None)])
 @pytest.mark.parametrize("L", [1, 5, 6, 7, 29, 300])
-@pytest.mark.parametrize("mode", ["f32", "3xbf16"])
+@pytest.mark.parametrize("mode", ["f32", "f32w", "3xbf16"])
 def test_hip_net_matches_torch_fp32(shape, A, weights, L, mode):
     from caro_ai_amd.net_hip import HipNet
     net = _net(shape, A, weights)
@@ -86,13 +86,14 @@ def test_hip_net_device_count_and_second_net_offset():
     hn.close()
 
 
-def test_pair_launch_equals_two_single_launches():
+@pytest.mark.parametrize("mode", ["f32", "f32w", "3xbf16"])
+def test_pair_launch_equals_two_single_launches(mode):
     """arena: one launch serving both nets gives the same bits as one launch per net"""
     from caro_ai_amd import _lib
     from caro_ai_amd.net_hip import HipNet
     L = _lib.load()
-    n0 = HipNet(_net((2, 6, 7), 7, "best_026_12000.dat"), "cuda:0")
-    n1 = HipNet(_net((2, 6, 7), 7, "best_025_10600.dat"), "cuda:0")
+    n0 = HipNet(_net((2, 6, 7), 7, "best_026_12000.dat"), "cuda:0", mode=mode)
+    n1 = HipNet(_net((2, 6, 7), 7, "best_025_10600.dat"), "cuda:0", mode=mode)
     for l0, l1 in [(13, 22), (0, 9), (6, 0), (12, 12), (1, 1)]:
         rows = l0 + l1
         x = torch.zeros((64, 2, 6, 7), device="cuda:0")

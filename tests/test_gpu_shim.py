@@ -225,7 +225,7 @@ def test_real_weights_exact_with_reference_net_arithmetic(name):
         eng.close()
 
 
-@pytest.mark.parametrize("inference", ["hip", "hip3x", "gemm"])
+@pytest.mark.parametrize("inference", ["hip", "hipw", "hip3x", "gemm"])
 def test_real_weights_gpu_net_tolerance(inference):
     """G3 with the net on the GPU (fused HIP kernel / torch GEMM form) vs the reference's CPU float32 forward.
     PUCT argmax is discontinuous: a 1e-6 difference in a prior can move one of 200 sims to another child, and

@@ -7,7 +7,9 @@ from caro_ai_amd.lib.model import Net
 from caro_ai_amd.net_hip import HipNet
 L = _lib.load()
 net = Net((2, 6, 7), 7); net.load_state_dict(torch.load("tests/golden/weights/best_026_12000.dat", map_location="cpu"))
-hn = HipNet(net, "cuda:0")
+mode = sys.argv[1] if len(sys.argv) > 1 else "f32"
+hn = HipNet(net, "cuda:0", mode=mode)
+n_mfma = 23040 if mode == "f32" else 15360
 for rows in (1434, 600):
     x = (torch.rand((rows, 2, 6, 7), device="cuda") < 0.3).float()
     counts = torch.tensor([rows, 0], dtype=torch.int32, device="cuda")
@@ -24,7 +26,7 @@ for rows in (1434, 600):
     ghz = cyc / (rt * 10.0)
     print("rows %d: workgroups %d, cycles median %.0f, wall us median %.1f, clock GHz median %.3f (min %.3f max %.3f)" % (
         rows, grid, np.median(cyc), np.median(rt) / 100.0, np.median(ghz), ghz.min(), ghz.max()))
-    print("   phases (cycles, median): zero+conv_in %.0f | trunk (45 taps + 5 epilogues) %.0f | heads+softmax %.0f" % (
+    print("   phases (cycles, median): zero+conv_in %.0f | trunk (taps + 5 epilogues) %.0f | heads+softmax %.0f" % (
         np.median(s[:, 2]), np.median(s[:, 3] - s[:, 2]), np.median(s[:, 0] - s[:, 3])))
-    print("   MFMA-bound cycles per workgroup = 23040 MFMA x 64 / 4 SIMD = 368640 -> %.1f %% of the measured cycles" % (
-        100 * 368640 / np.median(cyc)))
+    print("   MFMA-bound cycles per workgroup = %d MFMA x 64 / 4 SIMD = %d -> %.1f %% of the measured cycles" % (
+        n_mfma, n_mfma * 16, 100 * n_mfma * 16 / np.median(cyc)))
