@@ -19,6 +19,7 @@ a bounded sample, rank 0, N = 1 only.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -279,12 +280,20 @@ def main():
             achieved = leaves_per_launch * flops_per_leaf / avg_s / 1e12
             # hip3x issues 6 bf16 MFMA flops per algorithmic flop: priced against the dense bf16 peak / 6
             peak = MFMA_F32_PEAK_TFS if args.net != "hip3x" else MFMA_BF16_PEAK_TFS / 6.0
-            roofline = {"bound": "mfma", "kernel": {"hip": "k_net_forward", "hipw": "k_net_forward_w",
-                                                    "hip3x": "k_net_forward_3x"}[args.net],
+            kname = {"hip": "k_net_forward", "hipw": "k_net_forward_w", "hip3x": "k_net_forward_3x"}[args.net]
+            roofline = {"bound": "mfma", "kernel": kname,
                         "achieved": achieved, "peak": peak,
-                        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc.get("k_net_forward"),
+                        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc.get(kname),
                         "avg_launch_us": avg_s * 1e6, "launches_timed": n, "leaves_per_launch": leaves_per_launch,
                         "flops_per_leaf": flops_per_leaf}
+            if args.net == "hipw":
+                # the Winograd form issues 2/3 of the 3x3-conv multiplies: what the MFMA pipe itself executes
+                # (60 taps x 32 MFMAs x 8 waves x 4096 flop per workgroup of TB boards, padding included)
+                tb = hipnet.L.caro_net_boards_per_workgroup(hipnet.h)
+                issued = math.ceil(leaves_per_launch / tb) * 60 * 32 * 8 * 4096.0 / avg_s / 1e12
+                roofline["note"] = ("achieved = algorithmic (direct-convolution) flops per launch / launch time; "
+                                    "mfma_issued = flops the MFMA pipe executes in the F(2,3) form")
+                roofline["mfma_issued"] = {"achieved": issued, "frac": issued / peak}
         if roofline is None:  # torch evaluators: the net is not our kernel; the tree walk is the dominant own kernel
             roofline = roofline_tree
         out = {

@@ -118,13 +118,13 @@ def pack_net_3x(net: Net) -> np.ndarray:
 
 class HipNet:
     """Device-resident packed weights + the forward launch.
-    mode "f32": v_mfma_f32_32x32x2_f32 (exact float32, the default).
-    mode "f32w": the same float32 MFMA arithmetic with the 3x3 convolutions in row-Winograd F(2,3) form.
+    mode "f32w" (default): float32 on v_mfma_f32_32x32x2_f32, the 3x3 convolutions in row-Winograd F(2,3) form.
+    mode "f32": the same with direct 3x3 convolutions (a plain fma chain in k order).
     mode "3xbf16": opt-in, 3x3 convolutions on the bf16 MFMA pipe with three-way split operands."""
 
     device_counts = True  # the engine may call forward_dev without knowing L on the host
 
-    def __init__(self, net: Net, device="cuda:0", negative_slope=0.01, mode="f32"):
+    def __init__(self, net: Net, device="cuda:0", negative_slope=0.01, mode="f32w"):
         self.L = _lib.load()
         self.device = torch.device(device)
         self.H, self.W = net.input_shape[1], net.input_shape[2]

@@ -15,7 +15,9 @@ import os
 import sys
 from collections import defaultdict
 
-SHORT = {"k_select": "k_select", "k_net_forward": "k_net_forward", "k_expand_backup": "k_expand_backup",
+# longest names first: the first key found in the (mangled) kernel name wins
+SHORT = {"k_net_forward_w": "k_net_forward_w", "k_net_forward_3x": "k_net_forward_3x", "k_select": "k_select",
+         "k_net_forward": "k_net_forward", "k_expand_backup": "k_expand_backup",
          "k_encode": "k_encode", "k_scan": "k_scan", "k_step": "k_step", "k_drain_copy": "k_drain_copy"}
 
 
@@ -28,6 +30,7 @@ def collect(dirname, counter):
             for key, short in SHORT.items():
                 if key in r["Kernel_Name"]:
                     acc[short].append(float(r["Counter_Value"]))
+                    break
     return acc
 
 
