@@ -262,7 +262,7 @@ def main():
         roofline = roofline_tree = None
         if prof is not None and prof["select"][1] > 0:
             ms, n = prof["select"]
-            avg_s = ms * 1e-3 / n               # timed on a sample of the launches (every 8th minibatch)
+            avg_s = ms * 1e-3 / n               # timed on a sample of the launches (every 12th minibatch, all minibatch indices equally)
             n_launches = args.steps * S * n_streams
             levels_per_launch = delta["levels"] / n_launches
             achieved = levels_per_launch * bytes_per_level / avg_s / 1e9

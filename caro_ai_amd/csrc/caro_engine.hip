@@ -1258,6 +1258,7 @@ struct caro_engine {
   // optional HIP-event timing of the hot kernels (bench.py's live roofline)
   int prof_on;
   int prof_gate;  // 0: skip event records for this launch (sampling inside caro_search_batch)
+  uint64_t prof_ctr;  // minibatches enqueued by caro_search_batch since the engine was created
   std::vector<hipEvent_t> ev;      // pairs: [2*i] start, [2*i+1] stop
   std::vector<int> ev_kind;        // kernel id of pair i
   size_t ev_used;
@@ -1444,6 +1445,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   h->select_pending = 0;
   h->prof_on = 0;
   h->prof_gate = 1;
+  h->prof_ctr = 0;
   h->ev_used = 0;
   for (int i = 0; i < 8; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
   View& v = h->v;
@@ -1586,8 +1588,10 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
   const int64_t max_rows = (int64_t)h->v.G * batch;
   const size_t noise_stride = (size_t)h->v.G * batch * h->v.A;
   for (int mb = 0; mb < searches; ++mb) {
-    // HIP-event timing is SAMPLED (every 8th minibatch): an event pair per kernel costs ~8 % of the step
-    h->prof_gate = (mb & 7) == 0;
+    // HIP-event timing is SAMPLED: an event pair per kernel costs ~8 % of the step.  Every 12th minibatch of a
+    // counter that runs across moves: 12 is coprime to the usual 25 / 20 / 100 searches per move, so every
+    // minibatch index (the first ones after a move carry more leaves) is sampled equally often.
+    h->prof_gate = (h->prof_ctr++ % 12) == 0;
     int rc = caro_select(h, batch, mb, noise ? noise + (size_t)mb * noise_stride : nullptr, planes, leaf_keys, stream);
     if (rc) { h->prof_gate = 1; return rc; }
     const int p0 = prof_begin(h, PK_NET, (hipStream_t)stream);
