@@ -134,6 +134,8 @@ def main():
                     help="split the games of a GPU over this many engines on separate HIP streams (tree kernels of "
                          "one part overlap the net kernel of another)")
     ap.add_argument("--stream-mask", type=int, default=1, help="with --streams > 1: confine each part to its own CU slice")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N > 1: all-gather the finished games' tuples every this many moves (one payload message)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="host cores for the CPU baseline (0 = all, capped at 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -199,24 +201,27 @@ def main():
                              seed=0, device=str(device), searches_hint=S, **extra, **parallel.shard(G, rank, world))
 
     n_tuples = 0
+    # N > 1: tuples wait on the device and are all-gathered every 8th move (and at the end of the timed region)
+    gatherer = parallel.TupleGatherer(every=args.gather_every)
+
+    def count(d):
+        nonlocal n_tuples
+        if d is not None:
+            n_tuples += int(d["z"].shape[0])
 
     def one_step():
-        nonlocal n_tuples
         if n_streams > 1:
             d = eng.move(S, B)      # host-pipelined over the parts: drains the previous move of each part
-            if d is None:
-                return
         else:
             eng.search(S, B)
             eng.step()
             d = eng.drain(recycle=True)
-        if world > 1:
-            d = parallel.gather_tuples(d)
-        n_tuples += int(d["z"].shape[0])
+        count(gatherer.push(d))
 
     def barrier():
         if n_streams > 1:
-            eng.flush()             # the last enqueued move of every part belongs to the timed region
+            count(gatherer.push(eng.flush()))  # the last enqueued move of every part belongs to the timed region
+        count(gatherer.flush())
         torch.cuda.synchronize(device)
         if world > 1:
             torch.distributed.barrier()
@@ -312,7 +317,7 @@ def main():
                                       S, B, S * B, sbt0),
                        "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py Net, %s fp32" % {"hip": "fused HIP MFMA kernel", "hipw": "fused HIP MFMA kernel, 3x3 convs in row-Winograd F(2,3) form,", "hip3x": "fused HIP kernel, 3x3 convs as 3-way split bf16 MFMA with f32 accumulate,", "gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net],
                        "streams_per_gpu": n_streams,
-                       "parallelism": "games sharded x%d, all-gather of tuples per step" % world},
+                       "parallelism": "games sharded x%d, tuples all-gathered every %d moves" % (world, args.gather_every)},
             "per_gpu": exp_all / dt_max / world,
             "sims_per_s": sims_all / dt_max, "plies_per_s": plies_all / dt_max, "games_per_s": fin_all / dt_max,
             "net_rows_per_s": rows_all / dt_max, "mean_depth": levels_all / max(1.0, sims_all),

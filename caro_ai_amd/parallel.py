@@ -7,9 +7,13 @@ Exchanges (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box,
 "gloo" in the CPU tests):
   gather_tuples      variable-length all-gather of (state, player, pi, z) replay
                      tuples: one int64 count all-gather + one padded
-                     all_gather_into_tensor per field group.  Messages are
-                     KB..MB, i.e. latency bound, so one flat all-gather per
-                     drain and no ring/bucketing.
+                     all_gather_into_tensor per field group.
+  TupleGatherer      the same exchange batched over several moves: messages are
+                     KB..MB, i.e. latency bound (xGMI ring all-gather of a few
+                     hundred KB ~ tens of us plus launch and host overhead), and a
+                     move lasts ~6 ms, so tuples wait on the device and every
+                     `every`-th move ONE count all-gather and ONE byte-packed payload
+                     all-gather move them all.
   broadcast_weights  state_dict broadcast from rank 0 after a training step.
   allreduce_sum      arena W/L/D counters, expansion counters.
 """
@@ -119,6 +123,80 @@ def gather_tuples(tuples, pi_dtype=torch.float32):
     all_i, all_f = all_i[keep], all_f[keep]
     return {"states": all_i[:, :KW].contiguous().to(out_dev), "players": all_i[:, KW].to(torch.int32).to(out_dev),
             "pi": all_f.to(out_dev), "z": all_i[:, KW + 1].to(torch.int32).to(out_dev)}
+
+
+class TupleGatherer:
+    """Collects the drains of several moves on the device and exchanges them in one go.
+
+        tg = TupleGatherer(every=8)
+        for each move:  out = tg.push(engine.drain())     # None, or every rank's rows since the last exchange
+        out = tg.flush()                                  # at the end (collective: every rank calls it)
+
+    Rows come back rank-major, each rank's rows in the order they were pushed (deterministic).
+    One record = [KW int64 states | int32 player | int32 z | A float32 pi] as bytes, so the payload is a
+    single all_gather_into_tensor whatever the field types."""
+
+    FIELDS = ("states", "players", "pi", "z")
+
+    def __init__(self, every=8, pi_dtype=torch.float32):
+        self.every = max(1, int(every))
+        self.pi_dtype = pi_dtype
+        self.pending = []
+        self.moves = 0
+
+    def push(self, tuples):
+        if tuples is not None and int(tuples["z"].shape[0]) > 0:
+            self.pending.append({k: tuples[k] for k in self.FIELDS})
+        self.moves += 1
+        return self.flush() if self.moves % self.every == 0 else None
+
+    def _local(self):
+        if not self.pending:
+            return None
+        out = {"states": torch.cat([d["states"] for d in self.pending]),
+               "players": torch.cat([d["players"] for d in self.pending]).to(torch.int32),
+               "pi": torch.cat([d["pi"] for d in self.pending]).to(self.pi_dtype),
+               "z": torch.cat([d["z"] for d in self.pending]).to(torch.int32)}
+        self.pending = []
+        return out
+
+    def flush(self):
+        mine = self._local()
+        if not is_dist():
+            return mine
+        world = dist.get_world_size()
+        # shapes must be known on every rank, with or without local rows: agree on them through the count message
+        n = 0 if mine is None else int(mine["z"].shape[0])
+        KW = 0 if mine is None else int(mine["states"].shape[1])
+        A = 0 if mine is None else int(mine["pi"].shape[1])
+        dev = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device())
+        out_dev = dev if mine is None else mine["z"].device
+        head = torch.tensor([n, KW, A], dtype=torch.int64, device=dev)
+        heads = torch.zeros(world * 3, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(heads, head)
+        heads_h = heads.cpu().reshape(world, 3)
+        counts = heads_h[:, 0].tolist()
+        m = max(counts)
+        if m == 0:
+            return None
+        KW, A = int(heads_h[:, 1].max()), int(heads_h[:, 2].max())
+        isz = torch.empty((), dtype=self.pi_dtype).element_size()
+        rec = 8 * KW + 8 + isz * A
+        buf = torch.zeros((m, rec), dtype=torch.uint8, device=dev)
+        if n:
+            buf[:n, :8 * KW] = mine["states"].contiguous().to(dev).view(torch.uint8).reshape(n, 8 * KW)
+            buf[:n, 8 * KW:8 * KW + 4] = mine["players"].contiguous().to(dev).view(torch.uint8).reshape(n, 4)
+            buf[:n, 8 * KW + 4:8 * KW + 8] = mine["z"].contiguous().to(dev).view(torch.uint8).reshape(n, 4)
+            buf[:n, 8 * KW + 8:] = mine["pi"].contiguous().to(dev).view(torch.uint8).reshape(n, isz * A)
+        allb = torch.empty((world * m, rec), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(allb, buf)
+        keep = torch.cat([torch.arange(r * m, r * m + c, device=dev) for r, c in enumerate(counts)])
+        allb = allb[keep]
+        tot = allb.shape[0]
+        return {"states": allb[:, :8 * KW].contiguous().view(torch.int64).reshape(tot, KW).to(out_dev),
+                "players": allb[:, 8 * KW:8 * KW + 4].contiguous().view(torch.int32).reshape(tot).to(out_dev),
+                "z": allb[:, 8 * KW + 4:8 * KW + 8].contiguous().view(torch.int32).reshape(tot).to(out_dev),
+                "pi": allb[:, 8 * KW + 8:].contiguous().view(self.pi_dtype).reshape(tot, A).to(out_dev)}
 
 
 def broadcast_weights(net, src=0):

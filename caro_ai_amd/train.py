@@ -130,6 +130,9 @@ def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_ba
                          device=device, searches_hint=searches, uid_base=uid_base + rank * G, uid_stride=world * G)
     t0 = time.time()
     finished = steps = 0
+    # multi-GPU: every rank plays the same number of moves (the loop below is driven by rank-local counts, so the
+    # exchange is batched and flushed once at the end, when every rank has left the loop)
+    gatherer = parallel.TupleGatherer(every=1 << 30, pi_dtype=torch.float32)
     while finished < n_games:
         eng.search(searches, batch)
         eng.step()
@@ -138,11 +141,12 @@ def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_ba
         if ng:
             finished += ng
             steps += int(d["games"][:, 3].sum().item())
-            if parallel.is_dist():
-                d = parallel.gather_tuples(d, pi_dtype=torch.float32)
-            replay_buffer.extend(d)
+            gatherer.push(d)
         elif eng.live_games() == 0:
             break
+    out = gatherer.flush()
+    if out is not None:
+        replay_buffer.extend(out)
     c = eng.counters()
     dt = time.time() - t0
     eng.close()

@@ -44,6 +44,17 @@ def _worker(rank, world, port, counts, q):
         mine = _fake_tuples(rank * 10 + rnd, cnt[rank])
         allt = parallel.gather_tuples(mine)
         out["gather%d" % rnd] = {k: v.numpy() for k, v in allt.items()}
+    # 2b. the batched exchange: pushes of several moves, one collective every 2nd move and at the end
+    tg = parallel.TupleGatherer(every=2)
+    got = []
+    for rnd, cnt in enumerate(counts):
+        r_ = tg.push(_fake_tuples(rank * 10 + rnd, cnt[rank]))
+        if r_ is not None:
+            got.append({k: v.numpy() for k, v in r_.items()})
+    r_ = tg.flush()
+    if r_ is not None:
+        got.append({k: v.numpy() for k, v in r_.items()})
+    out["batched"] = got
     # 3. weight broadcast
     from caro_ai_amd.lib.model import Net
     torch.manual_seed(rank)
@@ -83,6 +94,20 @@ def test_two_rank_gloo():
             np.testing.assert_array_equal(got["players"], torch.cat([e["players"] for e in exp]).numpy())
             np.testing.assert_array_equal(got["z"], torch.cat([e["z"] for e in exp]).numpy())
             np.testing.assert_array_equal(got["pi"], torch.cat([e["pi"] for e in exp]).float().numpy())
+    # batched exchange: moves 0+1 in one message, move 2 (empty everywhere) gives nothing
+    for rank in range(world):
+        got = res[rank]["batched"]
+        assert len(got) == 1
+        exp = [torch.cat([_fake_tuples(r * 10 + rnd, counts[rnd][r])[k] for rnd in (0, 1)]) for r in range(world)
+               for k in ("states",)]
+        np.testing.assert_array_equal(got[0]["states"], torch.cat(exp).numpy())
+        for k in ("players", "z"):
+            e = torch.cat([torch.cat([_fake_tuples(r * 10 + rnd, counts[rnd][r])[k] for rnd in (0, 1)])
+                           for r in range(world)])
+            np.testing.assert_array_equal(got[0][k], e.numpy())
+        e = torch.cat([torch.cat([_fake_tuples(r * 10 + rnd, counts[rnd][r])["pi"] for rnd in (0, 1)])
+                       for r in range(world)]).float()
+        np.testing.assert_array_equal(got[0]["pi"], e.numpy())
     assert res[0]["wsum"] == res[1]["wsum"]
     assert res[0]["sum"] == res[1]["sum"] == [3, 30, 6]
     assert res[0]["max"] == [2, 20, 3]
@@ -94,5 +119,9 @@ def test_single_process_paths_are_noops():
     t = _fake_tuples(0, 4)
     out = parallel.gather_tuples(t)
     assert out["pi"].dtype == torch.float32 and out["z"].shape[0] == 4
+    tg = parallel.TupleGatherer(every=3)
+    assert tg.push(_fake_tuples(1, 2)) is None and tg.push(_fake_tuples(2, 0)) is None
+    both = tg.push(_fake_tuples(3, 5))
+    assert both["z"].shape[0] == 7 and both["pi"].dtype == torch.float32 and tg.flush() is None
     assert parallel.shard(1024, 0, 1) == {"uid_base": 0, "uid_stride": 1024}
     assert parallel.allreduce_sum(torch.tensor([5])).item() == 5
