@@ -271,8 +271,12 @@ def main():
             n_launches = args.steps * S * n_streams
             levels_per_launch = delta["levels"] / n_launches
             achieved = levels_per_launch * bytes_per_level / avg_s / 1e9
-            roofline_tree = {"bound": "hbm", "kernel": "k_select", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("k_select"),
+            # one net + one wavefront per game: caro_search_batch runs the fused k_tree (expand+backup of the
+            # previous minibatch, select, row reservation + planes); otherwise k_select / k_encode / k_expand_backup
+            fused = prof.get("compact", (0, 0))[1] == 0
+            tname = "k_tree" if fused else "k_select"
+            roofline_tree = {"bound": "hbm", "kernel": tname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(tname),
                              "avg_launch_us": avg_s * 1e6, "launches": n_launches, "launches_timed": n,
                              "levels_per_launch": levels_per_launch, "bytes_per_level": bytes_per_level,
                              "other_kernels_us": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in prof.items()

@@ -208,8 +208,14 @@ __device__ __forceinline__ void noise_group(uint64_t key, int l, int A, double a
 }
 
 // ------------------------------------------------------------------ select
+// `rows` (fused form, see k_tree): when non-null the block also places its unique leaves itself -- it reserves
+// rows [off, off + nleaf) with one atomicAdd on rows[0] and writes their NN planes (what k_encode does after a
+// grid-wide count in the step-wise form).  Which rows a game gets then depends on arrival order, the value
+// computed for a leaf does not (every row of the net kernel is independent of the others).
 template <class GEO>
-__global__ void k_select(View v, int B, int mb_index, const double* __restrict__ noise) {
+__device__ __forceinline__ void select_body(const View& v, int B, int mb_index, const double* __restrict__ noise,
+                                            int32_t* __restrict__ rows, float* __restrict__ planes,
+                                            uint64_t* __restrict__ leaf_keys) {
   using R = typename GEO::R;
   using Board = typename R::Board;
   constexpr int LPD = GEO::LPD, APL = GEO::APL, AP = GEO::AP, KW = GEO::KW;
@@ -221,6 +227,8 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
   __shared__ int s_status[MAXB];
   __shared__ int s_first[MAXB];
   __shared__ int s_depth[MAXB];
+  __shared__ int s_player[MAXB];
+  __shared__ int s_off;
 
   if (v.done[g]) {
     if (tid == 0) {
@@ -382,6 +390,7 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
     for (int w = 0; w < KW; ++w) s_key[b][w] = cur.w[w];
     s_status[b] = status;
     s_depth[b] = depth;
+    s_player[b] = player;
   }
   __syncthreads();
   // planned-set de-duplication (mcts.py:272-278): first occurrence of a new leaf is kept
@@ -436,7 +445,33 @@ __global__ void k_select(View v, int B, int mb_index, const double* __restrict__
     ctr[C_LEVELS] += (unsigned long long)levels;
     ctr[C_TERMINALS] += (unsigned long long)term;
     ctr[C_DROPPED] += (unsigned long long)drop;
+    if (rows) {
+      const int off = nleaf ? atomicAdd(rows, nleaf) : 0;
+      v.g_off[g] = off;
+      s_off = off;
+    }
   }
+  if (rows) {
+    __syncthreads();
+    const int HW = v.HW;
+    int local = 0;
+    for (int bb = 0; bb < B; ++bb) {
+      if (!s_first[bb]) continue;
+      const int rowi = s_off + local++;
+      Board brd;
+#pragma unroll
+      for (int w = 0; w < KW; ++w) brd.w[w] = s_key[bb][w];
+      const int who = s_player[bb];
+      float* dst = planes + (size_t)rowi * 2 * HW;
+      for (int i = tid; i < 2 * HW; i += blockDim.x) dst[i] = R::plane(v.gp, brd, who, i / HW, i % HW);
+      if (leaf_keys && tid < KW) leaf_keys[(size_t)rowi * KW + tid] = brd.w[tid];
+    }
+  }
+}
+
+template <class GEO>
+__global__ void k_select(View v, int B, int mb_index, const double* __restrict__ noise) {
+  select_body<GEO>(v, B, mb_index, noise, nullptr, nullptr, nullptr);
 }
 
 // NN planes of the unique leaves, written as dense rows (rows of net 0 first, then net 1).  Every block
@@ -514,7 +549,8 @@ __device__ __forceinline__ void backup_path(const View& v, int t, float value, b
 // seen; inside a path from the leaf upwards), the first entry of every distinct edge becomes its owner and
 // applies all entries of that edge in order, and the owners' read-modify-writes proceed in parallel.
 template <class GEO>
-__global__ void k_expand_backup(View v, const float* __restrict__ probs, const float* __restrict__ values) {
+__device__ __forceinline__ void expand_body(const View& v, int B, const float* __restrict__ probs,
+                                            const float* __restrict__ values) {
   using R = typename GEO::R;
   constexpr int AP = GEO::AP, KW = GEO::KW;
   constexpr int MAXE = 512;  // entries held in LDS; longer queues fall back to the sequential form
@@ -525,7 +561,6 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
   __shared__ int s_total;
   const int g = blockIdx.x;
   if (v.done[g]) return;
-  const int B = v.leaf_count[2];
   const int lane = threadIdx.x;
   const int t = v.g_tree[g];
   const int nleaf = v.g_nleaf[g];
@@ -649,6 +684,33 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
     row[AP + a] = __float_as_uint(w);
     row[2 * AP + a] = __float_as_uint(w / (float)cnt);  // value_avg = value / visit_count
   }
+}
+
+template <class GEO>
+__global__ void k_expand_backup(View v, const float* __restrict__ probs, const float* __restrict__ values) {
+  expand_body<GEO>(v, v.leaf_count[2], probs, values);
+}
+
+// Fused form used by caro_search_batch (one net, one 64-lane wavefront per game): expand + backup of the previous
+// minibatch, then the descents of the next one on the updated tree, then row reservation + NN planes -- all
+// per-game work, so one block does it back to back and a minibatch costs two launches (this + the net) instead
+// of four.  rows_cur[0] counts the leaves of this minibatch (the net kernel reads it), rows_next is cleared for
+// the launch after this one.
+template <class GEO>
+__global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ noise, const float* __restrict__ probs,
+                       const float* __restrict__ values, float* __restrict__ planes, uint64_t* __restrict__ leaf_keys,
+                       int32_t* __restrict__ rows_cur, int32_t* __restrict__ rows_next, int do_expand, int do_select) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    rows_next[0] = 0;
+    rows_next[1] = 0;
+    rows_next[2] = B;
+    rows_cur[2] = B;
+  }
+  if (do_expand) {
+    expand_body<GEO>(v, B, probs, values);
+    __syncthreads();  // the block's own tree updates are visible to its descents
+  }
+  if (do_select) select_body<GEO>(v, B, mb_index, noise, rows_cur, planes, leaf_keys);
 }
 
 // ------------------------------------------------------------------ policy / step
@@ -1259,6 +1321,9 @@ struct caro_engine {
   int prof_on;
   int prof_gate;  // 0: skip event records for this launch (sampling inside caro_search_batch)
   uint64_t prof_ctr;  // minibatches enqueued by caro_search_batch since the engine was created
+  int32_t* rows;      // [2][4] leaf counters of the fused tree kernel (ping-pong)
+  int rows_par;
+  int fused_ok;       // CARO_NO_FUSED_TREE=1 in the environment selects the four-launch form (A/B measurements)
   std::vector<hipEvent_t> ev;      // pairs: [2*i] start, [2*i+1] stop
   std::vector<int> ev_kind;        // kernel id of pair i
   size_t ev_used;
@@ -1446,6 +1511,12 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   h->prof_on = 0;
   h->prof_gate = 1;
   h->prof_ctr = 0;
+  h->rows = nullptr;
+  h->rows_par = 0;
+  {
+    const char* e = getenv("CARO_NO_FUSED_TREE");
+    h->fused_ok = !(e && e[0] == '1');
+  }
   h->ev_used = 0;
   for (int i = 0; i < 8; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
   View& v = h->v;
@@ -1499,9 +1570,11 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   DA(v.dr_off, G); DA(v.dr_gidx, G); DA(v.dr_sel, G); DA(v.dr_tot, 2);
   DA(h->scratch, (size_t)v.maxd + 8);
   DA(h->live, 1);
+  DA(h->rows, 8);
 #undef DA
   HIPCHK(hipMemset(v.counters, 0, sizeof(unsigned long long) * C_N * G));
   HIPCHK(hipMemset(v.leaf_count, 0, sizeof(int32_t) * 4));
+  HIPCHK(hipMemset(h->rows, 0, sizeof(int32_t) * 8));
   HIPCHK(hipMemset(v.g_nleaf, 0, sizeof(int32_t) * G));
   HIPCHK(hipHostMalloc((void**)&h->pinned, 64, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&h->pinned64, 128, hipHostMallocDefault));
@@ -1587,19 +1660,49 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
   if (searches < 1) return fail(CARO_E_INVAL, "searches must be >= 1");
   const int64_t max_rows = (int64_t)h->v.G * batch;
   const size_t noise_stride = (size_t)h->v.G * batch * h->v.A;
+  if (batch < 1 || batch > h->v.maxB) return fail(CARO_E_INVAL, "batch exceeds max_batch of the engine");
+  if (h->select_pending) return fail(CARO_E_STATE, "caro_search_batch with a pending caro_select");
+  hipStream_t st = (hipStream_t)stream;
+  // one net and one 64-lane wavefront per game: the fused tree kernel (k_tree), two launches per minibatch
+  const bool fused = h->fused_ok && h->v.n_nets == 1 && batch * variant_lpd(h->var) == 64;
   for (int mb = 0; mb < searches; ++mb) {
     // HIP-event timing is SAMPLED: an event pair per kernel costs ~8 % of the step.  Every 12th minibatch of a
     // counter that runs across moves: 12 is coprime to the usual 25 / 20 / 100 searches per move, so every
     // minibatch index (the first ones after a move carry more leaves) is sampled equally often.
     h->prof_gate = (h->prof_ctr++ % 12) == 0;
-    int rc = caro_select(h, batch, mb, noise ? noise + (size_t)mb * noise_stride : nullptr, planes, leaf_keys, stream);
+    int rc = 0;
+    const int32_t* counts = h->v.leaf_count;
+    if (fused) {
+      int32_t* cur = h->rows + 4 * h->rows_par;
+      int32_t* nxt = h->rows + 4 * (h->rows_par ^ 1);
+      h->rows_par ^= 1;
+      counts = cur;
+      const int p1 = prof_begin(h, PK_SELECT, st);
+      DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(64), 0, st, h->v, batch, mb,
+                                          noise ? noise + (size_t)mb * noise_stride : nullptr, probs, values, planes,
+                                          leaf_keys, cur, nxt, mb > 0 ? 1 : 0, 1));
+      prof_end(h, p1, st);
+      if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree launch failed"); }
+    } else {
+      rc = caro_select(h, batch, mb, noise ? noise + (size_t)mb * noise_stride : nullptr, planes, leaf_keys, stream);
+      if (rc) { h->prof_gate = 1; return rc; }
+    }
+    const int p0 = prof_begin(h, PK_NET, st);
+    if (h->v.n_nets == 2) rc = caro_net_forward_pair(net0, net1, planes, counts, max_rows, probs, values, stream);
+    else rc = caro_net_forward(net0, planes, counts, 0, max_rows, probs, values, stream);
+    prof_end(h, p0, st);
+    if (!rc && !fused) rc = caro_expand_backup(h, probs, values, stream);
     if (rc) { h->prof_gate = 1; return rc; }
-    const int p0 = prof_begin(h, PK_NET, (hipStream_t)stream);
-    if (h->v.n_nets == 2) rc = caro_net_forward_pair(net0, net1, planes, h->v.leaf_count, max_rows, probs, values, stream);
-    else rc = caro_net_forward(net0, planes, h->v.leaf_count, 0, max_rows, probs, values, stream);
-    prof_end(h, p0, (hipStream_t)stream);
-    if (!rc) rc = caro_expand_backup(h, probs, values, stream);
-    if (rc) { h->prof_gate = 1; return rc; }
+  }
+  if (fused) {  // expand + backup of the last minibatch
+    int32_t* cur = h->rows + 4 * h->rows_par;
+    int32_t* nxt = h->rows + 4 * (h->rows_par ^ 1);
+    h->rows_par ^= 1;
+    const int p1 = prof_begin(h, PK_EXPAND, st);
+    DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(64), 0, st, h->v, batch, searches,
+                                        (const double*)nullptr, probs, values, planes, leaf_keys, cur, nxt, 1, 0));
+    prof_end(h, p1, st);
+    if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree launch failed"); }
   }
   h->prof_gate = 1;
   return 0;
