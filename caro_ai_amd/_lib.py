@@ -68,6 +68,7 @@ _SIGNATURES = {
     "caro_stream_destroy": (C.c_int, [_P]),
     "caro_search_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "caro_net_forward_pair": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "caro_net_forward_pair_at": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P]),
     "caro_net_forward_stamped": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P]),
     "caro_get_descent": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "caro_select_cancel": (C.c_int, [_P]),

@@ -214,7 +214,7 @@ __device__ __forceinline__ void noise_group(uint64_t key, int l, int A, double a
 // computed for a leaf does not (every row of the net kernel is independent of the others).
 template <class GEO>
 __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, const double* __restrict__ noise,
-                                            int32_t* __restrict__ rows, float* __restrict__ planes,
+                                            int32_t* __restrict__ rows, int row1_base, float* __restrict__ planes,
                                             uint64_t* __restrict__ leaf_keys) {
   using R = typename GEO::R;
   using Board = typename R::Board;
@@ -445,8 +445,9 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
     ctr[C_LEVELS] += (unsigned long long)levels;
     ctr[C_TERMINALS] += (unsigned long long)term;
     ctr[C_DROPPED] += (unsigned long long)drop;
-    if (rows) {
-      const int off = nleaf ? atomicAdd(rows, nleaf) : 0;
+    if (rows) {  // two nets: the second net's rows live at row1_base + (index inside its class)
+      const int cls = v.n_nets == 2 ? player0 : 0;
+      const int off = (nleaf ? atomicAdd(rows + cls, nleaf) : 0) + (cls ? row1_base : 0);
       v.g_off[g] = off;
       s_off = off;
     }
@@ -471,7 +472,7 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
 
 template <class GEO>
 __global__ void k_select(View v, int B, int mb_index, const double* __restrict__ noise) {
-  select_body<GEO>(v, B, mb_index, noise, nullptr, nullptr, nullptr);
+  select_body<GEO>(v, B, mb_index, noise, nullptr, 0, nullptr, nullptr);
 }
 
 // NN planes of the unique leaves, written as dense rows (rows of net 0 first, then net 1).  Every block
@@ -691,15 +692,16 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
   expand_body<GEO>(v, v.leaf_count[2], probs, values);
 }
 
-// Fused form used by caro_search_batch (one net, one 64-lane wavefront per game): expand + backup of the previous
+// Fused form used by caro_search_batch (one 64-lane wavefront per game): expand + backup of the previous
 // minibatch, then the descents of the next one on the updated tree, then row reservation + NN planes -- all
 // per-game work, so one block does it back to back and a minibatch costs two launches (this + the net) instead
-// of four.  rows_cur[0] counts the leaves of this minibatch (the net kernel reads it), rows_next is cleared for
-// the launch after this one.
+// of four.  rows_cur[0 / 1] count the leaves of this minibatch per net (the net kernel reads them), rows_next is
+// cleared for the launch after this one.
 template <class GEO>
 __global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ noise, const float* __restrict__ probs,
                        const float* __restrict__ values, float* __restrict__ planes, uint64_t* __restrict__ leaf_keys,
-                       int32_t* __restrict__ rows_cur, int32_t* __restrict__ rows_next, int do_expand, int do_select) {
+                       int32_t* __restrict__ rows_cur, int32_t* __restrict__ rows_next, int row1_base, int do_expand,
+                       int do_select) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     rows_next[0] = 0;
     rows_next[1] = 0;
@@ -710,7 +712,7 @@ __global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ n
     expand_body<GEO>(v, B, probs, values);
     __syncthreads();  // the block's own tree updates are visible to its descents
   }
-  if (do_select) select_body<GEO>(v, B, mb_index, noise, rows_cur, planes, leaf_keys);
+  if (do_select) select_body<GEO>(v, B, mb_index, noise, rows_cur, row1_base, planes, leaf_keys);
 }
 
 // ------------------------------------------------------------------ policy / step
@@ -1663,8 +1665,9 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
   if (batch < 1 || batch > h->v.maxB) return fail(CARO_E_INVAL, "batch exceeds max_batch of the engine");
   if (h->select_pending) return fail(CARO_E_STATE, "caro_search_batch with a pending caro_select");
   hipStream_t st = (hipStream_t)stream;
-  // one net and one 64-lane wavefront per game: the fused tree kernel (k_tree), two launches per minibatch
-  const bool fused = h->fused_ok && h->v.n_nets == 1 && batch * variant_lpd(h->var) == 64;
+  // one 64-lane wavefront per game: the fused tree kernel (k_tree), two launches per minibatch
+  const bool fused = h->fused_ok && batch * variant_lpd(h->var) == 64;
+  const int row1_base = (int)max_rows;  // fused form, two nets: net 1's rows start here (buffers hold 2 * max_rows rows)
   for (int mb = 0; mb < searches; ++mb) {
     // HIP-event timing is SAMPLED: an event pair per kernel costs ~8 % of the step.  Every 12th minibatch of a
     // counter that runs across moves: 12 is coprime to the usual 25 / 20 / 100 searches per move, so every
@@ -1680,7 +1683,7 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
       const int p1 = prof_begin(h, PK_SELECT, st);
       DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(64), 0, st, h->v, batch, mb,
                                           noise ? noise + (size_t)mb * noise_stride : nullptr, probs, values, planes,
-                                          leaf_keys, cur, nxt, mb > 0 ? 1 : 0, 1));
+                                          leaf_keys, cur, nxt, row1_base, mb > 0 ? 1 : 0, 1));
       prof_end(h, p1, st);
       if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree launch failed"); }
     } else {
@@ -1688,7 +1691,8 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
       if (rc) { h->prof_gate = 1; return rc; }
     }
     const int p0 = prof_begin(h, PK_NET, st);
-    if (h->v.n_nets == 2) rc = caro_net_forward_pair(net0, net1, planes, counts, max_rows, probs, values, stream);
+    if (h->v.n_nets == 2)
+      rc = caro_net_forward_pair_at(net0, net1, planes, counts, fused ? row1_base : -1, max_rows, probs, values, stream);
     else rc = caro_net_forward(net0, planes, counts, 0, max_rows, probs, values, stream);
     prof_end(h, p0, st);
     if (!rc && !fused) rc = caro_expand_backup(h, probs, values, stream);
@@ -1700,7 +1704,7 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
     h->rows_par ^= 1;
     const int p1 = prof_begin(h, PK_EXPAND, st);
     DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(64), 0, st, h->v, batch, searches,
-                                        (const double*)nullptr, probs, values, planes, leaf_keys, cur, nxt, 1, 0));
+                                        (const double*)nullptr, probs, values, planes, leaf_keys, cur, nxt, row1_base, 1, 0));
     prof_end(h, p1, st);
     if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree launch failed"); }
   }

@@ -192,7 +192,7 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
 // `which` = 0 / 1: rows of that net only (p0 is used).  `which` = 2: both nets in ONE launch -- tiles
 // [0, ceil(L0/TB)) run net 0 on rows [0, L0), the following tiles run net 1 (p1) on rows [L0, L0+L1).
 __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p1, const float* __restrict__ planes,
-                                                         const int32_t* __restrict__ counts, int which,
+                                                         const int32_t* __restrict__ counts, int which, int row1,
                                                          float* __restrict__ probs, float* __restrict__ values,
                                                          unsigned long long* __restrict__ stamps) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
     const int t0 = (L0 + p0.TB - 1) / p0.TB;
     second = (int)blockIdx.x >= t0;
     L = second ? counts[1] : L0;
-    row0 = second ? L0 : 0;
+    row0 = second ? (row1 >= 0 ? row1 : L0) : 0;
     board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
   }
   if (board0 >= L) return;
@@ -388,7 +388,7 @@ constexpr int WNCHUNK = WTAPS / TPC;      // 20
 
 __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams p1,
                                                            const float* __restrict__ planes,
-                                                           const int32_t* __restrict__ counts, int which,
+                                                           const int32_t* __restrict__ counts, int which, int row1,
                                                            float* __restrict__ probs, float* __restrict__ values,
                                                            unsigned long long* __restrict__ stamps) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
     const int t0 = (L0 + p0.TB - 1) / p0.TB;
     second = (int)blockIdx.x >= t0;
     L = second ? counts[1] : L0;
-    row0 = second ? L0 : 0;
+    row0 = second ? (row1 >= 0 ? row1 : L0) : 0;
     board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
   }
   if (board0 >= L) return;
@@ -659,7 +659,7 @@ __device__ __forceinline__ void join3x4(uint2 H, uint2 M, uint2 L, float* x) {
 
 __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParams p1,
                                                             const float* __restrict__ planes,
-                                                            const int32_t* __restrict__ counts, int which,
+                                                            const int32_t* __restrict__ counts, int which, int row1,
                                                             float* __restrict__ probs, float* __restrict__ values) {
   __shared__ uint4 lds[LDS3_G];
   uint4* wbuf = lds + ACT3_G;
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParam
     const int t0 = (L0 + p0.TB - 1) / p0.TB;
     second = (int)blockIdx.x >= t0;
     L = second ? counts[1] : L0;
-    row0 = second ? L0 : 0;
+    row0 = second ? (row1 >= 0 ? row1 : L0) : 0;
     board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
   }
   if (board0 >= L) return;
@@ -1092,20 +1092,21 @@ int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts
   const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
   if (n->p.w3)
     hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
-                       planes_dev, counts_dev, which, probs_dev, values_dev);
+                       planes_dev, counts_dev, which, -1, probs_dev, values_dev);
   else if (n->p.ww)
     hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
-                       planes_dev, counts_dev, which, probs_dev, values_dev, (unsigned long long*)nullptr);
+                       planes_dev, counts_dev, which, -1, probs_dev, values_dev, (unsigned long long*)nullptr);
   else
     hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
-                       planes_dev, counts_dev, which, probs_dev, values_dev, (unsigned long long*)nullptr);
+                       planes_dev, counts_dev, which, -1, probs_dev, values_dev, (unsigned long long*)nullptr);
   if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
   return 0;
 }
 
-/* both nets of an arena in one launch: rows [0, L0) through n0, rows [L0, L0+L1) through n1 */
-int caro_net_forward_pair(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
-                          int64_t max_rows, float* probs_dev, float* values_dev, void* stream) {
+/* both nets of an arena in one launch: rows [0, L0) through n0; n1's rows start at row1_base, or at L0 when
+ * row1_base < 0 */
+int caro_net_forward_pair_at(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
+                             int64_t row1_base, int64_t max_rows, float* probs_dev, float* values_dev, void* stream) {
   if (!n0 || !n1 || !planes_dev || !counts_dev || !probs_dev || !values_dev) return nfail(CARO_E_INVAL, "null argument");
   if (n0->p.H != n1->p.H || n0->p.W != n1->p.W || n0->p.A != n1->p.A) return nfail(CARO_E_INVAL, "nets differ in shape");
   if (max_rows <= 0) return 0;
@@ -1114,15 +1115,20 @@ int caro_net_forward_pair(caro_net* n0, caro_net* n1, const float* planes_dev, c
   const unsigned grid = (unsigned)((max_rows + n0->p.TB - 1) / n0->p.TB + 1);  // +1: each class rounds up
   if (n0->p.w3)
     hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n0->p, n1->p,
-                       planes_dev, counts_dev, 2, probs_dev, values_dev);
+                       planes_dev, counts_dev, 2, (int)row1_base, probs_dev, values_dev);
   else if (n0->p.ww)
     hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n0->p, n1->p,
-                       planes_dev, counts_dev, 2, probs_dev, values_dev, (unsigned long long*)nullptr);
+                       planes_dev, counts_dev, 2, (int)row1_base, probs_dev, values_dev, (unsigned long long*)nullptr);
   else
     hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n0->p, n1->p,
-                       planes_dev, counts_dev, 2, probs_dev, values_dev, (unsigned long long*)nullptr);
+                       planes_dev, counts_dev, 2, (int)row1_base, probs_dev, values_dev, (unsigned long long*)nullptr);
   if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
   return 0;
+}
+
+int caro_net_forward_pair(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
+                          int64_t max_rows, float* probs_dev, float* values_dev, void* stream) {
+  return caro_net_forward_pair_at(n0, n1, planes_dev, counts_dev, -1, max_rows, probs_dev, values_dev, stream);
 }
 
 /* diagnostic: same launch, and per workgroup (total cycles, 100 MHz ticks, cycles at trunk start, at trunk end) into stamps_dev u64[4*grid] */
@@ -1134,10 +1140,10 @@ int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t
   if (n->p.w3) return nfail(CARO_E_STATE, "no stamps in 3xbf16 mode");
   if (n->p.ww)
     hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
-                       planes_dev, counts_dev, which, probs_dev, values_dev, (unsigned long long*)stamps_dev);
+                       planes_dev, counts_dev, which, -1, probs_dev, values_dev, (unsigned long long*)stamps_dev);
   else
     hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
-                       planes_dev, counts_dev, which, probs_dev, values_dev, (unsigned long long*)stamps_dev);
+                       planes_dev, counts_dev, which, -1, probs_dev, values_dev, (unsigned long long*)stamps_dev);
   if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
   return 0;
 }

@@ -98,7 +98,7 @@ class SelfPlayEngine:
         h = C.c_void_p()
         _lib.check(self.L.caro_engine_create(C.byref(c), C.byref(h)))
         self.h = h
-        rows = self.G * self.max_batch
+        rows = self.G * self.max_batch * self.n_nets  # two nets: caro_search_batch places net 1's rows from G*B on
         self.planes = torch.zeros((rows,) + self.obs_shape, dtype=torch.float32, device=self.device)
         self.leaf_keys = torch.zeros((rows, self.KW), dtype=torch.int64, device=self.device)
         self._probs = torch.zeros((rows, self.A), dtype=torch.float32, device=self.device)

@@ -233,6 +233,9 @@ int caro_stream_destroy(void* stream);
 /* both nets of an arena in ONE launch: rows [0, L0) through n0, rows [L0, L0+L1) through n1 */
 int caro_net_forward_pair(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
                           int64_t max_rows, float* probs_dev, float* values_dev, void* stream);
+/* the same with n1's rows starting at row1_base instead of L0 (row1_base < 0: at L0) */
+int caro_net_forward_pair_at(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
+                             int64_t row1_base, int64_t max_rows, float* probs_dev, float* values_dev, void* stream);
 /* diagnostic form: also writes per workgroup (total shader cycles, 100 MHz wall ticks, cycles at trunk start, at trunk end) to stamps_dev u64[4*grid],
  * grid = ceil(max_rows / caro_net_boards_per_workgroup); used by tools/probe_clock.py only */
 int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which,
@@ -241,7 +244,9 @@ int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t
 /* MCTS.search_batch (lib/mcts.py:162-176) for every live game with the fused net(s): `searches` x
  * (caro_select -> caro_net_forward per net -> caro_expand_backup) enqueued on `stream` from one call, no host
  * synchronisation.  noise_dev: f64[searches, G, batch, A] or NULL (generated); buffers as for caro_select /
- * caro_expand_backup; net1 may be NULL when the engine has one net. */
+ * caro_expand_backup, but with room for 2 * G * batch rows when the engine has two nets (the second net's rows
+ * are placed from row G * batch on); net1 may be NULL when the engine has one net.  With one wavefront per game
+ * (batch * lanes-per-descent == 64) the three tree kernels run fused (k_tree), two launches per minibatch. */
 int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch,
                       const double* noise_dev, float* planes_dev, uint64_t* leaf_keys_dev, float* probs_dev,
                       float* values_dev, void* stream);

@@ -290,3 +290,40 @@ def test_play_session_bot_moves():
     assert won is False and len(s.moves) == 2 and s.moves[1] in range(7)
     assert s.value is not None and "<pre>" in s.render()
     assert len(s.mcts_store) > 10
+
+
+@pytest.mark.parametrize("two_nets", [False, True])
+def test_fused_tree_kernel_equals_stepwise_kernels(two_nets, monkeypatch):
+    """caro_search_batch runs the fused k_tree (expand+backup, select, row reservation + planes in one launch)
+    when a game is one wavefront; CARO_NO_FUSED_TREE=1 keeps the four-launch form.  Net rows land in another
+    order, nothing else may change: per-ply root visit counts, roots and the drained tuples are identical."""
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    g = ConnectFour()
+    nets = []
+    for w in ("best_026_12000.dat", "best_025_10600.dat"):
+        n = Net(g.obs_shape, g.action_space)
+        n.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", w), map_location="cpu"))
+        nets.append(n.to("cuda:0"))
+    runs = []
+    for no_fused in ("1", "0"):
+        monkeypatch.setenv("CARO_NO_FUSED_TREE", no_fused)
+        kw = dict(n_stores=2, first_player_mode=2, steps_before_tau_0=0) if two_nets else dict(steps_before_tau_0=4)
+        eng = SelfPlayEngine(g, 96, net1=nets[0], net2=nets[1] if two_nets else None, max_batch=8, seed=5, **kw)
+        trace = []
+        for ply in range(12):
+            eng.search(9, 8)
+            pi, counts = eng.policy()
+            trace.append((counts.cpu().numpy().copy(), eng.roots()[0].copy()))
+            eng.step()
+            d = eng.drain(recycle=True)
+            trace.append(tuple(d[k].cpu().numpy().copy() for k in ("games", "states", "players", "pi", "z")))
+        c = eng.counters()
+        eng.close()
+        runs.append((trace, c))
+    (ta, ca), (tb, cb) = runs
+    assert ca == cb and ca["expansions"] > 0
+    for x, y in zip(ta, tb):
+        for u, w_ in zip(x, y):
+            assert np.array_equal(u, w_)
