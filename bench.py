@@ -36,6 +36,24 @@ MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/
 MFMA_BF16_PEAK_TFS = 2500.0 # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 
 
+def host_cores():
+    """cores this process may really use: the affinity mask, capped by the cgroup CPU quota (cpu.max / cfs quota)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def load_pmc():
     """HBM bytes per launch from the committed PMC passes (profiles/pmc_r01.json), keyed by kernel."""
     path = os.path.join(ROOT, "profiles", "pmc_r01.json")
@@ -137,7 +155,7 @@ def main():
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N > 1: all-gather the finished games' tuples every this many moves (one payload message)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-procs", type=int, default=0, help="host cores for the CPU baseline (0 = all, capped at 32)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="host cores for the CPU baseline (0 = all this process may use: affinity and cgroup quota, capped at 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the kernels")
     args = ap.parse_args()
@@ -151,7 +169,7 @@ def main():
     # CPU baseline first (N = 1 only): it forks worker processes, which must happen before the GPU is touched
     cpu_line = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and not args.arena:
-        procs = args.cpu_procs or min(32, os.cpu_count() or 1)
+        procs = args.cpu_procs or min(32, host_cores())
         w = args.weights if args.game == "c4" else None
         print("[bench] cpu baseline on %d cores for %.0f s" % (procs, args.cpu_seconds), file=sys.stderr, flush=True)
         cpu_line = cpu_baseline(args.game, args.searches, args.batch, 10, w, args.cpu_seconds, procs)
