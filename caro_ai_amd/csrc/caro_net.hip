@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -68,6 +69,7 @@ struct NetParams {
   const uint4* w3;      // 3xbf16 mode: [45 taps][1536 granules] LDS image of the split residual weights, or null
   const float* ww;      // f32w mode: [5][4 p][3 dx][4096] transformed residual weights (LDS image order), or null
   const uint32_t* wtab; // f32w mode: [128] tile of MFMA row (row tile, lane): board | ty << 8 | x << 16 | valid << 24
+  int ncu, TB2, TB4;    // f32w mode: compute units; boards per workgroup of the 2- / 4-way K-split overflow tiles (0: off)
 };
 
 __device__ __forceinline__ int aoff(int row, int c) {
@@ -386,66 +388,38 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
 constexpr int WTAPS = NRES * 12;          // 60
 constexpr int WNCHUNK = WTAPS / TPC;      // 20
 
-__global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams p1,
-                                                           const float* __restrict__ planes,
-                                                           const int32_t* __restrict__ counts, int which, int row1,
-                                                           float* __restrict__ probs, float* __restrict__ values,
-                                                           unsigned long long* __restrict__ stamps) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  float* act = lds;
-  float* wbuf = lds + ACT;
-
-  int L, row0, board0;
-  bool second = false;
-  if (which < 2) {
-    L = counts[which];
-    row0 = which ? counts[0] : 0;
-    board0 = blockIdx.x * p0.TB;
-  } else {
-    const int L0 = counts[0];
-    const int t0 = (L0 + p0.TB - 1) / p0.TB;
-    second = (int)blockIdx.x >= t0;
-    L = second ? counts[1] : L0;
-    row0 = second ? (row1 >= 0 ? row1 : L0) : 0;
-    board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
-  }
-  if (board0 >= L) return;
-  const NetParams p = second ? p1 : p0;
+template <int KS>
+__device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* wbuf, int nb, int tid) {
   const float slope = p.slope;
-  unsigned long long t_c0 = 0, t_r0 = 0;  // diagnostic only, as in k_net_forward
-  if (stamps) {
-    t_c0 = __builtin_amdgcn_s_memtime();
-    t_r0 = __builtin_amdgcn_s_memrealtime();
-  }
-  const int nb = min(p.TB, L - board0);
   const int HW = p.HW;
-  const int R = nb * HW;  // real rows
-  const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int i = lane & 31, h = lane >> 5;
-
-  for (int k = tid; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = tid; k < 9 * 2 * NF; k += NT) wbuf[k] = p.w_in[k];
-  __syncthreads();
-  conv_in_f32(p, planes + (size_t)(row0 + board0) * 2 * HW, act, wbuf, R, tid);
-  __syncthreads();
-  unsigned long long t_trunk0 = 0;
-  if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
-  {
-    const float4* src = reinterpret_cast<const float4*>(p.ww);
-#pragma unroll
-    for (int m = 0; m < 2 * TPC; ++m) reinterpret_cast<float4*>(wbuf)[tid + NT * m] = src[tid + NT * m];
+  // KS = 1: wave = row tile (wave >> 1) x col tile (wave & 1), all of K.  KS = 2 / 4 (workgroups of the second
+  // round of a launch that overflows one round, see k_net_forward_w): 4 / KS row tiles, and KS waves share one
+  // (row tile, col tile), wave kq taking the channel granules Q with Q % KS == kq; their partial sums meet in LDS
+  // before the in-place epilogue.
+  constexpr int NRT = 4 / KS;        // row tiles
+  constexpr int SPT = 8 / KS;        // operand sets per tap and wave
+  constexpr int NS = 3 * SPT;        // operand sets per chunk and wave
+  const int ct = wave & 1, rt = (wave >> 1) % NRT, kq = (wave >> 1) / NRT;
+  // this lane's tile.  KS = 1: which tile sits on which MFMA row is a host-built table: a ds_read_b128 is served
+  // in 16-lane groups, a group is conflict-free when its 16 activation rows differ mod 16 (the swizzle key), and
+  // the table picks the tiles of each group accordingly (caro_net_enable_winograd).  KS > 1: tiles in order.
+  int tbi, tty, tx;
+  bool tvalid;
+  if (KS == 1) {
+    const uint32_t tent = p.wtab[rt * 32 + i];
+    tbi = tent & 0xFF; tty = (tent >> 8) & 0xFF; tx = (tent >> 16) & 0xFF;
+    tvalid = (tent >> 24) != 0 && tbi < nb;
+  } else {
+    const int tpb = ((p.H + 1) >> 1) * p.W;
+    const int mt = rt * 32 + i;
+    tbi = mt / tpb;
+    const int rem = mt - tbi * tpb;
+    tty = rem / p.W; tx = rem - tty * p.W;
+    tvalid = mt < nb * tpb;
   }
-  __syncthreads();
-
-  const int rt = wave >> 1, ct = wave & 1;
-  // this lane's tile.  Which tile sits on which MFMA row is a host-built table: a ds_read_b128 is served in
-  // 16-lane groups, a group is conflict-free when its 16 activation rows differ mod 16 (the swizzle key), and the
-  // table picks the tiles of each group accordingly (caro_net_enable_winograd)
-  const uint32_t tent = p.wtab[rt * 32 + i];
-  const int tbi = tent & 0xFF, tty = (tent >> 8) & 0xFF, tx = (tent >> 16) & 0xFF;
-  const bool tvalid = (tent >> 24) != 0 && tbi < nb;
-  const int bswz = (i >> 1) & 7;
+  const int bswz = ((i >> 1) & 7) ^ kq;  // kq folded into the weight granule index (its low log2(KS) bits are free)
   // output side: with the WEIGHTS as first MFMA operand a lane's 16 accumulator registers are 4 groups of 4
   // consecutive channels (ct*32 + 8q + 4h + 0..3) of ITS tile, so the epilogue moves float4s
   const int orow0 = tbi * HW + 2 * tty * p.W + tx;  // activation row of output row 2ty
@@ -470,8 +444,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
       const bool okx = nx >= 0 && nx < p.W;
       const int rowa = oka && okx ? tbi * HW + ya * p.W + nx : ZROW;
       const int rowb = okb && okx ? tbi * HW + yb * p.W + nx : ZROW;
-      oa[d] = rowa * NF + (((h * 8) ^ (rowa & 15)) << 2);
-      ob[d] = rowb * NF + (((h * 8) ^ (rowb & 15)) << 2);
+      oa[d] = rowa * NF + (((h * 8 + kq) ^ (rowa & 15)) << 2);
+      ob[d] = rowb * NF + (((h * 8 + kq) ^ (rowb & 15)) << 2);
     }
   };
   const float* wlane = wbuf + (h * 64 + ct * 32 + i) * 32;
@@ -491,10 +465,11 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
     const float* wbase = wlane + cur * TPC * WCHUNK;
     const float* wnext = wlane + (cur ^ 1) * TPC * WCHUNK;
     int noffa[3], noffb[3];
-#define CARO_LOADW(A_, S_, B_, S)                                                                   \
-  A_ = *reinterpret_cast<const float4*>(act + (offa[(S) >> 3] ^ (((S) & 7) << 2)));                  \
-  S_ = *reinterpret_cast<const float4*>(act + (offb[(S) >> 3] ^ (((S) & 7) << 2)));                  \
-  B_ = *reinterpret_cast<const float4*>(wbase + ((S) >> 3) * WCHUNK + ((((S) & 7) ^ bswz) << 2));
+// operand set S of this wave: tap S / SPT, channel granule (S % SPT) * KS (+ kq, folded into the offsets)
+#define CARO_LOADW(A_, S_, B_, S)                                                                          \
+  A_ = *reinterpret_cast<const float4*>(act + (offa[(S) / SPT] ^ ((((S) % SPT) * KS) << 2)));               \
+  S_ = *reinterpret_cast<const float4*>(act + (offb[(S) / SPT] ^ ((((S) % SPT) * KS) << 2)));               \
+  B_ = *reinterpret_cast<const float4*>(wbase + ((S) / SPT) * WCHUNK + (((((S) % SPT) * KS) ^ bswz) << 2));
 // the four transformed operands first, then the four MFMAs back to back: interleaving v_fma / v_mfma pairs costs
 // ~6 % of the trunk (each MFMA then waits on the VALU result just ahead of it)
 #define CARO_MFMAW(A_, S_, B_)                                                                        \
@@ -511,12 +486,12 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
       CARO_LOADW(xa, xs, xb, 0)
     }
 #pragma unroll
-    for (int s_ = 0; s_ < 24; s_ += 2) {
+    for (int s_ = 0; s_ < NS; s_ += 2) {
       CARO_LOADW(ya_, ys, yb_, s_ + 1)
       __builtin_amdgcn_sched_barrier(0);
       CARO_MFMAW(xa, xs, xb)
       __builtin_amdgcn_sched_barrier(0);
-      if (s_ + 2 < 24) {
+      if (s_ + 2 < NS) {
         CARO_LOADW(xa, xs, xb, s_ + 2)
       } else if (pp != 3) {  // set 0 of the next chunk (same layer: the activations do not change)
         xa = *reinterpret_cast<const float4*>(act + noffa[0]);
@@ -526,7 +501,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
       __builtin_amdgcn_sched_barrier(0);
       CARO_MFMAW(ya_, ys, yb_)
       __builtin_amdgcn_sched_barrier(0);
-      if (s_ == 6) {
+      if (s_ == SPT - 2) {
         __syncthreads();  // every wave has left chunk c-1: the other buffer is free
         if (has_next) {
           // next chunk: global -> LDS directly (no staging registers); each wave instruction moves 1 KiB, the LDS
@@ -541,7 +516,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (s_ == 14) {
+      if (s_ == 2 * SPT - 2) {
         __syncthreads();  // chunk c+1 is visible to every wave
         tap_offsets((pp + 1) & 3, noffa, noffb);
         __builtin_amdgcn_sched_barrier(0);
@@ -565,6 +540,34 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
     }
     if (pp == 3) {
       __syncthreads();  // every wave has read this layer's input activations: they may be overwritten
+      if (KS > 1) {
+        // partial sums of the waves kq > 0 -> the weight buffer just read (free until the next chunk's fetch,
+        // which waits for the barrier after that chunk's first tap) -> added by the wave kq == 0 of the same tile
+        float* red = wbuf + cur * TPC * WCHUNK;
+        constexpr int NTASK = 2 * NRT;
+        const int task = rt * 2 + ct;
+        if (kq > 0) {
+          float* dst = red + ((kq - 1) * NTASK + task) * 2048 + lane;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            dst[e * 64] = accY0[e];
+            dst[(16 + e) * 64] = accY1[e];
+          }
+        }
+        __syncthreads();
+        if (kq == 0) {
+#pragma unroll
+          for (int k = 1; k < KS; ++k) {
+            const float* src = red + ((k - 1) * NTASK + task) * 2048 + lane;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              accY0[e] += src[e * 64];
+              accY1[e] += src[(16 + e) * 64];
+            }
+          }
+        }
+      }
+      const bool writer = kq == 0;
       // in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89); only real cells are written, the rest stay 0
       const float* bias = p.b_res + layer * NF + ct * 32 + 4 * h;
       const int g0 = ct * 8 + h;  // granule of group q is g0 + 2q
@@ -589,8 +592,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
         n1.y = old1[q].y + leaky(accY1[4 * q + 1] + bq.y, slope);
         n1.z = old1[q].z + leaky(accY1[4 * q + 2] + bq.z, slope);
         n1.w = old1[q].w + leaky(accY1[4 * q + 3] + bq.w, slope);
-        if (ovalid0) *reinterpret_cast<float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) = n0;
-        if (ovalid1) *reinterpret_cast<float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) = n1;
+        if (ovalid0 && writer) *reinterpret_cast<float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) = n0;
+        if (ovalid1 && writer) *reinterpret_cast<float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) = n1;
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -600,6 +603,78 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
       __syncthreads();  // new activations visible to every wave
     }
   }
+}
+
+__global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams p1,
+                                                           const float* __restrict__ planes,
+                                                           const int32_t* __restrict__ counts, int which, int row1,
+                                                           float* __restrict__ probs, float* __restrict__ values,
+                                                           unsigned long long* __restrict__ stamps) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float* act = lds;
+  float* wbuf = lds + ACT;
+
+  int L, row0, board0, nb, nb_cap = p0.TB;
+  int ks = 1;  // K-split of this workgroup's tiles (1: a full tile of TB boards)
+  bool second = false;
+  if (which < 2) {
+    L = counts[which];
+    row0 = which ? counts[0] : 0;
+    board0 = blockIdx.x * p0.TB;
+    // Launch quantisation: one round of the chip holds ncu full tiles.  When a launch overflows it by a little,
+    // the overflow is cut into SMALLER tiles whose K loop is split over the waves (4-way: TB4 boards, 2-way: TB2
+    // boards per workgroup) so that the second round lasts a third / half as long; workgroups [0, ncu) stay full.
+    const int full = p0.ncu * p0.TB;
+    if (L > full && p0.ncu > 0) {
+      const int over = L - full;
+      if (p0.TB4 > 0 && over <= p0.ncu * p0.TB4) ks = 4;
+      else if (p0.TB2 > 0 && over <= p0.ncu * p0.TB2) ks = 2;
+      if (ks > 1) {
+        if ((int)blockIdx.x < p0.ncu) {
+          ks = 1;
+        } else {
+          nb_cap = ks == 4 ? p0.TB4 : p0.TB2;
+          board0 = full + ((int)blockIdx.x - p0.ncu) * nb_cap;
+        }
+      }
+    }
+  } else {
+    const int L0 = counts[0];
+    const int t0 = (L0 + p0.TB - 1) / p0.TB;
+    second = (int)blockIdx.x >= t0;
+    L = second ? counts[1] : L0;
+    row0 = second ? (row1 >= 0 ? row1 : L0) : 0;
+    board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
+  }
+  if (board0 >= L) return;
+  const NetParams p = second ? p1 : p0;
+  unsigned long long t_c0 = 0, t_r0 = 0;  // diagnostic only, as in k_net_forward
+  if (stamps) {
+    t_c0 = __builtin_amdgcn_s_memtime();
+    t_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  nb = min(nb_cap, L - board0);
+  const int HW = p.HW;
+  const int R = nb * HW;  // real rows
+  const int tid = threadIdx.x;
+
+  for (int k = tid; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = tid; k < 9 * 2 * NF; k += NT) wbuf[k] = p.w_in[k];
+  __syncthreads();
+  conv_in_f32(p, planes + (size_t)(row0 + board0) * 2 * HW, act, wbuf, R, tid);
+  __syncthreads();
+  unsigned long long t_trunk0 = 0;
+  if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.ww);
+#pragma unroll
+    for (int m = 0; m < 2 * TPC; ++m) reinterpret_cast<float4*>(wbuf)[tid + NT * m] = src[tid + NT * m];
+  }
+  __syncthreads();
+
+  if (ks == 1) trunk_w<1>(p, act, wbuf, nb, tid);
+  else if (ks == 2) trunk_w<2>(p, act, wbuf, nb, tid);
+  else trunk_w<4>(p, act, wbuf, nb, tid);
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
   heads_f32(p, act, wbuf, probs + (size_t)(row0 + board0) * p.A, values + row0 + board0, nb, R, tid);
@@ -936,6 +1011,20 @@ static int nfail(int code, const std::string& m) {
   return code;
 }
 
+// workgroups of a launch over at most max_rows rows: full tiles, or (f32w, overflow by a little) ncu full tiles +
+// the overflow in split tiles -- never more than 2 * ncu of those, see k_net_forward_w
+static unsigned net_grid(const caro_net* n, int64_t max_rows) {
+  int64_t grid = (max_rows + n->p.TB - 1) / n->p.TB;
+  const int64_t full = (int64_t)n->p.ncu * n->p.TB;
+  const int tbmin = n->p.TB4 > 0 ? n->p.TB4 : n->p.TB2;
+  if (n->p.ww && n->p.ncu > 0 && tbmin > 0 && max_rows > full) {
+    int64_t split = n->p.ncu + (max_rows - full + tbmin - 1) / tbmin;
+    if (split > 2 * (int64_t)n->p.ncu) split = 2 * (int64_t)n->p.ncu;
+    if (split > grid) grid = split;
+  }
+  return (unsigned)grid;
+}
+
 extern "C" {
 
 // number of floats caro_net_create expects for an H x W board with A actions
@@ -991,6 +1080,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   p.w3 = nullptr;
   p.ww = nullptr;
   p.wtab = nullptr;
+  p.ncu = 0; p.TB2 = 0; p.TB4 = 0;
   *out = n;
   return 0;
 }
@@ -1070,6 +1160,14 @@ int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats
   if (hipMemcpy(n->wtab_dev, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) return nfail(CARO_E_HIP, "hipMemcpy failed");
   n->p.wtab = n->wtab_dev;
   n->p.ww = n->ww_dev;
+  // overflow tiles (k_net_forward_w): 64 / 32 GEMM rows with the K loop split over 2 / 4 waves
+  int ncu = 0;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->device) != hipSuccess) ncu = 0;
+  const char* off = getenv("CARO_NO_SPLIT_TILES");  // A/B measurements
+  if (off && off[0] == '1') ncu = 0;
+  n->p.ncu = ncu;
+  n->p.TB2 = 64 / tpb < n->p.TB ? 64 / tpb : 0;
+  n->p.TB4 = 32 / tpb < n->p.TB ? 32 / tpb : 0;
   return 0;
 }
 
@@ -1089,7 +1187,7 @@ int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts
   if (!n || !planes_dev || !counts_dev || !probs_dev || !values_dev) return nfail(CARO_E_INVAL, "null argument");
   if (which != 0 && which != 1) return nfail(CARO_E_INVAL, "which must be 0 or 1");
   if (max_rows <= 0) return 0;
-  const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
+  const unsigned grid = net_grid(n, max_rows);
   if (n->p.w3)
     hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
                        planes_dev, counts_dev, which, -1, probs_dev, values_dev);
@@ -1136,7 +1234,7 @@ int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t
                              int64_t max_rows, float* probs_dev, float* values_dev, uint64_t* stamps_dev,
                              void* stream) {
   if (!n || !stamps_dev) return nfail(CARO_E_INVAL, "null argument");
-  const unsigned grid = (unsigned)((max_rows + n->p.TB - 1) / n->p.TB);
+  const unsigned grid = net_grid(n, max_rows);
   if (n->p.w3) return nfail(CARO_E_STATE, "no stamps in 3xbf16 mode");
   if (n->p.ww)
     hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,

@@ -64,6 +64,46 @@ def test_hip_net_matches_torch_fp32(shape, A, weights, L, mode):
     hn.close()
 
 
+@pytest.mark.parametrize("shape,A,weights,L", [((2, 6, 7), 7, "best_026_12000.dat", 1537), ((2, 6, 7), 7, "best_026_12000.dat", 1700),
+                                               ((2, 6, 7), 7, "best_026_12000.dat", 1792), ((2, 6, 7), 7, "best_026_12000.dat", 1793),
+                                               ((2, 6, 7), 7, "best_026_12000.dat", 2304), ((2, 6, 7), 7, "best_026_12000.dat", 2305),
+                                               ((2, 6, 7), 7, "best_026_12000.dat", 3100), ((2, 3, 3), 9, "best_005_00900.dat", 5500),
+                                               ((2, 5, 5), 25, None, 2100)])
+def test_winograd_net_overflow_tiles(shape, A, weights, L):
+    """Launches that overflow one round of full tiles (256 compute units x TB boards) put the overflow into
+    smaller tiles with the K loop split over 4 or 2 waves (k_net_forward_w): same function, and the rows of the
+    full tiles keep their bits (compared with a launch that holds only them)."""
+    from caro_ai_amd.net_hip import HipNet
+    net = _net(shape, A, weights)
+    x = _boards(L, shape, L)
+    with torch.no_grad():
+        lg, vl = net(x)
+        p_ref = torch.softmax(lg, dim=1)
+        lg64, vl64 = net.double()(x.double())
+        p64 = torch.softmax(lg64, dim=1)
+    net.float()
+    hn = HipNet(net, "cuda:0", mode="f32w")
+    xg = x.to("cuda:0")
+    p, v = hn(xg)
+    full = 256 * hn.L.caro_net_boards_per_workgroup(hn.h)
+    assert L > full
+    p_head, v_head = hn(xg[:full])
+    torch.cuda.synchronize()
+    # thousands of boards: the extreme of the float32 re-association error grows with the sample, so the bound is
+    # relative to torch's own float32 forward against a float64 forward (x4 slack), as in the test above
+    e_hip = (p.cpu().double() - p64).abs().max().item()
+    e_ref = (p_ref.double() - p64).abs().max().item()
+    assert e_hip < max(4 * e_ref, 1e-6), (e_hip, e_ref)
+    assert (p.cpu() - p_ref).abs().max().item() < 3e-4
+    assert (v.cpu() - vl[:, 0]).abs().max().item() < 1e-4
+    # the overflow rows alone: same bound
+    e_tail = (p[full:].cpu().double() - p64[full:]).abs().max().item()
+    assert e_tail < max(4 * e_ref, 1e-6), (e_tail, e_ref)
+    assert torch.equal(p[:full], p_head) and torch.equal(v[:full], v_head)
+    assert torch.allclose(p.sum(1), torch.ones(L, device="cuda:0"), atol=1e-5)
+    hn.close()
+
+
 def test_hip_net_device_count_and_second_net_offset():
     """rows come from counts on the device: which = 1 starts at counts[0]."""
     from caro_ai_amd.net_hip import HipNet
