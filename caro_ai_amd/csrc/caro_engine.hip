@@ -570,21 +570,55 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
   const bool overflow = base + nleaf > v.cap;
   const int A = v.A;
   if (!overflow) {
-    for (int b = 0; b < B; ++b) {
-      const size_t di = (size_t)g * v.maxB + b;
-      if (v.d_status[di] != ST_LEAF) continue;
-      const int rowi = off + v.d_local[di];
-      int node = 0;
-      if (lane == 0) node = insert_key<R>(v, t, load_board<R>(v.d_key + di * KW));
-      node = __shfl(node, 0);
-      if (node < 0) continue;  // cannot happen while n_nodes <= cap < hcap
-      uint32_t* row = v.edges + (tbase(v, t) + node) * 4 * AP;
-      for (int a = lane; a < AP; a += blockDim.x) {
-        row[a] = 0u;
-        row[AP + a] = 0u;
-        row[2 * AP + a] = 0u;
-        row[3 * AP + a] = a < A ? __float_as_uint(probs[(size_t)rowi * A + a]) : 0u;
+    // _create_node for the unique leaves.  The reference inserts them one after another (first-seen order); here
+    // the home slots of ALL leaves are fetched first (one memory latency for the block instead of one per leaf),
+    // then lane 0 places them in that same order: a leaf whose home slot is free and not taken by an earlier leaf
+    // of this minibatch needs no further memory access, only collisions walk the probe sequence.  Slot choice is
+    // therefore identical to sequential insertion.
+    __shared__ int s_node[MAXB], s_row[MAXB];
+    __shared__ uint32_t s_home[MAXB];
+    __shared__ unsigned char s_free[MAXB];
+    if (lane < B) {
+      const size_t di = (size_t)g * v.maxB + lane;
+      s_node[lane] = -2;  // not a leaf
+      if (v.d_status[di] == ST_LEAF) {
+        const typename R::Board brd = load_board<R>(v.d_key + di * KW);
+        const uint32_t hs = home_slot<R>(v, brd);
+        s_home[lane] = hs;
+        s_free[lane] = v.node_key[(tbase(v, t) + hs) * KW] == EMPTY_KEY;
+        s_row[lane] = off + v.d_local[di];
+        s_node[lane] = -1;
       }
+    }
+    __syncthreads();
+    if (lane == 0) {
+      for (int b = 0; b < B; ++b) {
+        if (s_node[b] == -2) continue;
+        bool fast = s_free[b] != 0;
+        for (int bb = 0; bb < b && fast; ++bb) fast = !(s_node[bb] >= 0 && (uint32_t)s_node[bb] == s_home[b]);
+        const size_t di = (size_t)g * v.maxB + b;
+        const typename R::Board brd = load_board<R>(v.d_key + di * KW);
+        if (fast) {
+          uint64_t* k = v.node_key + (tbase(v, t) + s_home[b]) * KW;
+#pragma unroll
+          for (int w = KW - 1; w >= 0; --w) k[w] = brd.w[w];
+          s_node[b] = (int)s_home[b];
+        } else {
+          s_node[b] = insert_key<R>(v, t, brd);
+        }
+      }
+    }
+    __syncthreads();
+    // the four action rows of every new node, lanes over (leaf, action): one pass for B * AP <= block size
+    for (int idx = lane; idx < B * AP; idx += blockDim.x) {
+      const int b = idx / AP, a = idx - b * AP;
+      const int node = s_node[b];
+      if (node < 0) continue;  // not a leaf (a failed insert cannot happen while n_nodes <= cap < hcap)
+      uint32_t* row = v.edges + (tbase(v, t) + node) * 4 * AP;
+      row[a] = 0u;
+      row[AP + a] = 0u;
+      row[2 * AP + a] = 0u;
+      row[3 * AP + a] = a < A ? __float_as_uint(probs[(size_t)s_row[b] * A + a]) : 0u;
     }
   }
   // Flatten the backup queue, lane-parallel.  Queue order (reference): terminals by sim index, then new
@@ -708,11 +742,15 @@ __global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ n
     rows_next[2] = B;
     rows_cur[2] = B;
   }
+  unsigned long long t0 = 0;
+  if (v.dbg) t0 = __builtin_amdgcn_s_memtime();
   if (do_expand) {
     expand_body<GEO>(v, B, probs, values);
     __syncthreads();  // the block's own tree updates are visible to its descents
   }
+  if (v.dbg && threadIdx.x == 0) v.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime() - t0;  // expand + backup
   if (do_select) select_body<GEO>(v, B, mb_index, noise, rows_cur, row1_base, planes, leaf_keys);
+  if (v.dbg && threadIdx.x == 0) v.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime() - t0;  // whole block
 }
 
 // ------------------------------------------------------------------ policy / step

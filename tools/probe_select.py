@@ -26,5 +26,7 @@ print("  root rows + key arrived", q(rows))
 print("  noise generated        ", q(noise), " -> noise gen alone", q(noise - rows))
 print("  all descents done      ", q(loop), " -> descent loop after the root level", q(loop - noise))
 print("  end of kernel          ", q(end), " -> dedupe + result writes", q(end - loop))
+if d[:, 6].max() > 0:  # fused k_tree: expand + backup of the previous minibatch precedes the descents in the same block
+    print("  k_tree: expand+backup  ", q(d[:, 5]), " whole block", q(d[:, 6]), " select part", q(d[:, 6] - d[:, 5]))
 print("  max depth in the wave  ", q(maxd), " cycles per level after the root (median)", np.median((loop - noise) / np.maximum(1, maxd - 1)).round(0))
 eng.close()
