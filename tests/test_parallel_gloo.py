@@ -125,3 +125,65 @@ def test_single_process_paths_are_noops():
     assert both["z"].shape[0] == 7 and both["pi"].dtype == torch.float32 and tg.flush() is None
     assert parallel.shard(1024, 0, 1) == {"uid_base": 0, "uid_stride": 1024}
     assert parallel.allreduce_sum(torch.tensor([5])).item() == 5
+
+
+def _gpu_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), CARO_DIST_BACKEND="gloo")
+    from caro_ai_amd import parallel
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.lib.model import Net
+    parallel.init()
+    game = TicTacToe()
+    torch.manual_seed(0)
+    net = Net(game.obs_shape, game.action_space).to("cuda:0").eval()
+    parallel.broadcast_weights(net)
+    G = 24
+    eng = SelfPlayEngine(game, G, net1=net, max_batch=4, steps_before_tau_0=2, seed=3, device="cuda:0",
+                         **parallel.shard(G, rank, world))
+    tg = parallel.TupleGatherer(every=3)
+    rows, local = [], 0
+    for _ in range(10):
+        eng.search(5, 4)
+        eng.step()
+        d = eng.drain(recycle=True)
+        local += int(d["z"].shape[0])
+        out = tg.push(d)
+        if out is not None:
+            rows.append({k: v.cpu().numpy() for k, v in out.items()})
+    out = tg.flush()
+    if out is not None:
+        rows.append({k: v.cpu().numpy() for k, v in out.items()})
+    eng.close()
+    q.put((rank, local, rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_batched_tuple_exchange():
+    """N = 2 rehearsal on one GPU (gloo between the ranks, both engines on cuda:0): the batched tuple exchange
+    delivers every rank's tuples to every rank, rank-major, and the shards play disjoint game ids."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, local, rows = q.get(timeout=300)
+        res[rank] = (local, rows)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = res[0][0] + res[1][0]
+    assert total > 0
+    for rank in range(world):
+        got = sum(r["z"].shape[0] for r in res[rank][1])
+        assert got == total
+    for a, b in zip(res[0][1], res[1][1]):  # both ranks received the same rows in the same order
+        for k in ("states", "players", "pi", "z"):
+            np.testing.assert_array_equal(a[k], b[k])
