@@ -187,3 +187,43 @@ def test_two_ranks_share_one_gpu_batched_tuple_exchange():
     for a, b in zip(res[0][1], res[1][1]):  # both ranks received the same rows in the same order
         for k in ("states", "players", "pi", "z"):
             np.testing.assert_array_equal(a[k], b[k])
+
+
+def _nccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.pop("CARO_DIST_BACKEND", None)
+    from caro_ai_amd import parallel
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    parallel.is_dist = lambda: True  # a one-rank group: run the collectives anyway
+    t = _fake_tuples(0, 37, KW=1, A=7)
+    t = {k: v.cuda() for k, v in t.items()}
+    tg = parallel.TupleGatherer(every=2)
+    assert tg.push(t) is None
+    out = tg.push({k: v[:5] for k, v in t.items()})
+    ok = (out["z"].shape[0] == 42 and out["states"].is_cuda and torch.equal(out["states"][:37], t["states"])
+          and torch.equal(out["pi"][:37], t["pi"].float()) and torch.equal(out["z"][37:], t["z"][:5])
+          and torch.equal(out["players"][:37], t["players"]))
+    g = parallel.gather_tuples(t)
+    ok = ok and g["z"].shape[0] == 37 and torch.equal(g["pi"], t["pi"].float())
+    s = parallel.allreduce_sum(torch.tensor([3.0, 4.0], dtype=torch.float64, device="cuda"))
+    m = parallel.allreduce_max(torch.tensor([7.5], dtype=torch.float64, device="cuda"))
+    ok = ok and s.tolist() == [3.0, 4.0] and m.item() == 7.5
+    dist.barrier()
+    torch.cuda.synchronize()
+    q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_exchange_code_runs_on_rccl_with_device_tensors():
+    """The collectives of parallel.py on the nccl (= RCCL) backend with device tensors: a one-rank group is what a
+    1-GPU box can offer, it still runs all_gather_into_tensor / all_reduce / barrier through RCCL with the dtypes
+    and shapes the N > 1 bench uses (int64 header, uint8 payload, float64 counters)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=300) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0
