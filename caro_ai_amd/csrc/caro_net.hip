@@ -621,30 +621,47 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
     L = counts[which];
     row0 = which ? counts[0] : 0;
     board0 = blockIdx.x * p0.TB;
-    // Launch quantisation: one round of the chip holds ncu full tiles.  When a launch overflows it by a little,
-    // the overflow is cut into SMALLER tiles whose K loop is split over the waves (4-way: TB4 boards, 2-way: TB2
-    // boards per workgroup) so that the second round lasts a third / half as long; workgroups [0, ncu) stay full.
+    // Tile size by launch size.  A full tile is TB boards (128 GEMM rows); smaller tiles split the K loop over the
+    // waves instead (2-way: TB2 boards, 0.6 of a full tile's time; 4-way: TB4 boards, 0.4).  One round of the chip
+    // holds ncu workgroups, so
+    //   L <= ncu * TB4 / ncu * TB2 : every tile is a 4-way / 2-way tile (small launches finish sooner);
+    //   L a little above one round of full tiles: workgroups [0, ncu) stay full, the overflow goes into small
+    //   tiles and the second round is short;
+    //   otherwise full tiles.
     const int full = p0.ncu * p0.TB;
-    if (L > full && p0.ncu > 0) {
-      const int over = L - full;
-      if (p0.TB4 > 0 && over <= p0.ncu * p0.TB4) ks = 4;
-      else if (p0.TB2 > 0 && over <= p0.ncu * p0.TB2) ks = 2;
+    if (p0.ncu > 0) {
+      if (p0.TB4 > 0 && L <= p0.ncu * p0.TB4) ks = 4;
+      else if (p0.TB2 > 0 && L <= p0.ncu * p0.TB2) ks = 2;
       if (ks > 1) {
-        if ((int)blockIdx.x < p0.ncu) {
-          ks = 1;
-        } else {
-          nb_cap = ks == 4 ? p0.TB4 : p0.TB2;
-          board0 = full + ((int)blockIdx.x - p0.ncu) * nb_cap;
+        nb_cap = ks == 4 ? p0.TB4 : p0.TB2;
+        board0 = (int)blockIdx.x * nb_cap;
+      } else if (L > full) {
+        const int over = L - full;
+        if (p0.TB4 > 0 && over <= p0.ncu * p0.TB4) ks = 4;
+        else if (p0.TB2 > 0 && over <= p0.ncu * p0.TB2) ks = 2;
+        if (ks > 1) {
+          if ((int)blockIdx.x < p0.ncu) {
+            ks = 1;
+          } else {
+            nb_cap = ks == 4 ? p0.TB4 : p0.TB2;
+            board0 = full + ((int)blockIdx.x - p0.ncu) * nb_cap;
+          }
         }
       }
     }
   } else {
-    const int L0 = counts[0];
-    const int t0 = (L0 + p0.TB - 1) / p0.TB;
+    // two nets in one launch: the tile size follows the sum (one workgroup of slack: each class rounds up)
+    const int L0 = counts[0], L1 = counts[1];
+    if (p0.ncu > 1) {
+      if (p0.TB4 > 0 && L0 + L1 <= (p0.ncu - 1) * p0.TB4) ks = 4;
+      else if (p0.TB2 > 0 && L0 + L1 <= (p0.ncu - 1) * p0.TB2) ks = 2;
+      if (ks > 1) nb_cap = ks == 4 ? p0.TB4 : p0.TB2;
+    }
+    const int t0 = (L0 + nb_cap - 1) / nb_cap;
     second = (int)blockIdx.x >= t0;
-    L = second ? counts[1] : L0;
+    L = second ? L1 : L0;
     row0 = second ? (row1 >= 0 ? row1 : L0) : 0;
-    board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
+    board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * nb_cap;
   }
   if (board0 >= L) return;
   const NetParams p = second ? p1 : p0;
@@ -1015,12 +1032,20 @@ static int nfail(int code, const std::string& m) {
 // the overflow in split tiles -- never more than 2 * ncu of those, see k_net_forward_w
 static unsigned net_grid(const caro_net* n, int64_t max_rows) {
   int64_t grid = (max_rows + n->p.TB - 1) / n->p.TB;
-  const int64_t full = (int64_t)n->p.ncu * n->p.TB;
-  const int tbmin = n->p.TB4 > 0 ? n->p.TB4 : n->p.TB2;
-  if (n->p.ww && n->p.ncu > 0 && tbmin > 0 && max_rows > full) {
-    int64_t split = n->p.ncu + (max_rows - full + tbmin - 1) / tbmin;
-    if (split > 2 * (int64_t)n->p.ncu) split = 2 * (int64_t)n->p.ncu;
-    if (split > grid) grid = split;
+  if (n->p.ww && n->p.ncu > 0) {  // the kernel picks the tile size from L <= max_rows: cover every choice it can make
+    const int64_t ncu = n->p.ncu, full = ncu * n->p.TB;
+    const int tbs[2] = {n->p.TB4, n->p.TB2};
+    for (int tb : tbs) {
+      if (tb <= 0) continue;
+      int64_t small = (max_rows + tb - 1) / tb;  // every tile small (L <= ncu * tb)
+      if (small > ncu) small = ncu;
+      if (small > grid) grid = small;
+      if (max_rows > full) {                     // ncu full tiles + the overflow in small tiles
+        int64_t split = ncu + (max_rows - full + tb - 1) / tb;
+        if (split > 2 * ncu) split = 2 * ncu;
+        if (split > grid) grid = split;
+      }
+    }
   }
   return (unsigned)grid;
 }
@@ -1210,7 +1235,7 @@ int caro_net_forward_pair_at(caro_net* n0, caro_net* n1, const float* planes_dev
   if (max_rows <= 0) return 0;
   if ((n0->p.w3 == nullptr) != (n1->p.w3 == nullptr) || (n0->p.ww == nullptr) != (n1->p.ww == nullptr))
     return nfail(CARO_E_INVAL, "nets differ in arithmetic mode");
-  const unsigned grid = (unsigned)((max_rows + n0->p.TB - 1) / n0->p.TB + 1);  // +1: each class rounds up
+  const unsigned grid = net_grid(n0, max_rows) + 1;  // +1: each class rounds up
   if (n0->p.w3)
     hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n0->p, n1->p,
                        planes_dev, counts_dev, 2, (int)row1_base, probs_dev, values_dev);

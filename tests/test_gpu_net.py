@@ -104,6 +104,29 @@ def test_winograd_net_overflow_tiles(shape, A, weights, L):
     hn.close()
 
 
+@pytest.mark.parametrize("L", [255, 256, 257, 767, 768, 769, 1500, 1536])
+def test_winograd_net_tile_size_boundaries(L):
+    """k_net_forward_w picks its tile size from the launch size (4-way K-split tiles up to 256 boards, 2-way up
+    to 768, full tiles above): every size is the same function."""
+    from caro_ai_amd.net_hip import HipNet
+    net = _net((2, 6, 7), 7, "best_026_12000.dat")
+    x = _boards(L, (2, 6, 7), 1000 + L)
+    with torch.no_grad():
+        lg, vl = net(x)
+        p_ref = torch.softmax(lg, dim=1)
+        lg64, _ = net.double()(x.double())
+        p64 = torch.softmax(lg64, dim=1)
+    net.float()
+    hn = HipNet(net, "cuda:0", mode="f32w")
+    p, v = hn(x.to("cuda:0"))
+    torch.cuda.synchronize()
+    e_hip = (p.cpu().double() - p64).abs().max().item()
+    e_ref = (p_ref.double() - p64).abs().max().item()
+    assert e_hip < max(4 * e_ref, 1e-6), (e_hip, e_ref)
+    assert (p.cpu() - p_ref).abs().max().item() < 3e-4 and (v.cpu() - vl[:, 0]).abs().max().item() < 1e-4
+    hn.close()
+
+
 def test_hip_net_device_count_and_second_net_offset():
     """rows come from counts on the device: which = 1 starts at counts[0]."""
     from caro_ai_amd.net_hip import HipNet
