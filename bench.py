@@ -6,16 +6,19 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one move of every one of the G concurrent games on a rank: 25
-search minibatches (select -> net forward -> expand+backup), the ply itself,
-and the drain / recycling of finished games (plus, for N > 1, the all-gather of
-the drained (s, pi, z) tuples).  value = node-expansions (reference:
-`_create_node` calls, lib/mcts.py:178-190 = train.py's "leaves") summed over
-ranks / max-over-ranks wall time of the K timed steps.
+search minibatches (fused tree kernel -> net forward), the ply itself, and the
+drain / recycling of finished games (plus, for N > 1, the all-gather of the
+drained (s, pi, z) tuples).  value = node-expansions (reference: `_create_node`
+calls, lib/mcts.py:178-190 = train.py's "leaves") summed over ranks /
+max-over-ranks wall time of the K timed steps.
 
-One JSON line on stdout (rank 0).  `roofline` is the select kernel (HIP events
-on its launch stream, inside the timed region); `cpu_baseline` is the oracle
-(CPU port of the reference algorithm) driving the same net on one host core for
-a bounded sample, rank 0, N = 1 only.
+One JSON line on stdout (rank 0).  `roofline` is the dominant kernel (the fused
+net forward; HIP events on its launch stream, inside the timed region),
+`roofline_tree` the tree kernel; `cpu_baseline` is the oracle (CPU port of the
+reference algorithm) driving the same net on the host cores for a bounded
+sample, rank 0, N = 1 only.  At N = 1 the line also carries `config4` and
+`config5`: short legs of BASELINE.json's 15x15 and arena configurations, run in
+the same process after the headline loop (each with its own value / roofline).
 """
 import argparse
 import json
@@ -34,6 +37,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
 MFMA_BF16_PEAK_TFS = 2500.0 # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+PMC_FILE = os.path.join("profiles", "pmc_r02.json")
+CPU_RATIO_FILE = os.path.join("profiles", "cpu_ratio_r02.json")
+NET_KERNEL = {"hip": "k_net_forward", "hipw": "k_net_forward_w", "hip3x": "k_net_forward_3x"}
 
 
 def host_cores():
@@ -55,10 +61,9 @@ def host_cores():
 
 
 def load_pmc():
-    """HBM bytes per launch from the committed PMC passes (profiles/pmc_r01.json), keyed by kernel."""
-    path = os.path.join(ROOT, "profiles", "pmc_r01.json")
+    """HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of this command), by kernel"""
     try:
-        return {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(path))["kernels"].items()}
+        return {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(os.path.join(ROOT, PMC_FILE)))["kernels"].items()}
     except Exception:
         return {}
 
@@ -74,6 +79,7 @@ def load_net(game, device, weights):
     return net.to(device).eval(), tag
 
 
+# ------------------------------------------------------------------ CPU baseline
 def _cpu_worker(args):
     """one host core: the oracle (oracle/caro_oracle.c) playing whole games with the same net,
     torch CPU float32 forward, 1 thread, for ~`seconds`"""
@@ -120,11 +126,233 @@ def cpu_baseline(game_name, S, B, sbt0, weights, seconds, procs):
     value = sum(r[1] / r[5] for r in res)
     sims = sum(r[2] for r in res)
     rows, calls = sum(r[3] for r in res), sum(r[4] for r in res)
-    return {"value": value, "unit": "node-expansions/s", "cores": procs, "kind": "port",
-            "per_core": value / procs,
-            "sample": "%d whole games, %d sims, %.1f s wall on %d single-threaded processes, oracle/caro_oracle.c + "
-                      "torch CPU fp32 forward (eval-mode BN, %.2f rows/net call)"
-                      % (games, sims, max(r[5] for r in res), procs, rows / max(1, calls))}
+    out = {"value": value, "unit": "node-expansions/s", "cores": procs, "kind": "port",
+           "per_core": value / procs,
+           "sample": "%d whole games, %d sims, %.1f s wall on %d single-threaded processes, oracle/caro_oracle.c + "
+                     "torch CPU fp32 forward (eval-mode BN, %.2f rows/net call)"
+                     % (games, sims, max(r[5] for r in res), procs, rows / max(1, calls))}
+    try:  # how the port relates to the reference's own Python (both timed on one core of the build container)
+        out["ratio_vs_reference"] = json.load(open(os.path.join(ROOT, CPU_RATIO_FILE)))
+    except Exception:
+        out["ratio_vs_reference"] = None
+    return out
+
+
+# ------------------------------------------------------------------ one timed configuration
+class Leg:
+    """One BASELINE.json configuration: engine + nets + the move loop."""
+
+    def __init__(self, args, game_name, G, S, B, arena, rank, world, device, evict=None, node_cap=0):
+        from caro_ai_amd import parallel
+        from caro_ai_amd.engine import SelfPlayEngine, StreamedSelfPlay, torch_evaluator
+        from caro_ai_amd.lib.game.connect_four import ConnectFour
+        from caro_ai_amd.lib.game.tictactoe import TicTacToe
+        from caro_ai_amd.lib.model import FoldedNet, GemmNet
+        self.args, self.game_name, self.G, self.S, self.B, self.arena = args, game_name, G, S, B, arena
+        self.rank, self.world, self.device = rank, world, device
+        if game_name == "c4":
+            self.game, weights, self.sbt0 = ConnectFour(), args.weights, 10
+        else:
+            self.game, weights, self.sbt0 = TicTacToe(15, 5), None, 10
+        net, self.wtag = load_net(self.game, device, weights)
+        extra = {}
+        if node_cap:
+            extra["node_cap"] = node_cap
+        self.evict = int(game_name == "gomoku15") if evict is None or evict < 0 else evict
+        if self.evict:
+            extra["evict"] = True
+            extra.setdefault("node_cap", 4096)
+        if arena:
+            assert game_name == "c4" and args.net in NET_KERNEL
+            self.sbt0 = 0
+            net2, wtag2 = load_net(self.game, device, os.path.join(os.path.dirname(weights), "best_025_10600.dat"))
+            self.wtag += " vs " + wtag2
+            extra.update(n_stores=2, first_player_mode=2)
+        self.is_hip = args.net in NET_KERNEL
+        self.hipnet = None
+        if self.is_hip:
+            from caro_ai_amd.net_hip import HipNet
+            mode = {"hip": "f32", "hipw": "f32w", "hip3x": "3xbf16"}[args.net]
+            self.hipnet = HipNet(net, str(device), mode=mode)
+            hipnets = [self.hipnet] + ([HipNet(net2, str(device), mode=mode)] if arena else [])
+            make_evaluators = lambda: list(hipnets)
+        else:
+            fnet = {"gemm": GemmNet, "folded": FoldedNet, "net": lambda n: n}[args.net](net).to(device).eval()
+            make_evaluators = lambda: [torch_evaluator(fnet, form="net")]
+        self.n_streams = args.streams if self.is_hip else 1
+        common = dict(max_batch=B, steps_before_tau_0=self.sbt0, seed=0, device=str(device), searches_hint=S)
+        # a small copy of the same configuration: played to completion before the clock starts, it takes the
+        # first-use costs (code objects, torch's clone / cat / cast kernels, allocator growth of the drain path)
+        self._warm = SelfPlayEngine(self.game, 16, evaluators=make_evaluators(), uid_base=1 << 40, uid_stride=16,
+                                    **{**common, **extra, "searches_hint": 2})
+        if self.n_streams > 1:
+            self.eng = StreamedSelfPlay(self.game, G, make_evaluators, n_streams=self.n_streams,
+                                        partition_cus=bool(args.stream_mask), **common, **extra,
+                                        **parallel.shard(G, rank, world))
+        else:
+            self.eng = SelfPlayEngine(self.game, G, evaluators=make_evaluators(), **common, **extra,
+                                      **parallel.shard(G, rank, world))
+        self.gatherer = parallel.TupleGatherer(every=args.gather_every)
+        self.n_tuples = 0
+
+    def _count(self, d):
+        if d is not None:
+            self.n_tuples += int(d["z"].shape[0])
+
+    def prewarm(self, moves=48):
+        """fixed number of moves (every rank runs the same collectives), 2 x B sims each: games end and drain"""
+        from caro_ai_amd import parallel
+        tg = parallel.TupleGatherer(every=2)
+        w = self._warm
+        for _ in range(moves):
+            w.search(2, self.B)
+            w.step()
+            self._count(tg.push(w.drain(recycle=True)))
+        self._count(tg.flush())
+        w.counters()
+        w.close()
+        self._warm = None
+
+    def one_step(self):
+        if self.n_streams > 1:
+            d = self.eng.move(self.S, self.B)  # host-pipelined over the parts: drains the previous move of each part
+        else:
+            self.eng.search(self.S, self.B)
+            self.eng.step()
+            d = self.eng.drain(recycle=True)
+        self._count(self.gatherer.push(d))
+
+    def barrier(self):
+        if self.n_streams > 1:
+            self._count(self.gatherer.push(self.eng.flush()))  # the last enqueued move belongs to the timed region
+        self._count(self.gatherer.flush())
+        torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(self.device)
+
+    def run(self, steps, warmup, profile=True, label="bench"):
+        from caro_ai_amd import parallel
+        rank = self.rank
+        self.prewarm()
+        if profile:
+            self.eng.profile(True)  # on from the warm-up: the event pool is created before the clock starts
+        for i in range(warmup):
+            self.one_step()
+            if rank == 0 and i % 5 == 0:
+                print("[%s] warmup step %d" % (label, i), file=sys.stderr, flush=True)
+        self.barrier()
+        c0 = self.eng.counters()
+        if profile:
+            self.eng.profile_read(reset=True)
+        self.n_tuples = 0
+        stamps = []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.one_step()
+            stamps.append(time.perf_counter())
+        self.barrier()
+        dt = time.perf_counter() - t0
+        c1 = self.eng.counters()
+        prof = self.eng.profile_read(reset=True) if profile else None
+        self.eng.profile(False)
+        if rank == 0:  # host-side step times (each ends with the drain's sync): shows where a slow step sits
+            ms = np.diff(np.array([t0] + stamps)) * 1e3
+            print("[%s] ms per step: " % label + " ".join("%.2f" % x for x in ms) + " | closing barrier %.2f"
+                  % ((t0 + dt - stamps[-1]) * 1e3), file=sys.stderr, flush=True)
+        delta = {k: c1[k] - c0[k] for k in c1}
+        tot = torch.tensor([delta["expansions"], delta["sims"], delta["levels"], delta["plies"], delta["finished"]],
+                           dtype=torch.float64, device=self.device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=self.device)
+        parallel.allreduce_sum(tot)
+        parallel.allreduce_max(tmax)
+        return self._report(steps, warmup, float(tmax.item()), [float(x) for x in tot.tolist()], delta, prof)
+
+    def _report(self, steps, warmup, dt, tot, delta, prof):
+        args, game, G, S, B = self.args, self.game, self.G, self.S, self.B
+        exp_all, sims_all, levels_all, plies_all, fin_all = tot
+        n_streams = self.n_streams
+        pmc = load_pmc() if self.game_name == "c4" and G == 1024 and not self.arena else {}
+        A, KW, HW = game.action_space, game.key_words, game.obs_shape[1] * game.obs_shape[2]
+        bytes_per_level = 12 * A + 8 * KW + 28            # SURVEY.md 8(d): N,Q,P rows + key probe + backup RMW
+        bytes_per_exp = 16 * HW + 20 * A + 8 * KW + 12    # SURVEY.md 8(d)
+        # FLOPs of one leaf through lib/model.py Net (2 x MAC): conv_in, 5 residual 3x3 convs, 1x1 heads, FC heads
+        flops_per_leaf = 2.0 * (HW * 64 * 18 + 5 * HW * 64 * 576 + HW * 3 * 64 + 20 * HW + 20 + 2 * HW * A)
+        traffic_note = ("HBM bytes per launch from %s (separate rocprofv3 --pmc passes of this command, corrected as "
+                        "MI355X_MICROARCH.md prescribes); not measured in this run" % PMC_FILE)
+        kernel_us = 0.0
+        roofline = roofline_tree = None
+        if prof is not None and prof["select"][1] > 0:
+            ms, n = prof["select"]
+            avg_s = ms * 1e-3 / n        # timed on a sample of the launches (every 12th minibatch, all indices equally)
+            n_launches = steps * S * n_streams
+            levels_per_launch = delta["levels"] / n_launches
+            achieved = levels_per_launch * bytes_per_level / avg_s / 1e9
+            fused = prof.get("compact", (0, 0))[1] == 0
+            tname = "k_tree" if fused else "k_select"
+            others = {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in prof.items() if k not in ("select", "net")}
+            roofline_tree = {"bound": "hbm", "kernel": tname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(tname),
+                             "traffic_source": traffic_note if pmc.get(tname) else None,
+                             "avg_launch_us": avg_s * 1e6, "launches": n_launches, "launches_timed": n,
+                             "levels_per_launch": levels_per_launch, "bytes_per_level": bytes_per_level,
+                             "other_kernels_us": others}
+            kernel_us += S * avg_s * 1e6 + sum(v for v in others.values() if v)
+        if prof is not None and prof.get("net", (0, 0))[1] > 0:
+            ms, n = prof["net"]
+            avg_s = ms * 1e-3 / n
+            leaves_per_launch = delta["expansions"] / (steps * S * n_streams)
+            achieved = leaves_per_launch * flops_per_leaf / avg_s / 1e12
+            # hip3x issues 6 bf16 MFMA flops per algorithmic flop: priced against the dense bf16 peak / 6
+            peak = MFMA_F32_PEAK_TFS if args.net != "hip3x" else MFMA_BF16_PEAK_TFS / 6.0
+            kname = NET_KERNEL[args.net]
+            roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                        "frac": achieved / peak, "traffic": pmc.get(kname),
+                        "traffic_source": traffic_note if pmc.get(kname) else None,
+                        "avg_launch_us": avg_s * 1e6, "launches_timed": n, "leaves_per_launch": leaves_per_launch,
+                        "flops_per_leaf": flops_per_leaf}
+            if args.net == "hipw":
+                # the Winograd form issues 2/3 of the 3x3-conv multiplies: what the MFMA pipe itself executes
+                # (60 taps x 32 MFMAs x 8 waves x 4096 flop per workgroup of TB boards, padding included)
+                tb = self.hipnet.L.caro_net_boards_per_workgroup(self.hipnet.h)
+                issued = math.ceil(leaves_per_launch / tb) * 60 * 32 * 8 * 4096.0 / avg_s / 1e12
+                roofline["note"] = ("achieved = algorithmic (direct-convolution) flops per launch / launch time; "
+                                    "mfma_issued = flops the MFMA pipe executes in the F(2,3) form; the PMC MFMA-busy "
+                                    "fraction of the same kernel is in " + PMC_FILE)
+                roofline["mfma_issued"] = {"achieved": issued, "frac": issued / peak}
+            kernel_us += S * avg_s * 1e6
+        if roofline is None:  # torch evaluators: the net is not our kernel; the tree walk is the dominant own kernel
+            roofline = roofline_tree
+        ms_per_step = dt * 1e3 / steps
+        what = "arena matches (two nets, one tree per player)" if self.arena else "self-play games"
+        board = "Connect4 6x7" if self.game_name == "c4" else "m,n,k 15x15 k=5"
+        netdesc = {"hip": "fused HIP MFMA kernel", "hipw": "fused HIP MFMA kernel, 3x3 convs in row-Winograd F(2,3) form,",
+                   "hip3x": "fused HIP kernel, 3x3 convs as 3-way split bf16 MFMA with f32 accumulate,",
+                   "gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net]
+        return {
+            "value": exp_all / dt, "unit": "node-expansions/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": ms_per_step,
+            "data": "synthetic (self-play from empty boards; net weights: %s)" % self.wtag,
+            "config": {"workload": "%s %d concurrent %s/GPU, %dx%d = %d sims/move, tau=1 for %d plies"
+                                   % (board, G, what, S, B, S * B, self.sbt0),
+                       "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py Net, %s fp32" % netdesc,
+                       "streams_per_gpu": n_streams,
+                       "parallelism": "games sharded x%d, tuples all-gathered every %d moves"
+                                      % (self.world, args.gather_every)},
+            "per_gpu": exp_all / dt / self.world,
+            "sims_per_s": sims_all / dt, "plies_per_s": plies_all / dt, "games_per_s": fin_all / dt,
+            "net_rows_per_s": exp_all / dt, "mean_depth": levels_all / max(1.0, sims_all),
+            "expansions_per_sim": exp_all / max(1.0, sims_all),
+            "algorithmic_GBps": (levels_all * bytes_per_level + exp_all * bytes_per_exp) / dt / 1e9,
+            "overflows": delta["overflows"], "evict": bool(self.evict),
+            # per step: the kernels' own time (HIP events, sampled) against the wall clock
+            "kernel_ms_per_step": kernel_us / 1e3 if kernel_us else None,
+            "idle_frac": (1.0 - kernel_us / 1e3 / ms_per_step) if kernel_us else None,
+            "roofline": roofline, "roofline_tree": roofline_tree,
+        }
+
+    def close(self):
+        self.eng.close()
 
 
 def main():
@@ -158,16 +386,15 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=0, help="host cores for the CPU baseline (0 = all this process may use: affinity and cgroup quota, capped at 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the kernels")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the config4 (15x15) / config5 (arena) legs that follow the headline loop at N = 1")
     args = ap.parse_args()
 
     from caro_ai_amd import parallel
-    from caro_ai_amd.engine import SelfPlayEngine, StreamedSelfPlay, torch_evaluator
-    from caro_ai_amd.lib.game.connect_four import ConnectFour
-    from caro_ai_amd.lib.game.tictactoe import TicTacToe
-    from caro_ai_amd.lib.model import FoldedNet, GemmNet
 
     # CPU baseline first (N = 1 only): it forks worker processes, which must happen before the GPU is touched
     cpu_line = None
+    headline = args.game == "c4" and not args.arena
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and not args.arena:
         procs = args.cpu_procs or min(32, host_cores())
         w = args.weights if args.game == "c4" else None
@@ -180,178 +407,39 @@ def main():
     device = torch.device("cuda", 0 if os.environ.get("CARO_SHARE_GPU") else local_rank)
     torch.cuda.set_device(device)
 
-    if args.game == "c4":
-        game, weights, sbt0 = ConnectFour(), args.weights, 10
-    else:
-        game, weights, sbt0 = TicTacToe(15, 5), None, 10
-    net, wtag = load_net(game, device, weights)
-    G, S, B = args.games, args.searches, args.batch
-    extra = {}
-    if args.node_cap:
-        extra["node_cap"] = args.node_cap
-    evict = args.evict if args.evict >= 0 else int(args.game == "gomoku15")
-    if evict:
-        extra["evict"] = True
-        extra.setdefault("node_cap", 4096)
-    if args.arena:
-        assert args.game == "c4" and args.net in ("hip", "hipw", "hip3x")
-        sbt0 = 0
-        net2, wtag2 = load_net(game, device, os.path.join(os.path.dirname(weights), "best_025_10600.dat"))
-        wtag = wtag + " vs " + wtag2
-        extra.update(n_stores=2, first_player_mode=2)
-    is_hip = args.net in ("hip", "hipw", "hip3x")
-    if is_hip:
-        from caro_ai_amd.net_hip import HipNet
-        mode = {"hip": "f32", "hipw": "f32w", "hip3x": "3xbf16"}[args.net]
-        hipnet = HipNet(net, str(device), mode=mode)
-        hipnets = [hipnet] + ([HipNet(net2, str(device), mode=mode)] if args.arena else [])
-        make_evaluators = lambda: list(hipnets)
-    else:
-        fnet = {"gemm": GemmNet, "folded": FoldedNet, "net": lambda n: n}[args.net](net).to(device).eval()
-        make_evaluators = lambda: [torch_evaluator(fnet, form="net")]
-    n_streams = args.streams if is_hip else 1
-    if n_streams > 1:
-        eng = StreamedSelfPlay(game, G, make_evaluators, n_streams=n_streams, partition_cus=bool(args.stream_mask),
-                               max_batch=B, steps_before_tau_0=sbt0,
-                               seed=0, device=str(device), searches_hint=S, **extra, **parallel.shard(G, rank, world))
-    else:
-        eng = SelfPlayEngine(game, G, evaluators=make_evaluators(), max_batch=B, steps_before_tau_0=sbt0,
-                             seed=0, device=str(device), searches_hint=S, **extra, **parallel.shard(G, rank, world))
+    leg = Leg(args, args.game, args.games, args.searches, args.batch, args.arena, rank, world, device,
+              evict=args.evict, node_cap=args.node_cap)
+    res = leg.run(args.steps, args.warmup, profile=not args.no_profile)
+    leg.close()
 
-    n_tuples = 0
-    # N > 1: tuples wait on the device and are all-gathered every 8th move (and at the end of the timed region)
-    gatherer = parallel.TupleGatherer(every=args.gather_every)
-
-    def count(d):
-        nonlocal n_tuples
-        if d is not None:
-            n_tuples += int(d["z"].shape[0])
-
-    def one_step():
-        if n_streams > 1:
-            d = eng.move(S, B)      # host-pipelined over the parts: drains the previous move of each part
-        else:
-            eng.search(S, B)
-            eng.step()
-            d = eng.drain(recycle=True)
-        count(gatherer.push(d))
-
-    def barrier():
-        if n_streams > 1:
-            count(gatherer.push(eng.flush()))  # the last enqueued move of every part belongs to the timed region
-        count(gatherer.flush())
-        torch.cuda.synchronize(device)
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize(device)
-
-    for i in range(args.warmup):
-        one_step()
-        if rank == 0 and i % 5 == 0:
-            print("[bench] warmup step %d" % i, file=sys.stderr, flush=True)
-    barrier()
-    c0 = eng.counters()
-    if not args.no_profile:
-        eng.profile(True)
-        eng.profile_read(reset=True)
-    n_tuples = 0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step()
-        if rank == 0 and i % 10 == 0:
-            print("[bench] step %d" % i, file=sys.stderr, flush=True)
-    barrier()
-    dt = time.perf_counter() - t0
-    c1 = eng.counters()
-    prof = eng.profile_read(reset=True) if not args.no_profile else None
-    eng.profile(False)
-
-    delta = {k: c1[k] - c0[k] for k in c1}
-    tot = torch.tensor([delta["expansions"], delta["sims"], delta["levels"], delta["plies"], delta["finished"],
-                        delta["expansions"]], dtype=torch.float64, device=device)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    parallel.allreduce_sum(tot)
-    parallel.allreduce_max(tmax)
-    dt_max = float(tmax.item())
-    exp_all, sims_all, levels_all, plies_all, fin_all, rows_all = [float(x) for x in tot.tolist()]
+    extras = {}
+    if world == 1 and headline and not args.no_extra_configs and args.net in NET_KERNEL and args.streams == 1:
+        # BASELINE.json configs 5 and 4 at full size, a few moves each (parity of both is tests/ business)
+        for key, spec, st, wu in (("config5", dict(game_name="c4", G=512, S=100, B=8, arena=True), 6, 3),
+                                  ("config4", dict(game_name="gomoku15", G=1024, S=50, B=8, arena=False), 2, 1)):
+            try:
+                x = Leg(args, rank=rank, world=world, device=device, **spec)
+                r = x.run(st, wu, profile=not args.no_profile, label=key)
+                x.close()
+                del x
+                torch.cuda.empty_cache()
+                extras[key] = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "data",
+                                                 "sims_per_s", "games_per_s", "mean_depth", "overflows", "evict",
+                                                 "kernel_ms_per_step", "roofline", "roofline_tree")}
+            except Exception as e:  # the headline line must survive a failing side leg
+                extras[key] = {"error": repr(e)}
 
     if rank == 0:
-        pmc = load_pmc() if args.game == "c4" and G == 1024 else {}
-        A, KW, HW = game.action_space, game.key_words, game.obs_shape[1] * game.obs_shape[2]
-        bytes_per_level = 12 * A + 8 * KW + 28            # N,Q,P rows + key probe + backup RMW
-        bytes_per_exp = 16 * HW + 20 * A + 8 * KW + 12
-        # FLOPs of one leaf through lib/model.py Net (2 x MAC): conv_in, 5 residual 3x3 convs, 1x1 heads, FC heads
-        flops_per_leaf = 2.0 * (HW * 64 * 18 + 5 * HW * 64 * 576 + HW * 3 * 64 + 20 * HW + 20 + 2 * HW * A)
-        roofline = roofline_tree = None
-        if prof is not None and prof["select"][1] > 0:
-            ms, n = prof["select"]
-            avg_s = ms * 1e-3 / n               # timed on a sample of the launches (every 12th minibatch, all minibatch indices equally)
-            n_launches = args.steps * S * n_streams
-            levels_per_launch = delta["levels"] / n_launches
-            achieved = levels_per_launch * bytes_per_level / avg_s / 1e9
-            # one net + one wavefront per game: caro_search_batch runs the fused k_tree (expand+backup of the
-            # previous minibatch, select, row reservation + planes); otherwise k_select / k_encode / k_expand_backup
-            fused = prof.get("compact", (0, 0))[1] == 0
-            tname = "k_tree" if fused else "k_select"
-            roofline_tree = {"bound": "hbm", "kernel": tname, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(tname),
-                             "avg_launch_us": avg_s * 1e6, "launches": n_launches, "launches_timed": n,
-                             "levels_per_launch": levels_per_launch, "bytes_per_level": bytes_per_level,
-                             "other_kernels_us": {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in prof.items()
-                                                  if k not in ("select", "net")}}
-        if prof is not None and prof.get("net", (0, 0))[1] > 0:
-            ms, n = prof["net"]
-            avg_s = ms * 1e-3 / n
-            # the net is timed on a sample of the launches; one net launch per select launch
-            leaves_per_launch = delta["expansions"] / (args.steps * S * n_streams)
-            achieved = leaves_per_launch * flops_per_leaf / avg_s / 1e12
-            # hip3x issues 6 bf16 MFMA flops per algorithmic flop: priced against the dense bf16 peak / 6
-            peak = MFMA_F32_PEAK_TFS if args.net != "hip3x" else MFMA_BF16_PEAK_TFS / 6.0
-            kname = {"hip": "k_net_forward", "hipw": "k_net_forward_w", "hip3x": "k_net_forward_3x"}[args.net]
-            roofline = {"bound": "mfma", "kernel": kname,
-                        "achieved": achieved, "peak": peak,
-                        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc.get(kname),
-                        "avg_launch_us": avg_s * 1e6, "launches_timed": n, "leaves_per_launch": leaves_per_launch,
-                        "flops_per_leaf": flops_per_leaf}
-            if args.net == "hipw":
-                # the Winograd form issues 2/3 of the 3x3-conv multiplies: what the MFMA pipe itself executes
-                # (60 taps x 32 MFMAs x 8 waves x 4096 flop per workgroup of TB boards, padding included)
-                tb = hipnet.L.caro_net_boards_per_workgroup(hipnet.h)
-                issued = math.ceil(leaves_per_launch / tb) * 60 * 32 * 8 * 4096.0 / avg_s / 1e12
-                roofline["note"] = ("achieved = algorithmic (direct-convolution) flops per launch / launch time; "
-                                    "mfma_issued = flops the MFMA pipe executes in the F(2,3) form")
-                roofline["mfma_issued"] = {"achieved": issued, "frac": issued / peak}
-        if roofline is None:  # torch evaluators: the net is not our kernel; the tree walk is the dominant own kernel
-            roofline = roofline_tree
-        out = {
-            "metric": "self-play MCTS node-expansions/sec/GPU (Connect4, 200 sims/move); 1->8 GPU scaling"
-            if args.game == "c4" else "self-play MCTS node-expansions/sec/GPU (15x15 k=5)",
-            "value": exp_all / dt_max,
-            "unit": "node-expansions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.net != "hip3x" else "f32 (3x3 conv products as 3-way split bf16, f32 accumulate)",
-            "data": "synthetic (self-play from empty boards; net weights: %s)" % wtag,
-            "config": {"workload": "%s %d concurrent %s/GPU, %dx%d = %d sims/move, tau=1 for %d plies"
-                                   % ("Connect4 6x7" if args.game == "c4" else "m,n,k 15x15 k=5", G,
-                                      "arena matches (two nets, one tree per player)" if args.arena else "self-play games",
-                                      S, B, S * B, sbt0),
-                       "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py Net, %s fp32" % {"hip": "fused HIP MFMA kernel", "hipw": "fused HIP MFMA kernel, 3x3 convs in row-Winograd F(2,3) form,", "hip3x": "fused HIP kernel, 3x3 convs as 3-way split bf16 MFMA with f32 accumulate,", "gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net],
-                       "streams_per_gpu": n_streams,
-                       "parallelism": "games sharded x%d, tuples all-gathered every %d moves" % (world, args.gather_every)},
-            "per_gpu": exp_all / dt_max / world,
-            "sims_per_s": sims_all / dt_max, "plies_per_s": plies_all / dt_max, "games_per_s": fin_all / dt_max,
-            "net_rows_per_s": rows_all / dt_max, "mean_depth": levels_all / max(1.0, sims_all),
-            "expansions_per_sim": exp_all / max(1.0, sims_all),
-            "algorithmic_GBps": (levels_all * bytes_per_level + exp_all * bytes_per_exp) / dt_max / 1e9,
-            "overflows": delta["overflows"], "evict": bool(evict),
-            "roofline": roofline,
-            "roofline_tree": roofline_tree,
-        }
+        out = {"metric": "self-play MCTS node-expansions/sec/GPU (Connect4, 200 sims/move); 1->8 GPU scaling"
+               if args.game == "c4" else "self-play MCTS node-expansions/sec/GPU (15x15 k=5)",
+               "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.net != "hip3x" else "f32 (3x3 conv products as 3-way split bf16, f32 accumulate)"}
+        out.update({k: v for k, v in res.items() if k not in out})
         out["cpu_baseline"] = cpu_line
+        out.update(extras)
         print(json.dumps(out))
-    eng.close()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -85,6 +85,7 @@ struct View {
   int32_t* g_off;
   int32_t* g_tree;
   int32_t* g_class;
+  int32_t* g_pack;      // fused form: unique-leaf count | net class << 8 (what the net kernel's row map reads)
   int32_t* leaf_count;  // [4]: L0, L1, batch of the pending minibatch, -
   unsigned long long* counters;  // [G][C_N] per-game tallies (no atomics on the hot path), summed on read
   unsigned long long* counters_sum;  // [C_N]
@@ -208,13 +209,15 @@ __device__ __forceinline__ void noise_group(uint64_t key, int l, int A, double a
 }
 
 // ------------------------------------------------------------------ select
-// `rows` (fused form, see k_tree): when non-null the block also places its unique leaves itself -- it reserves
-// rows [off, off + nleaf) with one atomicAdd on rows[0] and writes their NN planes (what k_encode does after a
-// grid-wide count in the step-wise form).  Which rows a game gets then depends on arrival order, the value
-// computed for a leaf does not (every row of the net kernel is independent of the others).
+// `rows` (fused form, see k_tree): when non-null the block also places its unique leaves itself, in SLOT rows:
+// the j-th unique leaf of game g goes to row g * B + j of planes / leaf_keys (and its priors / value come back in
+// the same row), so no block needs to know what the others found.  rows[cls] only accumulates the launch's
+// total per net (a sum: the order of the adds does not matter); the net kernel maps its dense tiles onto the
+// slot rows in game order by itself (caro_net.hip tile_rows), which keeps the whole path free of any dependence
+// on block arrival order.  (k_encode produces DENSE rows for the step-wise form instead.)
 template <class GEO>
 __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, const double* __restrict__ noise,
-                                            int32_t* __restrict__ rows, int row1_base, float* __restrict__ planes,
+                                            int32_t* __restrict__ rows, float* __restrict__ planes,
                                             uint64_t* __restrict__ leaf_keys) {
   using R = typename GEO::R;
   using Board = typename R::Board;
@@ -228,12 +231,12 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
   __shared__ int s_first[MAXB];
   __shared__ int s_depth[MAXB];
   __shared__ int s_player[MAXB];
-  __shared__ int s_off;
 
   if (v.done[g]) {
     if (tid == 0) {
       v.g_nleaf[g] = 0;
       v.g_class[g] = 0;
+      if (rows) v.g_pack[g] = 0;
     }
     return;
   }
@@ -445,11 +448,11 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
     ctr[C_LEVELS] += (unsigned long long)levels;
     ctr[C_TERMINALS] += (unsigned long long)term;
     ctr[C_DROPPED] += (unsigned long long)drop;
-    if (rows) {  // two nets: the second net's rows live at row1_base + (index inside its class)
+    if (rows) {
       const int cls = v.n_nets == 2 ? player0 : 0;
-      const int off = (nleaf ? atomicAdd(rows + cls, nleaf) : 0) + (cls ? row1_base : 0);
-      v.g_off[g] = off;
-      s_off = off;
+      if (nleaf) atomicAdd(rows + cls, nleaf);
+      v.g_off[g] = g * B;
+      v.g_pack[g] = nleaf | (cls << 8);
     }
   }
   if (rows) {
@@ -458,7 +461,7 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
     int local = 0;
     for (int bb = 0; bb < B; ++bb) {
       if (!s_first[bb]) continue;
-      const int rowi = s_off + local++;
+      const int rowi = g * B + local++;
       Board brd;
 #pragma unroll
       for (int w = 0; w < KW; ++w) brd.w[w] = s_key[bb][w];
@@ -472,7 +475,7 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
 
 template <class GEO>
 __global__ void k_select(View v, int B, int mb_index, const double* __restrict__ noise) {
-  select_body<GEO>(v, B, mb_index, noise, nullptr, 0, nullptr, nullptr);
+  select_body<GEO>(v, B, mb_index, noise, nullptr, nullptr, nullptr);
 }
 
 // NN planes of the unique leaves, written as dense rows (rows of net 0 first, then net 1).  Every block
@@ -730,11 +733,11 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
 // minibatch, then the descents of the next one on the updated tree, then row reservation + NN planes -- all
 // per-game work, so one block does it back to back and a minibatch costs two launches (this + the net) instead
 // of four.  rows_cur[0 / 1] count the leaves of this minibatch per net (the net kernel reads them), rows_next is
-// cleared for the launch after this one.
+// cleared for the launch after this one.  Leaves, priors and values travel in slot rows (select_body).
 template <class GEO>
 __global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ noise, const float* __restrict__ probs,
                        const float* __restrict__ values, float* __restrict__ planes, uint64_t* __restrict__ leaf_keys,
-                       int32_t* __restrict__ rows_cur, int32_t* __restrict__ rows_next, int row1_base, int do_expand,
+                       int32_t* __restrict__ rows_cur, int32_t* __restrict__ rows_next, int do_expand,
                        int do_select) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     rows_next[0] = 0;
@@ -749,7 +752,7 @@ __global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ n
     __syncthreads();  // the block's own tree updates are visible to its descents
   }
   if (v.dbg && threadIdx.x == 0) v.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime() - t0;  // expand + backup
-  if (do_select) select_body<GEO>(v, B, mb_index, noise, rows_cur, row1_base, planes, leaf_keys);
+  if (do_select) select_body<GEO>(v, B, mb_index, noise, rows_cur, planes, leaf_keys);
   if (v.dbg && threadIdx.x == 0) v.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime() - t0;  // whole block
 }
 
@@ -1603,7 +1606,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   DA(v.path_len, G * v.maxB);
   DA(v.d_status, G * v.maxB); DA(v.d_value, G * v.maxB); DA(v.d_local, G * v.maxB); DA(v.d_player, G * v.maxB);
   DA(v.d_key, G * v.maxB * KW);
-  DA(v.g_nleaf, G); DA(v.g_off, G); DA(v.g_tree, G); DA(v.g_class, G);
+  DA(v.g_nleaf, G); DA(v.g_off, G); DA(v.g_tree, G); DA(v.g_class, G); DA(v.g_pack, G);
   DA(v.leaf_count, 4);
   DA(v.counters, G * C_N);
   DA(v.counters_sum, C_N);
@@ -1616,6 +1619,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   HIPCHK(hipMemset(v.leaf_count, 0, sizeof(int32_t) * 4));
   HIPCHK(hipMemset(h->rows, 0, sizeof(int32_t) * 8));
   HIPCHK(hipMemset(v.g_nleaf, 0, sizeof(int32_t) * G));
+  HIPCHK(hipMemset(v.g_pack, 0, sizeof(int32_t) * G));
   HIPCHK(hipHostMalloc((void**)&h->pinned, 64, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&h->pinned64, 128, hipHostMallocDefault));
   *out = h;
@@ -1705,7 +1709,6 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
   hipStream_t st = (hipStream_t)stream;
   // one 64-lane wavefront per game: the fused tree kernel (k_tree), two launches per minibatch
   const bool fused = h->fused_ok && batch * variant_lpd(h->var) == 64;
-  const int row1_base = (int)max_rows;  // fused form, two nets: net 1's rows start here (buffers hold 2 * max_rows rows)
   for (int mb = 0; mb < searches; ++mb) {
     // HIP-event timing is SAMPLED: an event pair per kernel costs ~8 % of the step.  Every 12th minibatch of a
     // counter that runs across moves: 12 is coprime to the usual 25 / 20 / 100 searches per move, so every
@@ -1721,7 +1724,7 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
       const int p1 = prof_begin(h, PK_SELECT, st);
       DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(64), 0, st, h->v, batch, mb,
                                           noise ? noise + (size_t)mb * noise_stride : nullptr, probs, values, planes,
-                                          leaf_keys, cur, nxt, row1_base, mb > 0 ? 1 : 0, 1));
+                                          leaf_keys, cur, nxt, mb > 0 ? 1 : 0, 1));
       prof_end(h, p1, st);
       if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree launch failed"); }
     } else {
@@ -1729,8 +1732,11 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
       if (rc) { h->prof_gate = 1; return rc; }
     }
     const int p0 = prof_begin(h, PK_NET, st);
-    if (h->v.n_nets == 2)
-      rc = caro_net_forward_pair_at(net0, net1, planes, counts, fused ? row1_base : -1, max_rows, probs, values, stream);
+    if (fused)
+      rc = caro_net_forward_slots(net0, h->v.n_nets == 2 ? net1 : nullptr, planes, counts, h->v.g_pack, h->v.G, batch,
+                                  probs, values, stream);
+    else if (h->v.n_nets == 2)
+      rc = caro_net_forward_pair_at(net0, net1, planes, counts, -1, max_rows, probs, values, stream);
     else rc = caro_net_forward(net0, planes, counts, 0, max_rows, probs, values, stream);
     prof_end(h, p0, st);
     if (!rc && !fused) rc = caro_expand_backup(h, probs, values, stream);
@@ -1742,7 +1748,7 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
     h->rows_par ^= 1;
     const int p1 = prof_begin(h, PK_EXPAND, st);
     DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(64), 0, st, h->v, batch, searches,
-                                        (const double*)nullptr, probs, values, planes, leaf_keys, cur, nxt, row1_base, 1, 0));
+                                        (const double*)nullptr, probs, values, planes, leaf_keys, cur, nxt, 1, 0));
     prof_end(h, p1, st);
     if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree launch failed"); }
   }

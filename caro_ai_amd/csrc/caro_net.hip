@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "../../include/caro_hip.h"
+#include "../../include/caro_noise.h"
 
 namespace cnet {
 
@@ -80,9 +81,10 @@ __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? 
 constexpr int NT = 512;  // threads per workgroup
 
 // conv_in on the VALU (lib/model.py:24-28 folded): two threads per row, 32 output channels each.
-// `pl0` = planes of this workgroup's first board, `win` = the [9][2][64] weights staged in LDS.
-__device__ __forceinline__ void conv_in_f32(const NetParams& p, const float* __restrict__ pl0, float* act,
-                                            const float* win, int R, int tid) {
+// `planes` = the launch's plane rows, `smap[bi]` = row of this workgroup's board bi (LDS), `win` = the [9][2][64]
+// weights staged in LDS.
+__device__ __forceinline__ void conv_in_f32(const NetParams& p, const float* __restrict__ planes, const int* smap,
+                                            float* act, const float* win, int R, int tid) {
   const int HW = p.HW;
   const float slope = p.slope;
   const int r = tid & 255;
@@ -90,7 +92,7 @@ __device__ __forceinline__ void conv_in_f32(const NetParams& p, const float* __r
   if (r < R) {
     const int bi = r / HW, cell = r - bi * HW;
     const int y = cell / p.W, x = cell - y * p.W;
-    const float* pl = pl0 + (size_t)bi * 2 * HW;
+    const float* pl = planes + (size_t)smap[bi] * 2 * HW;
     float in0[9], in1[9];  // the 18 inputs of this row (statically indexed: stays in registers)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -120,13 +122,16 @@ __device__ __forceinline__ void conv_in_f32(const NetParams& p, const float* __r
 }
 
 // 1x1 heads, the two FC heads, tanh and the softmax (lib/model.py:44-67, lib/mcts.py:216) from the trunk
-// output in `act`; `scratch` = the (now free) weight stage.  probs / values point at this workgroup's first board.
+// output in `act`; `scratch` = the (now free) weight stage.  probs / values are the launch's output rows;
+// `slot_v` = output row of board `tid` (threads tid < nb), re-published through the scratch for the prob rows.
 __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, float* scratch,
-                                          float* __restrict__ probs, float* __restrict__ values, int nb, int R,
-                                          int tid) {
+                                          float* __restrict__ probs, float* __restrict__ values, int slot_v, int nb,
+                                          int R, int tid) {
   const int HW = p.HW;
   const float slope = p.slope;
   float* feat = scratch;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
+  int* omap = reinterpret_cast<int*>(scratch + 768 + 20 * 32 + 1024 + 64);  // [TB] output rows, behind `stat`
+  if (tid < nb) omap[tid] = slot_v;
   {
     const int r = tid;
     if (r < R) {
@@ -175,7 +180,7 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
   if (tid < nb) {
     float s = p.b_v2[0];
     for (int u = 0; u < 20; ++u) s = fmaf(hid[tid * 20 + u], p.w_v2[u], s);
-    values[tid] = tanhf(s);
+    values[slot_v] = tanhf(s);
     float mx = -3.4e38f;
     for (int a = 0; a < p.A; ++a) mx = fmaxf(mx, logit[tid * p.A + a]);
     float sum = 0.f;
@@ -186,8 +191,54 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
   __syncthreads();
   for (int k = tid; k < nb * p.A; k += NT) {
     const int bi = k / p.A;
-    probs[k] = expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
+    probs[(size_t)omap[bi] * p.A + (k - bi * p.A)] = expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
   }
+}
+
+// Where a workgroup's boards come from and go to.  Dense form (gpack == nullptr): board bi of the tile is row
+// base + bi of planes / probs / values.  Slot form (the fused tree kernel, caro_engine.hip k_tree): game g keeps
+// its j-th unique leaf at row g * B + j, gpack[g] = count | net class << 8, and the tile's boards are the
+// leaves of class `cls` number [board0, board0 + nb) in GAME order -- every workgroup finds them itself with a
+// prefix sum over gpack (G ints from L2), so which leaf meets which tile never depends on block arrival order.
+// `sc` = 32 ints of LDS scratch, `smap` = nb ints of LDS; ends with a barrier.
+__device__ __forceinline__ void tile_rows(const int32_t* __restrict__ gpack, int G, int B, int cls, int base,
+                                          int board0, int nb, int* sc, int* smap, int tid) {
+  if (!gpack) {
+    if (tid < nb) smap[tid] = base + tid;
+    __syncthreads();
+    return;
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  const int cpt = (G + NT - 1) / NT;
+  const int g_lo = min(G, tid * cpt), g_hi = min(G, g_lo + cpt);
+  int mine = 0;
+  for (int g = g_lo; g < g_hi; ++g) {
+    const int v = gpack[g];
+    mine += (v >> 8) == cls ? (v & 0xFF) : 0;
+  }
+  int inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) sc[wave] = inc;
+  __syncthreads();
+  int ex = inc - mine;
+  for (int w = 0; w < wave; ++w) ex += sc[w];
+  if (ex < board0 + nb && ex + mine > board0) {
+    for (int g = g_lo; g < g_hi; ++g) {
+      const int v = gpack[g];
+      if ((v >> 8) != cls) continue;
+      const int n = v & 0xFF;
+      for (int j = 0; j < n; ++j) {
+        const int r = ex + j - board0;
+        if (r >= 0 && r < nb) smap[r] = g * B + j;
+      }
+      ex += n;
+    }
+  }
+  __syncthreads();
 }
 
 
@@ -196,7 +247,8 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
 __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p1, const float* __restrict__ planes,
                                                          const int32_t* __restrict__ counts, int which, int row1,
                                                          float* __restrict__ probs, float* __restrict__ values,
-                                                         unsigned long long* __restrict__ stamps) {
+                                                         unsigned long long* __restrict__ stamps,
+                                                         const int32_t* __restrict__ gpack, int gG, int gB) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* act = lds;
   float* wbuf = lds + ACT;
@@ -235,9 +287,11 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
   for (int k = tid; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   // conv_in weights into wbuf: [9][2][64] = 1152 floats
   for (int k = tid; k < 9 * 2 * NF; k += NT) wbuf[k] = p.w_in[k];
-  __syncthreads();
+  int* smap = reinterpret_cast<int*>(wbuf + 1536);  // [TB] plane / output row of every board of this tile
+  tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
 
-  conv_in_f32(p, planes + (size_t)(row0 + board0) * 2 * HW, act, wbuf, R, tid);
+  conv_in_f32(p, planes, smap, act, wbuf, R, tid);
+  const int slot_v = tid < nb ? smap[tid] : 0;
   __syncthreads();
 
   unsigned long long t_trunk0 = 0;
@@ -362,7 +416,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
   // `act` now holds the trunk output; the weight stage is free scratch
-  heads_f32(p, act, wbuf, probs + (size_t)(row0 + board0) * p.A, values + row0 + board0, nb, R, tid);
+  heads_f32(p, act, wbuf, probs, values, slot_v, nb, R, tid);
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
     stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
@@ -609,7 +663,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
                                                            const float* __restrict__ planes,
                                                            const int32_t* __restrict__ counts, int which, int row1,
                                                            float* __restrict__ probs, float* __restrict__ values,
-                                                           unsigned long long* __restrict__ stamps) {
+                                                           unsigned long long* __restrict__ stamps,
+                                                           const int32_t* __restrict__ gpack, int gG, int gB) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* act = lds;
   float* wbuf = lds + ACT;
@@ -677,8 +732,10 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
 
   for (int k = tid; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int k = tid; k < 9 * 2 * NF; k += NT) wbuf[k] = p.w_in[k];
-  __syncthreads();
-  conv_in_f32(p, planes + (size_t)(row0 + board0) * 2 * HW, act, wbuf, R, tid);
+  int* smap = reinterpret_cast<int*>(wbuf + 1536);  // [TB] plane / output row of every board of this tile
+  tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
+  conv_in_f32(p, planes, smap, act, wbuf, R, tid);
+  const int slot_v = tid < nb ? smap[tid] : 0;
   __syncthreads();
   unsigned long long t_trunk0 = 0;
   if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
@@ -694,7 +751,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   else trunk_w<4>(p, act, wbuf, nb, tid);
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
-  heads_f32(p, act, wbuf, probs + (size_t)(row0 + board0) * p.A, values + row0 + board0, nb, R, tid);
+  heads_f32(p, act, wbuf, probs, values, slot_v, nb, R, tid);
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
     stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
@@ -752,7 +809,8 @@ __device__ __forceinline__ void join3x4(uint2 H, uint2 M, uint2 L, float* x) {
 __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParams p1,
                                                             const float* __restrict__ planes,
                                                             const int32_t* __restrict__ counts, int which, int row1,
-                                                            float* __restrict__ probs, float* __restrict__ values) {
+                                                            float* __restrict__ probs, float* __restrict__ values,
+                                                            const int32_t* __restrict__ gpack, int gG, int gB) {
   __shared__ uint4 lds[LDS3_G];
   uint4* wbuf = lds + ACT3_G;
   char* actb = reinterpret_cast<char*>(lds);
@@ -784,7 +842,9 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParam
   for (int k = tid; k < ACT3_G; k += NT) lds[k] = make_uint4(0u, 0u, 0u, 0u);
   float* wf = reinterpret_cast<float*>(wbuf);
   for (int k = tid; k < 9 * 2 * NF; k += NT) wf[k] = p.w_in[k];
-  __syncthreads();
+  int* smap = reinterpret_cast<int*>(wf + 1536);  // [TB] plane / output row of every board of this tile
+  tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
+  const int slot_v = tid < nb ? smap[tid] : 0;
 
   // ---- conv_in (float32 on the VALU), result split into the three planes
   {
@@ -793,7 +853,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParam
     if (r < R) {
       const int bi = r / HW, cell = r - bi * HW;
       const int y = cell / p.W, x = cell - y * p.W;
-      const float* pl = planes + (size_t)(row0 + board0 + bi) * 2 * HW;
+      const float* pl = planes + (size_t)smap[bi] * 2 * HW;
       float in0[9], in1[9];  // the 18 inputs of this row (statically indexed: stays in registers)
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -946,6 +1006,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParam
 
   // ---- heads: reconstruct float32 activations of the row, then as the float32 kernel
   float* feat = reinterpret_cast<float*>(wbuf);  // [3][256]
+  int* omap = reinterpret_cast<int*>(feat + 768 + 20 * 32 + 1024 + 64);  // [TB] output rows, behind `stat`
+  if (tid < nb) omap[tid] = slot_v;
   {
     const int r = tid;
     if (r < R) {
@@ -994,7 +1056,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParam
   if (tid < nb) {
     float s = p.b_v2[0];
     for (int u = 0; u < 20; ++u) s = fmaf(hid[tid * 20 + u], p.w_v2[u], s);
-    values[row0 + board0 + tid] = tanhf(s);
+    values[slot_v] = tanhf(s);
     float mx = -3.4e38f;
     for (int a = 0; a < p.A; ++a) mx = fmaxf(mx, logit[tid * p.A + a]);
     float sum = 0.f;
@@ -1005,7 +1067,56 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParam
   __syncthreads();
   for (int k = tid; k < nb * p.A; k += NT) {
     const int bi = k / p.A;
-    probs[(size_t)(row0 + board0) * p.A + k] = expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
+    probs[(size_t)omap[bi] * p.A + (k - bi * p.A)] = expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
+  }
+}
+
+// ===================================================================================================
+// Table evaluator (caro_net_create_hash): priors and value are exact dyadic float32 functions of a 64-bit
+// hash of the leaf's planes (the arithmetic is integer only, so every implementation of the definition in
+// include/caro_hip.h gives the same bits).  It takes the place of the conv net wherever the search itself is to
+// be checked bit for bit: same launch interface, leaf counts read on device, dense or slot rows.
+// One wavefront per row; 4 rows per workgroup.
+__global__ __launch_bounds__(256) void k_net_hash(int HW2, int A, unsigned long long salt0, unsigned long long salt1,
+                                                  const float* __restrict__ planes,
+                                                  const int32_t* __restrict__ counts, int which, int row1,
+                                                  float* __restrict__ probs, float* __restrict__ values,
+                                                  const int32_t* __restrict__ gpack, int gG, int gB) {
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  long long row;
+  int cls = 0;
+  if (gpack) {  // slot rows: row g * B + j is live when j < count of game g
+    const int g = (int)(w / gB), j = (int)(w - (long long)g * gB);
+    if (g >= gG) return;
+    const int v = gpack[g];
+    if (j >= (v & 0xFF)) return;
+    cls = v >> 8;
+    row = w;
+  } else if (which < 2) {
+    if (w >= counts[which]) return;
+    row = w + (which ? counts[0] : 0);
+    cls = 0;  // a single net: its own salt is salt0
+  } else {
+    const int L0 = counts[0], L1 = counts[1];
+    if (w < L0) { row = w; cls = 0; }
+    else if (w < L0 + L1) { row = (row1 >= 0 ? row1 : L0) + (w - L0); cls = 1; }
+    else return;
+  }
+  const float* pl = planes + (size_t)row * HW2;
+  unsigned long long h = 0;
+  for (int j = lane; j < HW2; j += 64)
+    if (pl[j] != 0.0f) h += caro_mix64(0x5851f42d4c957f2dULL + (unsigned long long)j) | 1ULL;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) h += __shfl_xor(h, m, 64);
+  h += cls ? salt1 : salt0;
+  for (int a = lane; a < A; a += 64) {
+    const unsigned long long ha = caro_mix64(h + 0x9E3779B97F4A7C15ULL * (unsigned long long)(a + 1));
+    probs[(size_t)row * A + a] = (float)(((ha >> 20) & 1023ULL) + 1ULL) / 8192.0f;
+  }
+  if (lane == 0) {
+    const unsigned long long hv = caro_mix64(h ^ 0xA5A5A5A5A5A5A5A5ULL);
+    values[row] = (float)((long long)((hv >> 20) % 2001ULL) - 1000LL) / 1024.0f;
   }
 }
 
@@ -1015,6 +1126,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParam
 extern "C" void caro__set_error(const char* msg);  // caro_engine.hip
 
 struct caro_net {
+  int kind;            // 0: conv net (lib/model.py), 1: table evaluator (k_net_hash)
+  uint64_t salt;       // table evaluator
   cnet::NetParams p;
   float* dev;
   uint4* w3_dev;  // split residual weights (3xbf16 mode), or null
@@ -1070,6 +1183,8 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   if (device_id < 0 || device_id >= ndev) return nfail(CARO_E_INVAL, "device_id out of range");
   if (hipSetDevice(device_id) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
   caro_net* n = new caro_net();
+  n->kind = 0;
+  n->salt = 0;
   n->device = device_id;
   n->w3_dev = nullptr;
   n->ww_dev = nullptr;
@@ -1115,6 +1230,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
  * bf16 MFMA pipe for the 3x3 convolutions (float32 accumulate, error below float32 rounding). */
 int caro_net_enable_3xbf16(caro_net* n, const uint16_t* w3_host, int64_t n_u16) {
   if (!n || !w3_host) return nfail(CARO_E_INVAL, "null argument");
+  if (n->kind != 0) return nfail(CARO_E_STATE, "not a conv net");
   const int64_t want = (int64_t)cnet::NTAPS * cnet::W3_G * 8;
   if (n_u16 != want) return nfail(CARO_E_INVAL, "split weight image has the wrong size");
   if (hipSetDevice(n->device) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
@@ -1130,6 +1246,7 @@ int caro_net_enable_3xbf16(caro_net* n, const uint16_t* w3_host, int64_t n_u16) 
  * The boards-per-workgroup figure may shrink (128 tiles of ceil(H/2) x W per workgroup). */
 int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats) {
   if (!n || !ww_host) return nfail(CARO_E_INVAL, "null argument");
+  if (n->kind != 0) return nfail(CARO_E_STATE, "not a conv net");
   if (n->p.w3) return nfail(CARO_E_STATE, "net is already in 3xbf16 mode");
   const int64_t want = (int64_t)cnet::WTAPS * cnet::WCHUNK;
   if (n_floats != want) return nfail(CARO_E_INVAL, "transformed weight image has the wrong size");
@@ -1201,8 +1318,65 @@ void caro_net_destroy(caro_net* n) {
   if (n->w3_dev) (void)hipFree(n->w3_dev);
   if (n->ww_dev) (void)hipFree(n->ww_dev);
   if (n->wtab_dev) (void)hipFree(n->wtab_dev);
-  (void)hipFree(n->dev);
+  if (n->dev) (void)hipFree(n->dev);
   delete n;
+}
+
+/* table evaluator: see include/caro_hip.h for the definition of P and v */
+int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro_net** out) {
+  if (!out) return nfail(CARO_E_INVAL, "null argument");
+  if (H < 2 || W < 2 || H > 15 || W > 15 || A < 1 || A > 255) return nfail(CARO_E_INVAL, "unsupported board / action count");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return nfail(CARO_E_NODEV, "no HIP device: libcaro_hip needs a GPU (there is no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return nfail(CARO_E_INVAL, "device_id out of range");
+  caro_net* n = new caro_net();
+  memset(&n->p, 0, sizeof n->p);
+  n->kind = 1;
+  n->salt = salt;
+  n->device = device_id;
+  n->dev = nullptr;
+  n->w3_dev = nullptr;
+  n->ww_dev = nullptr;
+  n->wtab_dev = nullptr;
+  n->p.H = H; n->p.W = W; n->p.HW = H * W; n->p.A = A; n->p.TB = 4;
+  *out = n;
+  return 0;
+}
+
+// one launch of whichever kernel serves this pair of nets.  which 0 / 1: net n0 on its class' rows; 2: both.
+// gpack != null: slot rows (caro_net_forward_slots), otherwise dense rows.
+static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev, int which,
+                      int row1, int64_t max_rows, float* probs_dev, float* values_dev, const int32_t* gpack, int G,
+                      int B, unsigned long long* stamps, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n0->kind == 1) {
+    const int64_t waves = gpack ? (int64_t)G * B : max_rows;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    hipLaunchKernelGGL(cnet::k_net_hash, dim3(grid), dim3(256), 0, st, 2 * n0->p.HW, n0->p.A,
+                       (unsigned long long)n0->salt, (unsigned long long)n1->salt, planes_dev, counts_dev, which, row1,
+                       probs_dev, values_dev, gpack, G, B);
+  } else {
+    const unsigned grid = net_grid(n0, max_rows) + (which == 2 ? 1u : 0u);  // +1: each class rounds up
+    if (n0->p.w3)
+      hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
+                         counts_dev, which, row1, probs_dev, values_dev, gpack, G, B);
+    else if (n0->p.ww)
+      hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
+                         counts_dev, which, row1, probs_dev, values_dev, stamps, gpack, G, B);
+    else
+      hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
+                         counts_dev, which, row1, probs_dev, values_dev, stamps, gpack, G, B);
+  }
+  if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "net kernel launch failed");
+  return 0;
+}
+static int pair_ok(const caro_net* n0, const caro_net* n1) {
+  if (n0->p.H != n1->p.H || n0->p.W != n1->p.W || n0->p.A != n1->p.A) return nfail(CARO_E_INVAL, "nets differ in shape");
+  if (n0->kind != n1->kind || (n0->p.w3 == nullptr) != (n1->p.w3 == nullptr) ||
+      (n0->p.ww == nullptr) != (n1->p.ww == nullptr))
+    return nfail(CARO_E_INVAL, "nets differ in kind / arithmetic mode");
+  return 0;
 }
 
 int caro_net_boards_per_workgroup(const caro_net* n) { return n ? n->p.TB : 0; }
@@ -1212,18 +1386,8 @@ int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts
   if (!n || !planes_dev || !counts_dev || !probs_dev || !values_dev) return nfail(CARO_E_INVAL, "null argument");
   if (which != 0 && which != 1) return nfail(CARO_E_INVAL, "which must be 0 or 1");
   if (max_rows <= 0) return 0;
-  const unsigned grid = net_grid(n, max_rows);
-  if (n->p.w3)
-    hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
-                       planes_dev, counts_dev, which, -1, probs_dev, values_dev);
-  else if (n->p.ww)
-    hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
-                       planes_dev, counts_dev, which, -1, probs_dev, values_dev, (unsigned long long*)nullptr);
-  else
-    hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
-                       planes_dev, counts_dev, which, -1, probs_dev, values_dev, (unsigned long long*)nullptr);
-  if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
-  return 0;
+  return net_launch(n, n, planes_dev, counts_dev, which, -1, max_rows, probs_dev, values_dev, nullptr, 0, 0, nullptr,
+                    stream);
 }
 
 /* both nets of an arena in one launch: rows [0, L0) through n0; n1's rows start at row1_base, or at L0 when
@@ -1231,22 +1395,10 @@ int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts
 int caro_net_forward_pair_at(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
                              int64_t row1_base, int64_t max_rows, float* probs_dev, float* values_dev, void* stream) {
   if (!n0 || !n1 || !planes_dev || !counts_dev || !probs_dev || !values_dev) return nfail(CARO_E_INVAL, "null argument");
-  if (n0->p.H != n1->p.H || n0->p.W != n1->p.W || n0->p.A != n1->p.A) return nfail(CARO_E_INVAL, "nets differ in shape");
+  if (int rc = pair_ok(n0, n1)) return rc;
   if (max_rows <= 0) return 0;
-  if ((n0->p.w3 == nullptr) != (n1->p.w3 == nullptr) || (n0->p.ww == nullptr) != (n1->p.ww == nullptr))
-    return nfail(CARO_E_INVAL, "nets differ in arithmetic mode");
-  const unsigned grid = net_grid(n0, max_rows) + 1;  // +1: each class rounds up
-  if (n0->p.w3)
-    hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n0->p, n1->p,
-                       planes_dev, counts_dev, 2, (int)row1_base, probs_dev, values_dev);
-  else if (n0->p.ww)
-    hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n0->p, n1->p,
-                       planes_dev, counts_dev, 2, (int)row1_base, probs_dev, values_dev, (unsigned long long*)nullptr);
-  else
-    hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n0->p, n1->p,
-                       planes_dev, counts_dev, 2, (int)row1_base, probs_dev, values_dev, (unsigned long long*)nullptr);
-  if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
-  return 0;
+  return net_launch(n0, n1, planes_dev, counts_dev, 2, (int)row1_base, max_rows, probs_dev, values_dev, nullptr, 0, 0,
+                    nullptr, stream);
 }
 
 int caro_net_forward_pair(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
@@ -1254,21 +1406,28 @@ int caro_net_forward_pair(caro_net* n0, caro_net* n1, const float* planes_dev, c
   return caro_net_forward_pair_at(n0, n1, planes_dev, counts_dev, -1, max_rows, probs_dev, values_dev, stream);
 }
 
+/* slot rows (the fused tree kernel): game g's j-th unique leaf sits at row g * batch + j of planes / probs / values,
+ * gpack_dev[g] = count | net class << 8, counts_dev = {L0, L1} totals.  n1 == NULL: one net (every game class 0). */
+int caro_net_forward_slots(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
+                           const int32_t* gpack_dev, int n_games, int batch, float* probs_dev, float* values_dev,
+                           void* stream) {
+  if (!n0 || !planes_dev || !counts_dev || !gpack_dev || !probs_dev || !values_dev)
+    return nfail(CARO_E_INVAL, "null argument");
+  if (n_games < 1 || batch < 1 || batch > 255) return nfail(CARO_E_INVAL, "bad slot geometry");
+  if (n1)
+    if (int rc = pair_ok(n0, n1)) return rc;
+  return net_launch(n0, n1 ? n1 : n0, planes_dev, counts_dev, n1 ? 2 : 0, -1, (int64_t)n_games * batch, probs_dev,
+                    values_dev, gpack_dev, n_games, batch, nullptr, stream);
+}
+
 /* diagnostic: same launch, and per workgroup (total cycles, 100 MHz ticks, cycles at trunk start, at trunk end) into stamps_dev u64[4*grid] */
 int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which,
                              int64_t max_rows, float* probs_dev, float* values_dev, uint64_t* stamps_dev,
                              void* stream) {
   if (!n || !stamps_dev) return nfail(CARO_E_INVAL, "null argument");
-  const unsigned grid = net_grid(n, max_rows);
-  if (n->p.w3) return nfail(CARO_E_STATE, "no stamps in 3xbf16 mode");
-  if (n->p.ww)
-    hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
-                       planes_dev, counts_dev, which, -1, probs_dev, values_dev, (unsigned long long*)stamps_dev);
-  else
-    hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, (hipStream_t)stream, n->p, n->p,
-                       planes_dev, counts_dev, which, -1, probs_dev, values_dev, (unsigned long long*)stamps_dev);
-  if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "k_net_forward launch failed");
-  return 0;
+  if (n->kind != 0 || n->p.w3) return nfail(CARO_E_STATE, "stamps: float32 conv kernels only");
+  return net_launch(n, n, planes_dev, counts_dev, which, -1, max_rows, probs_dev, values_dev, nullptr, 0, 0,
+                    (unsigned long long*)stamps_dev, stream);
 }
 
 }  // extern "C"

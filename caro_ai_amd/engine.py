@@ -98,7 +98,7 @@ class SelfPlayEngine:
         h = C.c_void_p()
         _lib.check(self.L.caro_engine_create(C.byref(c), C.byref(h)))
         self.h = h
-        rows = self.G * self.max_batch * self.n_nets  # two nets: caro_search_batch places net 1's rows from G*B on
+        rows = self.G * self.max_batch  # one row per descent at most, whichever net it goes to
         self.planes = torch.zeros((rows,) + self.obs_shape, dtype=torch.float32, device=self.device)
         self.leaf_keys = torch.zeros((rows, self.KW), dtype=torch.int64, device=self.device)
         self._probs = torch.zeros((rows, self.A), dtype=torch.float32, device=self.device)
@@ -177,10 +177,15 @@ class SelfPlayEngine:
 
     def search(self, searches, batch, noise=None):
         """search_batch (mcts.py:162-176) for all games. noise: optional [searches, G, batch, A] rows."""
-        if self.async_net and noise is None:
+        if self.async_net:
             # whole search_batch enqueued by one C call (no Python / ctypes work per launch)
+            nz = None
+            if noise is not None:
+                nz = noise if torch.is_tensor(noise) else torch.as_tensor(np.asarray(noise, dtype=np.float64))
+                nz = nz.to(self.device, dtype=torch.float64).contiguous()
+                assert nz.numel() == searches * self.G * batch * self.A
             nets = [e.h for e in self.evaluators] + [None]
-            _lib.check(self.L.caro_search_batch(self.h, nets[0], nets[1], searches, batch, None, _ptr(self.planes),
+            _lib.check(self.L.caro_search_batch(self.h, nets[0], nets[1], searches, batch, _ptr(nz), _ptr(self.planes),
                                                 _ptr(self.leaf_keys), _ptr(self._probs), _ptr(self._values),
                                                 self._stream()))
             self.net_calls += searches * self.n_nets
@@ -205,7 +210,8 @@ class SelfPlayEngine:
         return actions, done, result
 
     def drain(self, recycle=True, cap=None):
-        """Finished games -> tuples (device tensors), in the reference's append order."""
+        """Finished games -> tuples (device tensors of their own: later drains do not touch them), in the
+        reference's append order."""
         cap = int(cap or self.G * self.maxply)
         if not hasattr(self, "_dr") or self._dr[0].shape[0] < cap:
             dev = self.device
@@ -219,7 +225,9 @@ class SelfPlayEngine:
         _lib.check(self.L.caro_drain_tuples(self.h, cap, _ptr(s), _ptr(p), _ptr(pi), _ptr(z), _ptr(games),
                                             1 if recycle else 0, C.addressof(nt), C.addressof(ng), self._stream()))
         nt, ng = nt.value, ng.value
-        return {"states": s[:nt], "players": p[:nt], "pi": pi[:nt], "z": z[:nt], "games": games[:ng]}
+        # the kernel wrote into one staging buffer that the next drain reuses from row 0: hand out copies
+        return {"states": s[:nt].clone(), "players": p[:nt].clone(), "pi": pi[:nt].clone(), "z": z[:nt].clone(),
+                "games": games[:ng].clone()}
 
     # ------------------------------------------------------------ inspection
     def counters(self):

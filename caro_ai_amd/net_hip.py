@@ -169,3 +169,29 @@ class HipNet:
         st = C.c_void_p(torch.cuda.current_stream(planes.device).cuda_stream)
         self.forward_dev(planes.contiguous(), counts.data_ptr(), 0, L, probs, values, st)
         return probs, values
+
+
+class HashNet:
+    """The table evaluator of include/caro_hip.h (`caro_net_create_hash`): priors and value are exact integer-hash
+    functions of the leaf planes.  Same device-side interface as `HipNet` (leaf counts read on the device), so an
+    engine built on it runs the very launches the conv net runs -- the form in which the search is compared bit for
+    bit with the oracle.  Not a model: it has no weights."""
+
+    device_counts = True
+
+    def __init__(self, game_or_shape, actions_n=None, device="cuda:0", salt=0):
+        shape = getattr(game_or_shape, "obs_shape", game_or_shape)
+        self.H, self.W = int(shape[1]), int(shape[2])
+        self.A = int(actions_n if actions_n is not None else game_or_shape.action_space)
+        self.L = _lib.load()
+        self.device = torch.device(device)
+        self.salt = int(salt)
+        h = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        _lib.check(self.L.caro_net_create_hash(self.H, self.W, self.A, self.salt, self.device.index or 0, C.byref(h)))
+        self.h = h
+
+    close = HipNet.close
+    __del__ = HipNet.__del__
+    forward_dev = HipNet.forward_dev
+    __call__ = HipNet.__call__

@@ -226,6 +226,25 @@ int caro_net_boards_per_workgroup(const caro_net* n);
 int caro_net_forward(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which, int64_t max_rows,
                      float* probs_dev, float* values_dev, void* stream);
 
+/* slot rows, the form the fused tree kernel of caro_search_batch produces: the j-th unique leaf of game g sits
+ * at row g * batch + j of planes_dev (its priors / value come back in the same row of probs_dev / values_dev),
+ * gpack_dev i32[n_games] = leaf count | net class << 8, counts_dev = {L0, L1} totals per net, all read ON DEVICE.
+ * Every workgroup maps its dense tile of boards onto the slot rows in game order itself, so which leaves share a
+ * tile (and the tile size) is a function of the games' states only, never of block arrival order.
+ * n1 may be NULL (one net, every game class 0). */
+int caro_net_forward_slots(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
+                           const int32_t* gpack_dev, int n_games, int batch, float* probs_dev, float* values_dev,
+                           void* stream);
+
+/* Table evaluator with the same launch interface as the conv net (leaf counts read on device, dense or slot
+ * rows): an exact integer-hash "net" for checking the SEARCH bit for bit -- it stands where lib/mcts.py:212-218
+ * calls the net.  With x = the 2*H*W input planes of a row, mix64 = the splitmix64 finaliser of caro_noise.h:
+ *   h    = salt + sum over j with x[j] != 0 of (mix64(0x5851f42d4c957f2d + j) | 1)          (mod 2^64)
+ *   P[a] = (((mix64(h + 0x9E3779B97F4A7C15 * (a + 1)) >> 20) & 1023) + 1) / 8192            (float32, exact)
+ *   v    = ((mix64(h ^ 0xA5A5A5A5A5A5A5A5) >> 20) % 2001 - 1000) / 1024                      (float32, exact)
+ * (P is used as is, no softmax).  oracle/caro_oracle.c and tests/synth_net.py hold independent twins. */
+int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro_net** out);
+
 /* A HIP stream confined to the compute units [part/nparts, (part+1)/nparts) of the device
  * (hipExtStreamCreateWithCUMask): independent engines on such streams run side by side on disjoint CUs. */
 int caro_stream_create_partition(int device_id, int part, int nparts, void** stream_out);
@@ -244,9 +263,9 @@ int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t
 /* MCTS.search_batch (lib/mcts.py:162-176) for every live game with the fused net(s): `searches` x
  * (caro_select -> caro_net_forward per net -> caro_expand_backup) enqueued on `stream` from one call, no host
  * synchronisation.  noise_dev: f64[searches, G, batch, A] or NULL (generated); buffers as for caro_select /
- * caro_expand_backup, but with room for 2 * G * batch rows when the engine has two nets (the second net's rows
- * are placed from row G * batch on); net1 may be NULL when the engine has one net.  With one wavefront per game
- * (batch * lanes-per-descent == 64) the three tree kernels run fused (k_tree), two launches per minibatch. */
+ * caro_expand_backup (G * batch rows); net1 may be NULL when the engine has one net.  With one wavefront per game
+ * (batch * lanes-per-descent == 64) the three tree kernels run fused (k_tree), two launches per minibatch, and
+ * leaves travel in slot rows (caro_net_forward_slots); otherwise in the dense rows of caro_select. */
 int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch,
                       const double* noise_dev, float* planes_dev, uint64_t* leaf_keys_dev, float* probs_dev,
                       float* values_dev, void* stream);

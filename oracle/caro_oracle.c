@@ -711,18 +711,22 @@ int oracle_play_game(oracle* o, int steps_before_tau_0, int searches, int batch_
 /* ------------------------------------------- synthetic hash net (tests) */
 /* A deterministic "net" whose P and v are exact dyadic float32 values of an
  * integer hash of the input planes, so that CPU and GPU sides can evaluate it
- * with identical bits (tests/synth_net.py is the torch twin). */
+ * with identical bits (tests/synth_net.py is the torch twin; include/caro_hip.h
+ * states the definition for the engine's table evaluator).  `salt` (0 in every
+ * vector recorded from the reference) tells the two nets of an arena apart. */
 static uint64_t synth_coef(int i) { return caro_mix64(0x5851f42d4c957f2dULL + (uint64_t)i) | 1ULL; }
 
-void oracle_synth_net(void* ctx, int L, const float* planes, const uint8_t* cells,
-                      const int32_t* players, float* P, float* v) {
-  const oracle* o = (const oracle*)ctx;
+typedef struct { const oracle* o; uint64_t salt; } synth_ctx;
+static synth_ctx g_synth[2][64]; /* per net; a small pool so that several oracles can coexist in one process */
+static int g_synth_used = 0;
+
+static void synth_eval(const oracle* o, uint64_t salt, int L, const float* planes, float* P, float* v) {
   int A = o->game.A, hw2 = 2 * ncells(&o->game);
-  (void)cells; (void)players;
   for (int i = 0; i < L; ++i) {
     uint64_t h = 0;
     for (int j = 0; j < hw2; ++j)
       if (planes[(size_t)i * hw2 + j] != 0.0f) h += synth_coef(j);
+    h += salt;
     for (int a = 0; a < A; ++a) {
       uint64_t ha = caro_mix64(h + 0x9E3779B97F4A7C15ULL * (uint64_t)(a + 1));
       P[(size_t)i * A + a] = (float)(((ha >> 20) & 1023ULL) + 1ULL) / 8192.0f;
@@ -731,7 +735,30 @@ void oracle_synth_net(void* ctx, int L, const float* planes, const uint8_t* cell
     v[i] = (float)((long long)((hv >> 20) % 2001ULL) - 1000LL) / 1024.0f;
   }
 }
+void oracle_synth_net(void* ctx, int L, const float* planes, const uint8_t* cells,
+                      const int32_t* players, float* P, float* v) {
+  (void)cells; (void)players;
+  synth_eval((const oracle*)ctx, 0, L, planes, P, v);
+}
+static void synth_net_salted(void* ctx, int L, const float* planes, const uint8_t* cells,
+                             const int32_t* players, float* P, float* v) {
+  const synth_ctx* c = (const synth_ctx*)ctx;
+  (void)cells; (void)players;
+  synth_eval(c->o, c->salt, L, planes, P, v);
+}
+/* direct evaluation of the salted table net (twin checks in tests) */
+void oracle_synth_eval(const oracle* o, uint64_t salt, int L, const float* planes, float* P, float* v) {
+  synth_eval(o, salt, L, planes, P, v);
+}
 void oracle_use_synth_net(oracle* o) { oracle_set_net(o, 0, oracle_synth_net, o); oracle_set_net(o, 1, oracle_synth_net, o); }
+/* net 0 / net 1 = the table net with salt0 / salt1 */
+void oracle_use_synth_nets(oracle* o, uint64_t salt0, uint64_t salt1) {
+  int k = g_synth_used++ % 64;
+  g_synth[0][k].o = o; g_synth[0][k].salt = salt0;
+  g_synth[1][k].o = o; g_synth[1][k].salt = salt1;
+  oracle_set_net(o, 0, synth_net_salted, &g_synth[0][k]);
+  oracle_set_net(o, 1, synth_net_salted, &g_synth[1][k]);
+}
 
 /* noise helpers exported for tests (host form of the public spec) */
 void oracle_noise_row(uint64_t seed, uint64_t uid, uint32_t ply, uint32_t sim, int A, double alpha, double* out) {

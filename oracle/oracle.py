@@ -44,6 +44,7 @@ def lib():
         L.oracle_clear.argtypes = [C.c_void_p]
         L.oracle_set_net.argtypes = [C.c_void_p, C.c_int, NET_FN, C.c_void_p]
         L.oracle_use_synth_net.argtypes = [C.c_void_p]
+        L.oracle_use_synth_nets.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
         L.oracle_set_noise_table.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.oracle_set_uniform_table.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.oracle_set_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
@@ -157,8 +158,12 @@ class Oracle:
         return out
 
     # ---- nets ----
-    def use_synth_net(self):
-        self.L.oracle_use_synth_net(self.h)
+    def use_synth_net(self, salt0=0, salt1=None):
+        """the table net (salt 0: the one the reference-recorded vectors use); two salts = two different nets"""
+        if salt0 == 0 and salt1 in (None, 0):
+            self.L.oracle_use_synth_net(self.h)
+        else:
+            self.L.oracle_use_synth_nets(self.h, salt0, salt0 if salt1 is None else salt1)
 
     def set_net(self, which, fn):
         """fn(planes float32[L,2,H,W], states list[int], players int32[L]) -> (P float32[L,A], v float32[L])"""

@@ -38,8 +38,9 @@ def _mix64(z):
 
 
 class SynthNet:
-    def __init__(self, n_inputs, A, device):
+    def __init__(self, n_inputs, A, device, salt=0):
         self.A = A
+        self.salt = _s64(salt)
         coef = [_s64(_mix64_py(0x5851f42d4c957f2d + j) | 1) for j in range(n_inputs)]
         self.coef = torch.tensor(coef, dtype=torch.int64, device=device)
         self.astep = torch.tensor([_s64(0x9E3779B97F4A7C15 * (a + 1)) for a in range(A)], dtype=torch.int64,
@@ -49,7 +50,7 @@ class SynthNet:
     def __call__(self, planes):
         L = planes.shape[0]
         mask = (planes.reshape(L, -1) != 0).to(torch.int64)
-        h = (mask * self.coef).sum(dim=1)  # wraps mod 2^64
+        h = (mask * self.coef).sum(dim=1) + self.salt  # wraps mod 2^64
         ha = _mix64(h[:, None] + self.astep[None, :])
         P = ((_lsr(ha, 20) & 1023) + 1).to(torch.float32) / 8192.0
         hv = _mix64(h ^ _s64(0xA5A5A5A5A5A5A5A5))
@@ -57,8 +58,8 @@ class SynthNet:
         return P.contiguous(), v.contiguous()
 
 
-def synth_numpy(planes, A):
+def synth_numpy(planes, A, salt=0):
     """numpy/CPU form through torch CPU (used by CPU-side checks)"""
-    net = SynthNet(int(np.prod(planes.shape[1:])), A, "cpu")
+    net = SynthNet(int(np.prod(planes.shape[1:])), A, "cpu", salt)
     P, v = net(torch.from_numpy(np.ascontiguousarray(planes)))
     return P.numpy(), v.numpy()

@@ -138,3 +138,10 @@ def test_synth_net_twins_agree():
         o.L.oracle_synth_net(o.h, 17, planes.ctypes.data, None, None, Pc.ctypes.data, vc.ctypes.data)
         assert np.array_equal(P, Pc) and np.array_equal(v, vc)
         assert P.min() > 0 and abs(v).max() <= 1000 / 1024
+        # salted form (the two nets of an arena): torch twin == C twin, and the salt changes the outputs
+        o.L.oracle_synth_eval.argtypes = [C.c_void_p, C.c_uint64, C.c_int] + [C.c_void_p] * 3
+        for salt in (0, 0x2222, (1 << 64) - 5):
+            Ps, vs = synth_numpy(planes, o.A, salt)
+            o.L.oracle_synth_eval(o.h, salt, 17, planes.ctypes.data, Pc.ctypes.data, vc.ctypes.data)
+            assert np.array_equal(Ps, Pc) and np.array_equal(vs, vc)
+            assert (salt == 0) == np.array_equal(Ps, P)

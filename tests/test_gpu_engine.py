@@ -28,9 +28,26 @@ def _oracle_of(d, n_stores=1):
                                                                                  n_stores=n_stores)
 
 
-def _synth(game):
+FORMS = ["stepwise", "fused"]
+
+
+@pytest.fixture(params=FORMS)
+def form(request):
+    """How the table net is evaluated, i.e. which launches the engine runs.
+    stepwise: the torch twin (tests/synth_net.py); leaf counts cross to the host, the engine issues
+              k_select / k_encode / k_expand_backup one by one (the form torch evaluators use).
+    fused:    the device table evaluator (`caro_net_create_hash`, leaf counts read on the device); a whole
+              search_batch is enqueued by `caro_search_batch`: k_tree + slot rows when one wavefront serves a
+              game (batch x lanes-per-descent = 64), dense rows otherwise -- the launches bench.py and train.py run."""
+    return request.param
+
+
+def _synth(game, form="stepwise", salt=0):
+    if form == "fused":
+        from caro_ai_amd.net_hip import HashNet
+        return HashNet(game, device=DEV, salt=salt)
     from tests.synth_net import SynthNet
-    return SynthNet(2 * game.obs_shape[1] * game.obs_shape[2], game.action_space, DEV)
+    return SynthNet(2 * game.obs_shape[1] * game.obs_shape[2], game.action_space, DEV, salt)
 
 
 def _engine(game, G, evaluators, **kw):
@@ -97,11 +114,11 @@ def test_rules_kernels_vs_reference(name):
 
 
 # ------------------------------------------------------------------ engine vs recorded reference games
-def _play_and_check_golden(d, g, explicit_noise=False):
+def _play_and_check_golden(d, g, form, explicit_noise=False):
     from oracle.oracle import noise_row
     game = _game_of(d)
     A = game.action_space
-    eng = _engine(game, 1, [_synth(game)], n_stores=g["n_stores"], max_batch=g["batch"], steps_before_tau_0=g["steps_before_tau_0"],
+    eng = _engine(game, 1, [_synth(game, form)], n_stores=g["n_stores"], max_batch=g["batch"], steps_before_tau_0=g["steps_before_tau_0"],
                   seed=g["seed"], uid_base=g["uid"], node_cap=g["searches"] * g["batch"] * g["plies"] + 64)
     eng.reset([g["first_player"]])
     S, B = g["searches"], g["batch"]
@@ -148,27 +165,27 @@ def _play_and_check_golden(d, g, explicit_noise=False):
 
 @pytest.mark.parametrize("name", ["synth_c4.json.gz", "synth_ttt3.json.gz", "synth_mnk5.json.gz",
                                   "synth_mnk15.json.gz"])
-def test_engine_replays_reference_games(name):
+def test_engine_replays_reference_games(name, form):
     """G2 on the GPU: the engine reproduces games recorded from the REFERENCE
     (synthetic table net, noise generated on device from the spec)."""
     d = load_golden(name)
     for g in d["games"]:
-        _play_and_check_golden(d, g)
+        _play_and_check_golden(d, g, form)
 
 
-def test_explicit_noise_table_path():
+def test_explicit_noise_table_path(form):
     d = load_golden("synth_ttt3.json.gz")
-    _play_and_check_golden(d, d["games"][2], explicit_noise=True)
+    _play_and_check_golden(d, d["games"][2], form, explicit_noise=True)
     d = load_golden("synth_c4.json.gz")
-    _play_and_check_golden(d, d["games"][2], explicit_noise=True)
+    _play_and_check_golden(d, d["games"][2], form, explicit_noise=True)
 
 
 # ------------------------------------------------------------------ many concurrent games vs the oracle
-def _oracle_games(d, uids, seed, sbt0, S, B, n_stores, first_mode=2):
+def _oracle_games(d, uids, seed, sbt0, S, B, n_stores, first_mode=2, salts=(0, 0)):
     out = {}
     for uid in uids:
         o = _oracle_of(d, n_stores)
-        o.use_synth_net()
+        o.use_synth_net(*salts)
         o.set_stream(seed, int(uid))
         fp = int(uid) & 1 if first_mode == 2 else first_mode
         r = o.play_game(sbt0, S, B, fp)
@@ -178,9 +195,11 @@ def _oracle_games(d, uids, seed, sbt0, S, B, n_stores, first_mode=2):
     return out
 
 
-def _check_against_oracle(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base):
+def _check_against_oracle(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base, form="stepwise", salts=None):
+    """salts = (s0, s1): player 0's leaves go to table net s0, player 1's to net s1 (n_nets = 2, play.py arena)"""
     game = _game_of(d)
-    eng = _engine(game, G, [_synth(game)], n_stores=n_stores, max_batch=B, steps_before_tau_0=sbt0, seed=seed,
+    evs = [_synth(game, form)] if salts is None else [_synth(game, form, salts[0]), _synth(game, form, salts[1])]
+    eng = _engine(game, G, evs, n_stores=n_stores, max_batch=B, steps_before_tau_0=sbt0, seed=seed,
                   uid_base=uid_base, node_cap=S * B * game.obs_shape[1] * game.obs_shape[2] + 64)
     tuples, games = eng.play_until(S, B, n_finished=n_finish)
     c = eng.counters()
@@ -188,7 +207,7 @@ def _check_against_oracle(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base):
     eng.close()
     uids = games[:, 0]
     assert len(set(uids.tolist())) == len(uids)
-    ref = _oracle_games(d, uids, seed, sbt0, S, B, n_stores)
+    ref = _oracle_games(d, uids, seed, sbt0, S, B, n_stores, salts=salts or (0, 0))
     # per-game records
     for uid, first, result, steps in games.tolist():
         r = ref[uid]
@@ -211,38 +230,62 @@ def _check_against_oracle(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base):
     return c, ref, games
 
 
-def test_connect4_64_games_vs_oracle():
+def test_connect4_64_games_vs_oracle(form):
     """64 concurrent connect-four games, 25x8 sims/move (config 2's S x B), slots
     recycled until 96 games finished: every game identical to the oracle's."""
-    c, ref, games = _check_against_oracle({"kind": "c4"}, 64, 96, 10, 25, 8, 1, seed=3, uid_base=1000)
+    c, ref, games = _check_against_oracle({"kind": "c4"}, 64, 96, 10, 25, 8, 1, seed=3, uid_base=1000, form=form)
     assert len(games) >= 96
 
 
-def test_connect4_arena_two_stores_vs_oracle():
-    _check_against_oracle({"kind": "c4"}, 16, 16, 0, 10, 16, 2, seed=5, uid_base=5000)
+def test_connect4_arena_two_stores_vs_oracle(form):
+    _check_against_oracle({"kind": "c4"}, 16, 16, 0, 10, 16, 2, seed=5, uid_base=5000, form=form)
 
 
-def test_tictactoe_games_vs_oracle_with_draws():
-    c, ref, games = _check_against_oracle({"kind": "mnk", "n": 3, "k": 3}, 64, 200, 2, 25, 4, 1, seed=9, uid_base=0)
+def test_connect4_arena_two_nets_two_stores_vs_oracle(form):
+    """config 5's shape (play.py:47): two different nets, one tree per player, tau = 0 from move 0; B = 8 is the
+    one-wavefront-per-game geometry, so form=fused runs k_tree with both nets' rows in one launch"""
+    _check_against_oracle({"kind": "c4"}, 32, 48, 0, 12, 8, 2, seed=6, uid_base=7000, form=form,
+                          salts=(0x1111, 0x2222))
+    _check_against_oracle({"kind": "c4"}, 8, 8, 0, 6, 16, 2, seed=7, uid_base=7100, form=form, salts=(3, 0))
+
+
+def test_tictactoe_games_vs_oracle_with_draws(form):
+    c, ref, games = _check_against_oracle({"kind": "mnk", "n": 3, "k": 3}, 64, 200, 2, 25, 4, 1, seed=9, uid_base=0,
+                                          form=form)
     assert (games[:, 2] == 0).any(), "no drawn game in the sample"  # draw path covered
 
 
-def test_gomoku15_games_vs_oracle():
-    _check_against_oracle({"kind": "mnk", "n": 15, "k": 5}, 8, 8, 6, 6, 8, 1, seed=17, uid_base=40)
+def test_gomoku15_games_vs_oracle(form):
+    _check_against_oracle({"kind": "mnk", "n": 15, "k": 5}, 8, 8, 6, 6, 8, 1, seed=17, uid_base=40, form=form)
 
 
-def test_mnk_mid_sizes_vs_oracle():
-    _check_against_oracle({"kind": "mnk", "n": 6, "k": 4}, 8, 8, 3, 8, 8, 1, seed=21, uid_base=0)
-    _check_against_oracle({"kind": "mnk", "n": 10, "k": 5}, 4, 4, 3, 6, 8, 1, seed=22, uid_base=0)
+def test_mnk_mid_sizes_vs_oracle(form):
+    _check_against_oracle({"kind": "mnk", "n": 6, "k": 4}, 8, 8, 3, 8, 8, 1, seed=21, uid_base=0, form=form)
+    _check_against_oracle({"kind": "mnk", "n": 10, "k": 5}, 4, 4, 3, 6, 8, 1, seed=22, uid_base=0, form=form)
 
 
-def test_counters_match_oracle_totals():
+@pytest.mark.parametrize("d,B,two_nets", [({"kind": "mnk", "n": 4, "k": 3}, 4, False),    # 16 lanes x 4 descents
+                                          ({"kind": "mnk", "n": 5, "k": 4}, 2, False),    # 32 x 2
+                                          ({"kind": "mnk", "n": 8, "k": 5}, 1, False),    # 64 x 1
+                                          ({"kind": "mnk", "n": 10, "k": 5}, 1, False),   # 64 x 1, 2 actions per lane
+                                          ({"kind": "mnk", "n": 15, "k": 5}, 1, True),    # 64 x 1, 4 actions per lane
+                                          ({"kind": "mnk", "n": 3, "k": 3}, 4, True)])
+def test_one_wavefront_geometries_vs_oracle(d, B, two_nets, form):
+    """every geometry in which caro_search_batch runs the fused tree kernel (batch x lanes-per-descent = 64),
+    with one and with two nets"""
+    n = d["n"]
+    S = 24 // B if n <= 5 else 10
+    _check_against_oracle(d, 8, 12 if n <= 5 else 8, 2, S, B, 2 if two_nets else 1, seed=80 + n, uid_base=300, form=form,
+                          salts=(9, 10) if two_nets else None)
+
+
+def test_counters_match_oracle_totals(form):
     """sims / levels / expansions / terminals / dropped summed over complete
     games equal the oracle's (the roofline's byte formula is built on these)."""
     d = {"kind": "c4"}
     game = _game_of(d)
     G, S, B = 32, 25, 8
-    eng = _engine(game, G, [_synth(game)], max_batch=B, steps_before_tau_0=10, seed=77, uid_base=0)
+    eng = _engine(game, G, [_synth(game, form)], max_batch=B, steps_before_tau_0=10, seed=77, uid_base=0)
     tuples, games = eng.play_until(S, B, recycle=False)
     c = eng.counters()
     eng.close()
@@ -255,12 +298,12 @@ def test_counters_match_oracle_totals():
     assert c["plies"] == sum(r["plies"] for r in ref.values())
 
 
-def test_full_size_1024_games_invariants():
+def test_full_size_1024_games_invariants(form):
     """Config 2 geometry (1024 games, 25x8): size-independent properties."""
     d = {"kind": "c4"}
     game = _game_of(d)
     G, S, B = 1024, 25, 8
-    eng = _engine(game, G, [_synth(game)], max_batch=B, steps_before_tau_0=10, seed=1, uid_base=0)
+    eng = _engine(game, G, [_synth(game, form)], max_batch=B, steps_before_tau_0=10, seed=1, uid_base=0)
     for _ in range(3):
         eng.search(S, B)
         pi, counts = eng.policy()
@@ -294,9 +337,9 @@ def test_full_size_1024_games_invariants():
 
 
 # ------------------------------------------------------------------ node eviction is result-neutral
-def _check_evict(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base, cap):
+def _check_evict(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base, cap, form):
     game = _game_of(d)
-    eng = _engine(game, G, [_synth(game)], n_stores=n_stores, max_batch=B, steps_before_tau_0=sbt0, seed=seed,
+    eng = _engine(game, G, [_synth(game, form)], n_stores=n_stores, max_batch=B, steps_before_tau_0=sbt0, seed=seed,
                   uid_base=uid_base, node_cap=cap, evict=True)
     tuples, games = eng.play_until(S, B, n_finished=n_finish)
     c = eng.counters()
@@ -316,16 +359,17 @@ def _check_evict(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base, cap):
     return c
 
 
-def test_eviction_connect4_small_cap():
+def test_eviction_connect4_small_cap(form):
     """cap 1024 live nodes per tree is far below what a whole game creates (~600-2600) once trees are shared
     across 20+ plies without eviction: with eviction nothing overflows and every game still equals the oracle."""
-    _check_evict({"kind": "c4"}, 32, 48, 10, 25, 8, 1, seed=31, uid_base=0, cap=1024)
-    _check_evict({"kind": "c4"}, 8, 8, 0, 10, 16, 2, seed=32, uid_base=100, cap=512)
+    _check_evict({"kind": "c4"}, 32, 48, 10, 25, 8, 1, seed=31, uid_base=0, cap=1024, form=form)
+    _check_evict({"kind": "c4"}, 8, 8, 0, 10, 16, 2, seed=32, uid_base=100, cap=512, form=form)
 
 
-def test_eviction_gomoku15_and_ttt():
-    _check_evict({"kind": "mnk", "n": 15, "k": 5}, 4, 4, 6, 6, 8, 1, seed=33, uid_base=0, cap=256)
-    _check_evict({"kind": "mnk", "n": 3, "k": 3}, 32, 64, 2, 25, 4, 1, seed=34, uid_base=0, cap=128)
+def test_eviction_gomoku15_and_ttt(form):
+    _check_evict({"kind": "mnk", "n": 15, "k": 5}, 4, 4, 6, 6, 8, 1, seed=33, uid_base=0, cap=256, form=form)
+    _check_evict({"kind": "mnk", "n": 15, "k": 5}, 4, 4, 4, 12, 1, 1, seed=35, uid_base=0, cap=256, form=form)
+    _check_evict({"kind": "mnk", "n": 3, "k": 3}, 32, 64, 2, 25, 4, 1, seed=34, uid_base=0, cap=128, form=form)
 
 
 def test_without_eviction_the_small_cap_overflows():
@@ -337,7 +381,7 @@ def test_without_eviction_the_small_cap_overflows():
 
 
 # ------------------------------------------------------------------ sharding does not change the games
-def test_games_do_not_depend_on_sharding():
+def test_games_do_not_depend_on_sharding(form):
     """8 slots in one engine == 2 'ranks' of 4 slots (parallel.shard layout) == StreamedSelfPlay with 2 parts:
     every uid gives the same game (result, steps, tuples), whatever plays it."""
     from caro_ai_amd import parallel
@@ -354,13 +398,13 @@ def test_games_do_not_depend_on_sharding():
             off += n
         return out
 
-    eng = _engine(game, 8, [_synth(game)], max_batch=B, seed=seed)
+    eng = _engine(game, 8, [_synth(game, form)], max_batch=B, seed=seed)
     t, g = eng.play_until(S, B, n_finished=16)
     eng.close()
     ref = collect(t, g)
     got = {}
     for rank in range(2):
-        e = _engine(game, 4, [_synth(game)], max_batch=B, seed=seed, **parallel.shard(4, rank, 2))
+        e = _engine(game, 4, [_synth(game, form)], max_batch=B, seed=seed, **parallel.shard(4, rank, 2))
         t, g = e.play_until(S, B, n_finished=8)
         e.close()
         got.update(collect(t, g))
@@ -368,7 +412,7 @@ def test_games_do_not_depend_on_sharding():
     assert len(common) >= 12
     for uid in common:
         assert ref[uid] == got[uid], uid
-    sp = StreamedSelfPlay(game, 8, lambda: [_synth(game)], n_streams=2, max_batch=B, seed=seed)
+    sp = StreamedSelfPlay(game, 8, lambda: [_synth(game, form)], n_streams=2, max_batch=B, seed=seed)
     seen = {}
     for _ in range(40):
         sp.search(S, B); sp.step()
@@ -383,7 +427,7 @@ def test_games_do_not_depend_on_sharding():
 
 
 # ------------------------------------------------------------------ searches from recorded mid / late game positions
-def _search_from_positions(d, recs, S, B, seed):
+def _search_from_positions(d, recs, S, B, seed, form):
     """One engine slot per recorded position (set_roots on empty trees), S x B sims, then root N / W / Q /
     strong flag / tree size / pi against the oracle searching the same position with the same noise key."""
     from oracle.oracle import Oracle
@@ -391,7 +435,7 @@ def _search_from_positions(d, recs, S, B, seed):
     states = [int(r["s2"]) for r in recs]
     players = [1 - r["p"] for r in recs]
     G = len(states)
-    eng = _engine(game, G, [_synth(game)], max_batch=B, steps_before_tau_0=10, seed=seed, uid_base=0,
+    eng = _engine(game, G, [_synth(game, form)], max_batch=B, steps_before_tau_0=10, seed=seed, uid_base=0,
                   node_cap=S * B + 8)
     eng.set_roots(states, players)
     eng.search(S, B)
@@ -427,38 +471,40 @@ def _search_from_positions(d, recs, S, B, seed):
     return checked, terminal_roots
 
 
-def test_connect4_search_from_2000_recorded_positions():
+def test_connect4_search_from_2000_recorded_positions(form):
     d = load_golden("rules_c4.json.gz")
     recs = [r for r in d["recs"] if not r["won"]][:2000]
-    checked, with_terminals = _search_from_positions({"kind": "c4"}, recs, 6, 8, seed=51)
+    checked, with_terminals = _search_from_positions({"kind": "c4"}, recs, 6, 8, seed=51, form=form)
     assert checked >= 1900 and with_terminals > 200  # late-game roots: wins, full columns and draws inside the search
 
 
-def test_tictactoe_and_gomoku_search_from_recorded_positions():
+def test_tictactoe_and_gomoku_search_from_recorded_positions(form):
     d = load_golden("rules_ttt3.json.gz")
     recs = [r for r in d["recs"] if not r["won"]]
-    checked, with_terminals = _search_from_positions({"kind": "mnk", "n": 3, "k": 3}, recs, 8, 4, seed=52)
+    checked, with_terminals = _search_from_positions({"kind": "mnk", "n": 3, "k": 3}, recs, 8, 4, seed=52, form=form)
     assert checked > 700 and with_terminals > 300
     d = load_golden("rules_mnk15.json.gz")
     recs = [r for r in d["recs"] if not r["won"]][::4]
-    checked, _ = _search_from_positions({"kind": "mnk", "n": 15, "k": 5}, recs, 3, 8, seed=53)
+    checked, _ = _search_from_positions({"kind": "mnk", "n": 15, "k": 5}, recs, 3, 8, seed=53, form=form)
     assert checked > 100
     d = load_golden("rules_mnk5.json.gz")
     recs = [r for r in d["recs"] if not r["won"]]
-    checked, with_terminals = _search_from_positions({"kind": "mnk", "n": 5, "k": 4}, recs, 5, 8, seed=54)
+    checked, with_terminals = _search_from_positions({"kind": "mnk", "n": 5, "k": 4}, recs, 5, 8, seed=54, form=form)
+    checked, with_terminals = _search_from_positions({"kind": "mnk", "n": 5, "k": 4}, recs, 12, 2, seed=55, form=form)
+    assert checked > 500
     assert checked > 500 and with_terminals > 20
 
 
 @pytest.mark.parametrize("B", [1, 2, 16, 64])
-def test_batch_size_edge_cases_connect4(B):
+def test_batch_size_edge_cases_connect4(B, form):
     """mcts_batch_size from 1 (TicTacToe plumbing config) to 64 (the kernel's block = 64 x 8 lanes)"""
-    _check_against_oracle({"kind": "c4"}, 8, 8, 4, 200 // B if B <= 16 else 3, B, 1, seed=60 + B, uid_base=0)
+    _check_against_oracle({"kind": "c4"}, 8, 8, 4, 200 // B if B <= 16 else 3, B, 1, seed=60 + B, uid_base=0, form=form)
 
 
 @pytest.mark.parametrize("n,k", [(4, 3), (8, 5), (11, 5), (12, 6), (4, 4)])
-def test_mnk_geometry_variants(n, k):
+def test_mnk_geometry_variants(n, k, form):
     """every lane geometry: A = 16 (no padding lanes), 64 (full wave), 121 / 144 (2 and 4 actions per lane), k = n"""
-    _check_against_oracle({"kind": "mnk", "n": n, "k": k}, 4, 4, 3, 5, 8, 1, seed=70 + n, uid_base=0)
+    _check_against_oracle({"kind": "mnk", "n": n, "k": k}, 4, 4, 3, 5, 8, 1, seed=70 + n, uid_base=0, form=form)
 
 
 def test_capi_rejects_bad_arguments():

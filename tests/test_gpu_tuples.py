@@ -1,0 +1,150 @@
+"""Replay tuples on their way out of the engine, and run-to-run reproducibility.
+
+* A drain hands out tensors of its own: tuples kept across later drains (what `parallel.TupleGatherer` and
+  `train.self_play` do) must not change when the engine's staging buffer is rewritten.
+* The replay rows `train.self_play` stores are exactly the drained tuples, in drain order.
+* Two runs of the same seeded configuration give the same bits, at the full 1024-game size where the
+  net kernel mixes full and K-split tiles (the tile a leaf meets is a function of the games' states only).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _host(d):
+    return {k: v.cpu().numpy().copy() for k, v in d.items()}
+
+
+def test_drained_tuples_survive_later_drains_and_the_gatherer_keeps_them():
+    from caro_ai_amd import parallel
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.net_hip import HashNet
+    from oracle.oracle import Oracle
+    game = TicTacToe()
+    S, B, seed = 6, 4, 13
+    eng = SelfPlayEngine(game, 32, evaluators=[HashNet(game, device=DEV)], max_batch=B, steps_before_tau_0=2, seed=seed,
+                         device=DEV)
+    tg = parallel.TupleGatherer(every=7)
+    kept, copies, gathered = [], [], []
+    for _ in range(30):
+        eng.search(S, B)
+        eng.step()
+        d = eng.drain(recycle=True)
+        kept.append(d)                      # device tensors, NOT cloned by the caller
+        copies.append(_host(d))             # what they held when they were handed out
+        out = tg.push(d)
+        if out is not None:
+            gathered.append(_host(out))
+    out = tg.flush()
+    if out is not None:
+        gathered.append(_host(out))
+    eng.close()
+    n_rows = sum(c["z"].shape[0] for c in copies)
+    assert n_rows > 200 and sum(c["z"].shape[0] > 0 for c in copies) > 10  # many non-empty drains
+    for d, c in zip(kept, copies):
+        for k in c:
+            np.testing.assert_array_equal(d[k].cpu().numpy(), c[k], err_msg=k)
+    for k in ("states", "players", "z"):
+        np.testing.assert_array_equal(np.concatenate([g[k] for g in gathered]), np.concatenate([c[k] for c in copies]))
+    np.testing.assert_array_equal(np.concatenate([g["pi"] for g in gathered]),
+                                  np.concatenate([c["pi"] for c in copies]).astype(np.float32))
+    # and the rows are the games the oracle plays for the same uids
+    off = 0
+    S_all = np.concatenate([c["states"] for c in copies])
+    Z_all = np.concatenate([c["z"] for c in copies])
+    PI_all = np.concatenate([c["pi"] for c in copies])
+    for c in copies:
+        for uid, first, result, steps in c["games"].tolist():
+            o = Oracle(Oracle.MNK, 3, 3)
+            o.use_synth_net()
+            o.set_stream(seed, int(uid))
+            r = o.play_game(2, S, B, int(uid) & 1)
+            n = r["plies"]
+            assert (result, steps) == (r["result"], r["steps"])
+            assert game.from_keys(S_all[off:off + n].view(np.uint64)) == r["states"][::-1]
+            assert Z_all[off:off + n].tolist() == r["z"][::-1].tolist()
+            assert np.array_equal(PI_all[off:off + n], r["pi"][::-1])
+            off += n
+    assert off == n_rows
+
+
+def test_self_play_replay_rows_are_the_drained_tuples():
+    from caro_ai_amd import config as cfg
+    from caro_ai_amd import train
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.lib.model import Net
+    game = TicTacToe()
+    torch.manual_seed(3)
+    net = Net(game.obs_shape, game.action_space).to(DEV).eval()
+    n_games, G, S, B = 96, 32, 5, 4
+    rb = train.DeviceReplayBuffer(game, 4096, DEV)
+    sp = train.self_play(game, rb, net, n_games, device=DEV, seed=5, uid_base=0, searches=S, batch=B, concurrent=G)
+    assert sp["games"] >= n_games
+    # the same games again, every drain copied to the host at once
+    eng = SelfPlayEngine(game, G, net1=net, max_batch=B, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, seed=5, device=DEV,
+                         searches_hint=S, uid_base=0, uid_stride=G)
+    rows, finished = [], 0
+    while finished < n_games:
+        eng.search(S, B)
+        eng.step()
+        d = eng.drain(recycle=finished + G < n_games)
+        ng = int(d["games"].shape[0])
+        if ng:
+            finished += ng
+            rows.append(_host(d))
+        elif eng.live_games() == 0:
+            break
+    eng.close()
+    n = sum(r["z"].shape[0] for r in rows)
+    assert len(rb) == n and n > 5 * n_games
+    np.testing.assert_array_equal(rb.states[:n].cpu().numpy(), np.concatenate([r["states"] for r in rows]))
+    np.testing.assert_array_equal(rb.players[:n].cpu().numpy(), np.concatenate([r["players"] for r in rows]))
+    np.testing.assert_array_equal(rb.z[:n].cpu().numpy(), np.concatenate([r["z"] for r in rows]).astype(np.float32))
+    np.testing.assert_array_equal(rb.pi[:n].cpu().numpy(), np.concatenate([r["pi"] for r in rows]).astype(np.float32))
+    # several different games, not one drain repeated
+    assert len(set(map(bytes, np.concatenate([r["states"] for r in rows])))) > n // 4
+
+
+@pytest.mark.parametrize("inference", ["hipw", "hip"])
+def test_same_seed_same_bits_at_1024_games(inference):
+    """config 2 size: the first minibatches of a move carry more leaves than one round of full net tiles, so
+    full and K-split tiles are both in play; every root row and pi must still repeat bit for bit"""
+    import os
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    from tests.conftest import GOLDEN
+    game = ConnectFour()
+    net = Net(game.obs_shape, game.action_space)
+    net.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", "best_026_12000.dat"), map_location="cpu"))
+    net = net.to(DEV).eval()
+
+    def run():
+        eng = SelfPlayEngine(game, 1024, net1=net, max_batch=8, seed=99, device=DEV, searches_hint=25,
+                             inference=inference)
+        out = []
+        for _ in range(3):
+            eng.search(25, 8)
+            pi, counts = eng.policy()
+            keys = eng.roots()[0]
+            nd = eng.lookup(list(range(0, 1024, 7)), [0] * len(range(0, 1024, 7)),
+                            [game.from_key(k) for k in keys[::7]])
+            out.append((pi.cpu().numpy().tobytes(), counts.cpu().numpy().tobytes(), nd["W"].tobytes(),
+                        nd["P"].tobytes()))
+            eng.step()
+        c = eng.counters()
+        eng.close()
+        return out, c
+
+    a, ca = run()
+    b, cb = run()
+    assert ca == cb and ca["overflows"] == 0
+    assert ca["expansions"] / (3 * 25) > 1536 * 0.9  # launches around one round of full tiles (256 x 6 boards)
+    for x, y in zip(a, b):
+        assert x == y
