@@ -25,10 +25,19 @@ def update_counts(counts_dict, key, counts):
     counts_dict[key] = (v[0] + counts[0], v[1] + counts[1], v[2] + counts[2])
 
 
+def _first_mover(net1_plays_first):
+    """player index (0 = net1) that opens the game; `None` draws it from numpy's global stream (utils.py:65-68)"""
+    if net1_plays_first is None:
+        return int(np.random.choice(2))
+    return 0 if net1_plays_first else 1
+
+
 def play_game(game, mcts_stores, replay_buffer: Union[collections.deque, None], net1, net2,
               steps_before_tau_0: int, mcts_searches: int, mcts_batch_size: int,
               net1_plays_first: bool = None, device: str = "cpu"):
-    """One game; returns (net1_result in {+1, 0, -1}, step)."""
+    """One game; returns (net1_result in {+1, 0, -1}, step).  Interface, assertions, numpy draws (one
+    `choice(2)` when the first mover is open, one `choice(A, p=pi)` per ply, one Dirichlet row per descent inside
+    `MCTS`) and the replay records are those of the reference's lib/utils.py:25-108."""
     assert isinstance(replay_buffer, (collections.deque, type(None)))
     assert isinstance(mcts_stores, (mcts.MCTS, type(None), list))
     assert isinstance(net1, model.Net)
@@ -37,105 +46,98 @@ def play_game(game, mcts_stores, replay_buffer: Union[collections.deque, None], 
     assert isinstance(mcts_searches, int) and mcts_searches > 0
     assert isinstance(mcts_batch_size, int) and mcts_batch_size > 0
 
-    if mcts_stores is None:
-        mcts_stores = [mcts.MCTS(game), mcts.MCTS(game)]
-    elif isinstance(mcts_stores, mcts.MCTS):
-        mcts_stores = [mcts_stores, mcts_stores]
-
-    state = game.initial_state
-    nets = [net1, net2]
-    if net1_plays_first is None:
-        cur_player = int(np.random.choice(2))
+    # one tree per player (none given), one shared tree (a single MCTS), or the caller's pair
+    if isinstance(mcts_stores, mcts.MCTS):
+        trees = (mcts_stores, mcts_stores)
     else:
-        cur_player = 0 if net1_plays_first else 1
-    step = 0
-    tau = 1 if steps_before_tau_0 > 0 else 0
-    history = []
-    result = None
-    net1_result = None
-
-    while result is None:
-        store = mcts_stores[cur_player]
-        store.search_batch(mcts_searches, mcts_batch_size, state, cur_player, nets[cur_player], device=device)
-        probs, _ = store.get_policy_value(state, tau=tau)
-        history.append((state, cur_player, probs))
-        action = int(np.random.choice(game.action_space, p=probs))
-        if action not in game.possible_moves(state):
+        trees = tuple(mcts_stores) if mcts_stores is not None else (mcts.MCTS(game), mcts.MCTS(game))
+    brains = (net1, net2)
+    mover = _first_mover(net1_plays_first)
+    state, step = game.initial_state, 0
+    plies = []       # (state, mover, pi) in playing order
+    outcome = None   # for the player who made the last move: 1 = won, 0 = board full
+    while outcome is None:
+        tau = 1 if step < steps_before_tau_0 else 0  # tau = 1 for the first `steps_before_tau_0` plies
+        tree = trees[mover]
+        tree.search_batch(mcts_searches, mcts_batch_size, state, mover, brains[mover], device=device)
+        pi, _ = tree.get_policy_value(state, tau=tau)
+        plies.append((state, mover, pi))
+        move = int(np.random.choice(game.action_space, p=pi))  # drawn at tau = 0 too, as the reference does
+        if move not in game.possible_moves(state):
             print("Impossible action selected")
-        state, won = game.move(state, action, cur_player)
+        state, won = game.move(state, move, mover)
         if won:
-            result = 1
-            net1_result = 1 if cur_player == 0 else -1
-            break
-        cur_player = 1 - cur_player
-        if len(game.possible_moves(state)) == 0:
-            result = 0
-            net1_result = 0
-            break
-        step += 1
-        if step >= steps_before_tau_0:
-            tau = 0
-
+            outcome = 1
+        elif not game.possible_moves(state):
+            outcome = 0
+        else:
+            mover, step = 1 - mover, step + 1
+    net1_result = 0 if outcome == 0 else (1 if mover == 0 else -1)
     if replay_buffer is not None:
-        for s, p, probs in reversed(history):
-            replay_buffer.append((s, p, probs, result))
-            result = -result
+        z = outcome  # seen by the last mover; alternates back through the game
+        for s, who, pi in reversed(plies):
+            replay_buffer.append((s, who, pi, z))
+            z = -z
     return net1_result, step
 
 
 def play_games(game, n_games, replay_buffer, net1, net2=None, steps_before_tau_0=10, mcts_searches=10,
                mcts_batch_size=8, n_stores=None, concurrent=None, seed=0, uid_base=0, device="cuda:0",
                first_player_mode=2, engine=None, return_stats=False):
-    """Play `n_games` games on the HIP engine, `concurrent` at a time.
+    """Play the `n_games` games with uids uid_base .. uid_base + n_games - 1 on the HIP engine, `concurrent` at a time.
 
     net2 given -> arena: player 0 is net1, player 1 is net2, one tree per player (play.py:47 semantics,
     n_stores=2); otherwise self-play with one shared tree per game (train.py:43-47).
-    Returns the list of net1 results (one per finished game, in finishing order); with return_stats=True
-    also a dict with steps, counters and timing."""
+    Returns the list of net1 results ordered by uid (which games are played, and how each one goes, depends on
+    the uids and the seed only -- not on `concurrent`); with return_stats=True also a dict with steps, counters
+    and timing."""
     from caro_ai_amd.engine import SelfPlayEngine
     arena = net2 is not None and net2 is not net1
     if n_stores is None:
         n_stores = 2 if arena else 1
     G = int(concurrent or min(n_games, 1024))
+    G = max(1, min(G, n_games))
     own = engine is None
     if own:
         engine = SelfPlayEngine(game, G, net1=net1, net2=net2 if arena else None, n_stores=n_stores,
                                 max_batch=mcts_batch_size, steps_before_tau_0=steps_before_tau_0, seed=seed,
                                 uid_base=uid_base, first_player_mode=first_player_mode, device=device,
                                 searches_hint=mcts_searches)
-    results, steps = [], []
     t0 = time.time()
     c0 = engine.counters()
+    last_uid = uid_base + n_games - 1
+    outcome = {}  # uid -> (net1 result, steps)
 
     def consume(d):
-        if replay_buffer is None:
-            return
-        states = game.from_keys(d["states"].cpu().numpy().view(np.uint64))
-        players = d["players"].cpu().numpy().tolist()
-        pis = d["pi"].cpu().numpy().tolist()
-        zs = d["z"].cpu().numpy().tolist()
-        for s, p, pi, z in zip(states, players, pis, zs):
-            replay_buffer.append((s, p, pi, z))
+        """tuples of the wanted games -> the caller's deque, in the reference's record format"""
+        recs = d["games"].cpu().numpy()
+        plies = recs[:, 3] + 1
+        keep = np.repeat(recs[:, 0] <= last_uid, plies)
+        states = game.from_keys(d["states"].cpu().numpy().view(np.uint64)[keep])
+        players = d["players"].cpu().numpy()[keep].tolist()
+        pis = d["pi"].cpu().numpy()[keep].tolist()
+        zs = d["z"].cpu().numpy()[keep].tolist()
+        replay_buffer.extend(zip(states, players, pis, zs))
 
-    started = G
-    while len(results) < n_games:
+    started = G  # uids uid_base .. uid_base + started - 1 have been handed to a slot
+    while len(outcome) < n_games:
         engine.search(mcts_searches, mcts_batch_size)
         engine.step()
-        # recycle finished slots only while more games are still to be started
-        recycle = started < n_games
+        recycle = started < n_games  # a drained slot restarts with the next unplayed uid
         d = engine.drain(recycle=recycle)
-        ng = d["games"].shape[0]
+        ng = int(d["games"].shape[0])
         if ng:
-            recs = d["games"].cpu().numpy()
-            if recycle and started + ng > n_games:
-                pass  # a few extra games may start; their results are simply not collected
-            started += ng if recycle else 0
-            results.extend(int(r) for r in recs[:, 2])
-            steps.extend(int(r) for r in recs[:, 3])
-            consume(d)
-        if not recycle and engine.live_games() == 0:
+            if recycle:
+                started += ng  # may run past n_games by a few slots: those games are played but not reported
+            for uid, _first, result, steps in d["games"].cpu().numpy().tolist():
+                if uid <= last_uid:
+                    outcome[uid] = (int(result), int(steps))
+            if replay_buffer is not None:
+                consume(d)
+        elif not recycle and engine.live_games() == 0:
             break
-    results, steps = results[:n_games], steps[:n_games]
+    results = [outcome[u][0] for u in sorted(outcome)]
+    steps = [outcome[u][1] for u in sorted(outcome)]
     if not return_stats:
         if own:
             engine.close()

@@ -57,6 +57,25 @@ def shard(n_games_per_rank, rank, world):
     return {"uid_base": rank * n_games_per_rank, "uid_stride": world * n_games_per_rank}
 
 
+def shard_rounds(n, rank, world):
+    """(first, count) of the contiguous share of n independent rounds that `rank` plays; the shares tile
+    [0, n) whatever the world size (the first n % world ranks take one more)"""
+    per, rest = divmod(int(n), int(world))
+    lo = rank * per + min(rank, rest)
+    return lo, per + (1 if rank < rest else 0)
+
+
+def allreduce_counts(counts, device="cpu"):
+    """arena W / L / D (or any small tuple of ints) summed over the ranks -> tuple of ints on every rank
+    (train.py:120-149 run sharded: SURVEY 8(e) "all_reduce(SUM) of 3 ints")"""
+    if not is_dist():
+        return tuple(int(c) for c in counts)
+    dev = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device(device)
+    t = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return tuple(int(x) for x in t.tolist())
+
+
 def _via_host(t):
     """gloo collectives run on host memory; nccl (RCCL) takes the device tensors as they are"""
     return dist.get_backend() == "gloo" and t.is_cuda

@@ -1,66 +1,107 @@
 #!/usr/bin/env python3
-"""Round-robin arena between checkpoints, the drop-in for the reference's play.py:15-76.
+"""Round-robin arena between checkpoints: the command-line surface of the reference's play.py:15-76 (same
+arguments, same pairing rule, same printed lines) on the batched HIP engine.
 
-Same CLI (`models...`, `-r/--rounds`, `--cuda`, `-g/--game`), same pairing (every ordered pair plays `rounds`
-games), same settings (tau = 0 from move 0, PLAY_MCTS_SEARCHES x PLAY_MCTS_BATCH_SIZE, a fresh pair of trees
-per game, first player random) and the same output lines; each pair's games run concurrently on the HIP engine.
+Every ordered pair (first, second) of the given checkpoints meets `--rounds` times: tau = 0 from the first move,
+PLAY_MCTS_SEARCHES x PLAY_MCTS_BATCH_SIZE simulations per move, a fresh pair of trees per game, the opening side
+alternating with the game id (the reference draws it at random, play.py:47-52 / utils.py:65-66).  All rounds of
+a pairing advance together on the GPU; with several ranks (torchrun) each rank plays a contiguous share of the
+rounds and the win / loss / draw counts are all-reduced.
 
     python -m caro_ai_amd.play -g 0 --cuda a.dat b.dat -r 64
 """
 import argparse
+import itertools
 import sys
 import time
+from dataclasses import dataclass
 
 import torch
 
 from caro_ai_amd import config as cfg
+from caro_ai_amd import parallel
 from caro_ai_amd.lib import model, utils
 from caro_ai_amd.lib.game import game_provider
 
 
+@dataclass(frozen=True)
+class Tally:
+    wins: int = 0
+    losses: int = 0
+    draws: int = 0
+
+    @classmethod
+    def of(cls, net1_results):
+        return cls(sum(r > 0 for r in net1_results), sum(r < 0 for r in net1_results),
+                   sum(r == 0 for r in net1_results))
+
+    def as_tuple(self):
+        return (self.wins, self.losses, self.draws)
+
+    def mirrored(self):
+        """the same games seen from the other side of the board"""
+        return (self.losses, self.wins, self.draws)
+
+    def __str__(self):
+        return "w=%d, l=%d, d=%d" % self.as_tuple()
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("models", nargs="+", help="The list of models (at least 2) to play against each other")
+    ap.add_argument("-r", "--rounds", type=int, default=2, help="Count of rounds to perform for every pair")
+    ap.add_argument("--cuda", default=False, action="store_true", help="Enable CUDA")
+    ap.add_argument("--seed", type=int, default=0, help="key of the generated noise / move uniforms")
+    game_provider.add_game_argument(ap)
+    return ap.parse_args(argv)
+
+
+def load_checkpoint(game, path, device):
+    """a `.dat` file is torch.save(net.state_dict()) (train.py:214-216)"""
+    net = model.Net(game.obs_shape, game.action_space)
+    net.load_state_dict(torch.load(path, map_location=lambda storage, loc: storage))
+    return net.to(device).eval()
+
+
+def meet(game, first, second, rounds, seed, uid_base, device):
+    """`rounds` games `first` (player 0) vs `second`; this rank plays its share, every rank gets the total"""
+    rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
+    lo, n = parallel.shard_rounds(rounds, rank, world)
+    mine = []
+    if n:
+        mine = utils.play_games(game, n, None, first, second, steps_before_tau_0=0,
+                                mcts_searches=cfg.PLAY_MCTS_SEARCHES, mcts_batch_size=cfg.PLAY_MCTS_BATCH_SIZE,
+                                concurrent=min(n, 1024), seed=seed, uid_base=uid_base + lo, device=device,
+                                first_player_mode=2)
+    return Tally(*parallel.allreduce_counts(Tally.of(mine).as_tuple(), device))
+
+
 def main(argv=None):
-    parser = argparse.ArgumentParser()
-    parser.add_argument("models", nargs="+", help="The list of models (at least 2) to play against each other")
-    parser.add_argument("-r", "--rounds", type=int, default=2, help="Count of rounds to perform for every pair")
-    parser.add_argument("--cuda", default=False, action="store_true", help="Enable CUDA")
-    parser.add_argument("--seed", type=int, default=0)
-    game_provider.add_game_argument(parser)
-    args = parser.parse_args(argv)
-    device = "cuda:0"  # the engine is GPU only; --cuda is accepted for CLI compatibility
-
+    args = parse_args(argv)
+    rank, local_rank, world = parallel.init()
+    device = "cuda:%d" % (local_rank if world > 1 else 0)  # the engine is GPU only; --cuda is accepted as is
     game = game_provider.get_game(args)
-    nets = []
-    for fname in args.models:
-        net = model.Net(game.obs_shape, game.action_space)
-        net.load_state_dict(torch.load(fname, map_location=lambda storage, loc: storage))
-        nets.append((fname, net.to(device)))
+    agents = [(path, load_checkpoint(game, path, device)) for path in args.models]
 
-    total_agent, total_pairs = {}, {}
-    uid = 0
-    for idx1, n1 in enumerate(nets):
-        for idx2, n2 in enumerate(nets):
-            if idx1 == idx2:
-                continue
-            ts = time.time()
-            res = utils.play_games(game, args.rounds, None, n1[1], n2[1], steps_before_tau_0=0,
-                                   mcts_searches=cfg.PLAY_MCTS_SEARCHES, mcts_batch_size=cfg.PLAY_MCTS_BATCH_SIZE,
-                                   concurrent=min(args.rounds, 1024), seed=args.seed, uid_base=uid, device=device,
-                                   first_player_mode=2)
-            uid += args.rounds
-            wins, losses, draws = res.count(1), res.count(-1), res.count(0)
-            speed_games = args.rounds / (time.time() - ts)
-            print("%s vs %s -> w=%d, l=%d, d=%d" % (n1[0], n2[0], wins, losses, draws))
-            sys.stderr.write("Speed %.2f games/s\n" % speed_games)
-            sys.stdout.flush()
-            utils.update_counts(total_agent, n1[0], (wins, losses, draws))
-            utils.update_counts(total_agent, n2[0], (losses, wins, draws))
-            utils.update_counts(total_pairs, (n1[0], n2[0]), (wins, losses, draws))
+    per_agent, per_pair = {}, {}
+    say = print if rank == 0 else (lambda *a, **k: None)
+    pairings = list(itertools.permutations(range(len(agents)), 2))  # every ordered pair, first index outermost
+    for k, (i, j) in enumerate(pairings):
+        (name_i, net_i), (name_j, net_j) = agents[i], agents[j]
+        started = time.time()
+        tally = meet(game, net_i, net_j, args.rounds, args.seed, k * args.rounds, device)
+        say("%s vs %s -> %s" % (name_i, name_j, tally))
+        if rank == 0:
+            sys.stderr.write("Speed %.2f games/s\n" % (args.rounds / (time.time() - started)))
+        sys.stdout.flush()
+        utils.update_counts(per_agent, name_i, tally.as_tuple())
+        utils.update_counts(per_agent, name_j, tally.mirrored())
+        utils.update_counts(per_pair, (name_i, name_j), tally.as_tuple())
 
-    leaders = sorted(total_agent.items(), reverse=True, key=lambda p: p[1][0])
-    print("Leaderboard:")
-    for name, (wins, losses, draws) in leaders:
-        print("%s: \t w=%d, l=%d, d=%d" % (name, wins, losses, draws))
-    return total_agent, total_pairs
+    say("Leaderboard:")
+    for name, (w, l, d) in sorted(per_agent.items(), key=lambda item: item[1][0], reverse=True):  # by total wins
+        say("%s: \t w=%d, l=%d, d=%d" % (name, w, l, d))
+    return per_agent, per_pair
 
 
 if __name__ == "__main__":

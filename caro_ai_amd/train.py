@@ -156,11 +156,18 @@ def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_ba
 
 def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="cuda:0", seed=0):
     """challenger (net1) vs champion (net2): `rounds` games, 20 x 16 sims, tau = 0 from move 0, one tree per
-    player; returns challenger_win / (wins + losses + draws)  (train.py:120-149)"""
+    player; returns challenger_win / (wins + losses + draws)  (train.py:120-149).
+    With several ranks each plays a contiguous share of the rounds (round = game uid, so the set of games is the
+    single-rank one) and the three counters are all-reduced: every rank gets the same ratio and takes the same
+    promote / keep decision."""
     from caro_ai_amd.lib.utils import play_games
-    res = play_games(game, rounds, None, challenger, champion, steps_before_tau_0=0, mcts_searches=20,
-                     mcts_batch_size=16, concurrent=rounds, seed=seed, device=device)
-    wins, losses, draws = res.count(1), res.count(-1), res.count(0)
+    rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
+    lo, n = parallel.shard_rounds(rounds, rank, world)
+    res = []
+    if n:
+        res = play_games(game, n, None, challenger, champion, steps_before_tau_0=0, mcts_searches=20,
+                         mcts_batch_size=16, concurrent=n, seed=seed, uid_base=lo, device=device)
+    wins, losses, draws = parallel.allreduce_counts((res.count(1), res.count(-1), res.count(0)), device)
     return wins / max(1, wins + losses + draws)
 
 

@@ -65,6 +65,12 @@ def _worker(rank, world, port, counts, q):
     t = torch.tensor([rank + 1, 10 * (rank + 1), 3], dtype=torch.int64)
     out["sum"] = parallel.allreduce_sum(t.clone()).tolist()
     out["max"] = parallel.allreduce_max(t.clone()).tolist()
+    # 5. arena rounds: contiguous shares + the W/L/D all-reduce that train.evaluate / play.py use
+    rounds = 7
+    lo, n = parallel.shard_rounds(rounds, rank, world)
+    out["rounds"] = list(range(lo, lo + n))
+    fake = [(-1, 0, 1)[u % 3] for u in out["rounds"]]  # "result" of round u
+    out["wld"] = parallel.allreduce_counts((fake.count(1), fake.count(-1), fake.count(0)))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -111,6 +117,9 @@ def test_two_rank_gloo():
     assert res[0]["wsum"] == res[1]["wsum"]
     assert res[0]["sum"] == res[1]["sum"] == [3, 30, 6]
     assert res[0]["max"] == [2, 20, 3]
+    assert res[0]["rounds"] + res[1]["rounds"] == list(range(7))  # every round exactly once, in order
+    allr = [(-1, 0, 1)[u % 3] for u in range(7)]
+    assert res[0]["wld"] == res[1]["wld"] == (allr.count(1), allr.count(-1), allr.count(0))
 
 
 def test_single_process_paths_are_noops():
@@ -124,6 +133,11 @@ def test_single_process_paths_are_noops():
     both = tg.push(_fake_tuples(3, 5))
     assert both["z"].shape[0] == 7 and both["pi"].dtype == torch.float32 and tg.flush() is None
     assert parallel.shard(1024, 0, 1) == {"uid_base": 0, "uid_stride": 1024}
+    assert parallel.shard_rounds(20, 0, 1) == (0, 20) and parallel.allreduce_counts((3, 2, 1)) == (3, 2, 1)
+    for world in (2, 3, 8):
+        shares = [parallel.shard_rounds(20, r, world) for r in range(world)]
+        assert sum(n for _, n in shares) == 20 and all(shares[r + 1][0] == shares[r][0] + shares[r][1]
+                                                       for r in range(world - 1))
     assert parallel.allreduce_sum(torch.tensor([5])).item() == 5
 
 
@@ -227,3 +241,49 @@ def test_exchange_code_runs_on_rccl_with_device_tensors():
     assert q.get(timeout=300) is True
     p.join(timeout=60)
     assert p.exitcode == 0
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), CARO_DIST_BACKEND="gloo")
+    from caro_ai_amd import parallel, train
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.lib.model import Net
+    parallel.init()
+    game = TicTacToe()
+    nets = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        nets.append(Net(game.obs_shape, game.action_space).to("cuda:0").eval())
+    ratio = train.evaluate(game, nets[0], nets[1], rounds=10, device="cuda:0", seed=4)
+    q.put((rank, ratio))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_evaluate_equals_single_rank():
+    """train.evaluate (train.py:120-149) with its 10 rounds split 5 + 5 over two ranks and the W/L/D counters
+    all-reduced: both ranks get the ratio one rank gets playing all 10 rounds (a round is a game uid)."""
+    from caro_ai_amd import train
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.lib.model import Net
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    game = TicTacToe()
+    nets = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        nets.append(Net(game.obs_shape, game.action_space).to("cuda:0").eval())
+    single = train.evaluate(game, nets[0], nets[1], rounds=10, device="cuda:0", seed=4)
+    assert res[0] == res[1] == single
+    assert round(single * 10) == single * 10

@@ -136,3 +136,49 @@ def test_evaluate_ratio_and_device_planes():
     pl = torch.tensor([0, 0], dtype=torch.int32).cuda()
     x = rb.planes(keys, pl).cpu().numpy()
     np.testing.assert_array_equal(x, g.states_to_training_batch([s0, s1], [0, 0]))
+
+
+@pytest.mark.gpu
+def test_train_step_on_gpu_matches_cpu_on_reference_tuples():
+    """f1, anchored on the reference: the (state, player, pi, z) tuples of 32 games recorded from the reference
+    (tests/golden/real_c4_x32.json.gz) + the shipped best_026_12000.dat; ONE round of `train_neural_net`
+    (train.py:62-117: planes, train-mode BN forward, MSE + cross-entropy, SGD 0.1 / 0.9) on cuda:0 against the
+    same call on the CPU, the batch being the whole buffer so that both devices see the same set of rows.
+    Stated tolerance (float32, different summation orders): loss terms 1e-4 relative, every weight and BN
+    statistic after the step within 2e-4 * max(1, |w|)."""
+    import copy
+    from caro_ai_amd import train
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    from tests.conftest import GOLDEN, load_golden
+    g = ConnectFour()
+    d = load_golden("real_c4_x32.json.gz")
+    states, players, pis, zs = [], [], [], []
+    for gm in d["games"]:
+        states += [int(s) for s in gm["states"]]
+        players += gm["players"]
+        pis += gm["pi"]
+        zs += gm["z"]
+    n = 256
+    tup = {"states": torch.from_numpy(g.to_keys(states[:n]).view(np.int64)),
+           "players": torch.tensor(players[:n], dtype=torch.int32),
+           "pi": torch.tensor(pis[:n], dtype=torch.float64), "z": torch.tensor(zs[:n], dtype=torch.int32)}
+    base = Net(g.obs_shape, g.action_space)
+    base.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", d["weights"]), map_location="cpu"))
+    out, nets = {}, {}
+    for dev in ("cpu", "cuda:0"):
+        net = copy.deepcopy(base).to(dev)
+        rb = train.DeviceReplayBuffer(g, n, dev)
+        rb.extend({k: v.to(dev) for k, v in tup.items()})
+        opt = torch.optim.SGD(net.parameters(), lr=cfg.LEARNING_RATE, momentum=0.9)
+        out[dev] = train.train_neural_net(g, rb, net, opt, device=dev, train_rounds=1, batch_size=n)
+        nets[dev] = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    for k in ("loss_total", "loss_value", "loss_policy"):
+        assert abs(out["cpu"][k] - out["cuda:0"][k]) <= 1e-4 * max(1.0, abs(out["cpu"][k])), (k, out)
+    assert out["cpu"]["loss_total"] > 0.1  # a real loss, not a degenerate batch
+    moved = 0.0
+    for k, a in nets["cpu"].items():
+        b = nets["cuda:0"][k]
+        assert torch.all((a - b).abs() <= 2e-4 * torch.clamp(a.abs(), min=1.0)), k
+        moved = max(moved, float((a - base.state_dict()[k].double()).abs().max()))
+    assert moved > 1e-3  # the step did change the weights
