@@ -19,7 +19,7 @@ DEPS = SOURCES + [os.path.join(CSRC, "caro_rules.h"),
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # caro_engine.hip: PUCT / noise arithmetic must not be fused (bit parity with the oracle)
-PER_FILE = {"caro_engine.hip": ["-ffp-contract=off"],
+PER_FILE = {"caro_engine.hip": ["-ffp-contract=off", "-mllvm", "-disable-promote-alloca-to-lds"],
             # keep small per-thread arrays in registers: LDS is budgeted by hand in the net kernel
             "caro_net.hip": ["-mllvm", "-disable-promote-alloca-to-lds"]}
 

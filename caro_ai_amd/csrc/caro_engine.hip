@@ -181,11 +181,37 @@ __device__ __forceinline__ double group_sum_f64(double x) {
   for (int m = 1; m < LPD; m <<= 1) x = x + __shfl_xor(x, m, LPD);
   return x;
 }
+
+// Cross-lane moves inside a descent group on the DPP path (no LDS round trip): xor 1 / xor 2 inside a quad, then
+// the mirror of 8 and of 16 lanes.  After the quad steps every lane of a quad holds the quad's result, so the
+// mirrors pair lanes of different quads / different halves exactly as an xor-butterfly would: the all-reduce of
+// a commutative operation comes out the same in every lane.  Steps of 32 / 64 lanes go through __shfl_xor.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+template <int LPD, class OP>
+__device__ __forceinline__ int group_allreduce_i32(int x, OP op) {
+  if constexpr (LPD >= 2) x = op(x, dpp_i32<0xB1>(x));   // quad_perm [1,0,3,2]
+  if constexpr (LPD >= 4) x = op(x, dpp_i32<0x4E>(x));   // quad_perm [2,3,0,1]
+  if constexpr (LPD >= 8) x = op(x, dpp_i32<0x141>(x));  // row_half_mirror
+  if constexpr (LPD >= 16) x = op(x, dpp_i32<0x140>(x)); // row_mirror
+  if constexpr (LPD >= 32) x = op(x, __shfl_xor(x, 16, 64));
+  if constexpr (LPD >= 64) x = op(x, __shfl_xor(x, 32, 64));
+  return x;
+}
 template <int LPD>
 __device__ __forceinline__ int group_sum_i32(int x) {
-#pragma unroll
-  for (int m = 1; m < LPD; m <<= 1) x = x + __shfl_xor(x, m, LPD);
-  return x;
+  return group_allreduce_i32<LPD>(x, [](int a, int b) { return a + b; });
+}
+template <int LPD>
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t x) {
+  return (uint32_t)group_allreduce_i32<LPD>((int)x, [](int a, int b) { return (int)max((uint32_t)a, (uint32_t)b); });
+}
+// float -> uint32 with the same order (-inf lowest); -0.0 must not reach it (callers add +0.0f first)
+__device__ __forceinline__ uint32_t orderable(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
 }
 
 // One Dirichlet row of caro_noise.h for the LPD lanes of a descent group:
@@ -209,6 +235,150 @@ __device__ __forceinline__ void noise_group(uint64_t key, int l, int A, double a
 }
 
 // ------------------------------------------------------------------ select
+// State of one descent; every lane of the descent's group holds the same copy.
+template <class GEO>
+struct Descent {
+  typename GEO::R::Board cur;
+  typename GEO::R::Aux aux;
+  int player, depth, status;
+  float value;
+};
+
+// One level of find_leaf (lib/mcts.py:123-147) for the descents of a wave.  ROOT: the level at the game's root
+// (_add_noise, float64 scores, mcts.py:131-132); otherwise float32 scores.  Returns false when the descent has
+// ended (state not in the tree = the leaf, a win, or a full board).  Everything a group needs from its other lanes
+// travels by DPP / ballot; the only memory access is the node's row.
+template <class GEO, bool ROOT>
+__device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, int t, const uint64_t* __restrict__ tkeys,
+                                              const uint32_t* __restrict__ tedges, int32_t* __restrict__ pn,
+                                              int32_t* __restrict__ pa, int l, int first, const double* nz) {
+  using R = typename GEO::R;
+  constexpr int LPD = GEO::LPD, APL = GEO::APL, AP = GEO::AP, KW = GEO::KW;
+  // one latency per level: the key and the action rows of the home slot are loaded together
+  const uint32_t slot = home_slot<R>(v, d.cur);
+  const uint32_t* row = tedges + (size_t)slot * 4 * AP;
+  uint32_t nraw[APL], wraw[APL];
+  float q[APL], p[APL];
+#pragma unroll
+  for (int j = 0; j < APL; ++j) {
+    const int a = l * APL + j;
+    nraw[j] = row[a];
+    if (ROOT) wraw[j] = row[AP + a];
+    q[j] = __uint_as_float(row[2 * AP + a]);
+    p[j] = __uint_as_float(row[3 * AP + a]);
+  }
+  int node;
+  {
+    const uint64_t* k = tkeys + (size_t)slot * KW;
+    const uint64_t k0 = k[0];
+    bool eq = k0 == d.cur.w[0];
+#pragma unroll
+    for (int w = 1; w < KW; ++w) eq = eq && (k[w] == d.cur.w[w]);
+    if (eq) node = (int)slot;
+    else if (k0 == EMPTY_KEY) node = -1;
+    else {  // collision with another board: walk the probe sequence, then reload the rows
+      node = probe_from<R>(v, t, d.cur, (slot + 1u) & ((uint32_t)v.hcap - 1u));
+      if (node >= 0) {
+        row = tedges + (size_t)node * 4 * AP;
+#pragma unroll
+        for (int j = 0; j < APL; ++j) {
+          const int a = l * APL + j;
+          nraw[j] = row[a];
+          if (ROOT) wraw[j] = row[AP + a];
+          q[j] = __uint_as_float(row[2 * AP + a]);
+          p[j] = __uint_as_float(row[3 * AP + a]);
+        }
+      }
+    }
+  }
+  if (node < 0) return false;  // not in the tree: this is the leaf (mcts.py:123)
+  int nsum = 0;
+#pragma unroll
+  for (int j = 0; j < APL; ++j) nsum += (int)(nraw[j] & NMASK);
+  nsum = group_sum_i32<LPD>(nsum);
+  int besta;
+  if (ROOT) {
+    // _add_noise (mcts.py:48-62) -> float64 probs, float64 scores, first maximum by butterfly
+    const double sq = caro_sqrt((double)nsum);  // m.sqrt(sum(counts)), mcts.py:79
+    const double c64 = (double)v.c_puct;
+    const float keepf = (float)(1.0 - v.explore);
+    double best = -__builtin_huge_val();
+    besta = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < APL; ++j) {
+      const int a = l * APL + j;
+      const int n = (int)(nraw[j] & NMASK);
+      const float keep = keepf * p[j];                            // py float * float32 -> float32
+      const double prob = (double)keep + v.explore * nz[j];       // float32 + float64 -> float64
+      const double u = ((c64 * prob) * sq) / (double)(1 + n);
+      double qd;
+      if (nraw[j] & NSTRONG) qd = (double)q[j];                   // np.float32 Q
+      else if (n > 0) qd = (double)__uint_as_float(wraw[j]) / (double)n;  // python-float W / int
+      else qd = 0.0;
+      double sc = qd + u;
+      if (!R::legal(v.gp, d.cur, a)) sc = -__builtin_huge_val();
+      if (sc > best || (sc == best && a < besta)) {
+        best = sc;
+        besta = a;
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < LPD; m <<= 1) {  // np.argmax: first maximum (mcts.py:136)
+      const double ob = __shfl_xor(best, m, LPD);
+      const int oa = __shfl_xor(besta, m, LPD);
+      if (ob > best || (ob == best && oa < besta)) {
+        best = ob;
+        besta = oa;
+      }
+    }
+  } else {
+    // Q + ((c * P) * sqrt(sum N)) / (1 + N) in float32, no contraction (mcts.py:79-84 under numpy >= 2).
+    // float32(sqrt(float64(n))) == sqrtf(float32(n)) for n < 2^24: rounding a correctly rounded 53-bit root
+    // again to 24 bits is innocuous (53 >= 2 * 24 + 2), so the float64 root is not needed here.
+    const float sqf = sqrtf((float)nsum);  // IEEE correctly rounded (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
+    const float c32 = v.c_puct;
+    float bs = -__builtin_huge_valf();
+    int ba = l * APL;
+#pragma unroll
+    for (int j = 0; j < APL; ++j) {
+      const int a = l * APL + j;
+      const int n = (int)(nraw[j] & NMASK);
+      float tt = c32 * p[j];
+      tt = tt * sqf;
+      tt = tt / (float)(1 + n);
+      float sc = q[j] + tt;
+      if (!R::legal(v.gp, d.cur, a)) sc = -__builtin_huge_valf();
+      if (sc > bs) {  // strict: the lowest action of the lane keeps a tie
+        bs = sc;
+        ba = a;
+      }
+    }
+    // first maximum of the group (np.argmax, mcts.py:136): the maximum by DPP, then the lowest lane holding it
+    const uint32_t u = orderable(bs + 0.0f);
+    const uint32_t um = group_max_u32<LPD>(u);
+    const uint64_t holders = group_bits<LPD>(__ballot(u == um), first);
+    besta = __shfl(ba, __ffsll((unsigned long long)holders) - 1, LPD);
+  }
+  if (l == 0) {
+    pn[d.depth] = node;
+    pa[d.depth] = besta;
+  }
+  const bool won = R::template move_group<LPD>(v.gp, d.cur, d.aux, besta, d.player, l, first);  // game.move, mcts.py:138
+  d.player ^= 1;
+  ++d.depth;
+  if (won) {  // mcts.py:140-142
+    d.status = ST_TERMINAL;
+    d.value = -1.0f;
+    return false;
+  }
+  if (R::full(v.gp, d.cur)) {  // mcts.py:145-146
+    d.status = ST_TERMINAL;
+    d.value = 0.0f;
+    return false;
+  }
+  return d.depth < v.maxd;
+}
+
 // `rows` (fused form, see k_tree): when non-null the block also places its unique leaves itself, in SLOT rows:
 // the j-th unique leaf of game g goes to row g * B + j of planes / leaf_keys (and its priors / value come back in
 // the same row), so no block needs to know what the others found.  rows[cls] only accumulates the launch's
@@ -225,6 +395,7 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
   const int g = blockIdx.x;
   const int tid = threadIdx.x;
   const int b = tid / LPD, l = tid % LPD;
+  const int first = (tid & 63) - l;  // first lane of this descent's group inside its wave
 
   __shared__ uint64_t s_key[MAXB][KW];
   __shared__ int s_status[MAXB];
@@ -240,154 +411,48 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
     }
     return;
   }
-  unsigned long long st0 = 0, st_rows = 0, st_noise = 0, st_loop = 0;
+  unsigned long long st0 = 0, st_noise = 0, st_root = 0, st_loop = 0;
   if (v.dbg) st0 = __builtin_amdgcn_s_memtime();
-  const Board root = load_board<R>(v.root + (size_t)g * KW);
+  Descent<GEO> d;
+  d.cur = load_board<R>(v.root + (size_t)g * KW);
+  d.aux = R::aux_of(v.gp, d.cur);
   const int player0 = v.player[g];
+  d.player = player0;
+  d.depth = 0;
+  d.status = ST_LEAF;
+  d.value = 0.0f;
   const int t = g * v.n_stores + (v.n_stores == 2 ? player0 : 0);
-  const uint32_t ply = (uint32_t)v.ply[g];
-  const uint64_t uid = v.uid[g];
   const int A = v.A;
-
-  Board cur = root;
-  int player = player0;
-  int depth = 0;
-  int status = ST_LEAF;
-  float value = 0.0f;
   int32_t* pn = v.path_node + ((size_t)g * v.maxB + b) * v.maxd;
   int32_t* pa = v.path_act + ((size_t)g * v.maxB + b) * v.maxd;
-  const float c32 = v.c_puct;
-  const double c64 = (double)v.c_puct;
-
   const size_t tb = tbase(v, t);
   const uint64_t* tkeys = v.node_key + tb * KW;
   const uint32_t* tedges = v.edges + tb * 4 * AP;
-  uint32_t slot = home_slot<R>(v, cur);
-  while (depth < v.maxd) {
-    // one latency per level: the key and the action rows of the home slot are loaded together
-    const uint32_t* row = tedges + (size_t)slot * 4 * AP;
-    uint32_t nraw[APL];
-    float q[APL], p[APL];
+
+  // the descent's Dirichlet row (only used if the root is in the tree; generated while the root's row is on its way)
+  double nz[APL];
+  if (noise) {
 #pragma unroll
     for (int j = 0; j < APL; ++j) {
       const int a = l * APL + j;
-      nraw[j] = row[a];
-      q[j] = __uint_as_float(row[2 * AP + a]);
-      p[j] = __uint_as_float(row[3 * AP + a]);
+      nz[j] = a < A ? noise[((size_t)g * B + b) * A + a] : 0.0;
     }
-    int node;
-    {
-      const uint64_t* k = tkeys + (size_t)slot * KW;
-      const uint64_t k0 = k[0];
-      bool eq = k0 == cur.w[0];
-#pragma unroll
-      for (int w = 1; w < KW; ++w) eq = eq && (k[w] == cur.w[w]);
-      if (eq) node = (int)slot;
-      else if (k0 == EMPTY_KEY) node = -1;
-      else {  // collision with another board: walk the probe sequence, then reload the rows
-        node = probe_from<R>(v, t, cur, (slot + 1u) & ((uint32_t)v.hcap - 1u));
-        if (node >= 0) {
-          row = tedges + (size_t)node * 4 * AP;
-#pragma unroll
-          for (int j = 0; j < APL; ++j) {
-            const int a = l * APL + j;
-            nraw[j] = row[a];
-            q[j] = __uint_as_float(row[2 * AP + a]);
-            p[j] = __uint_as_float(row[3 * AP + a]);
-          }
-        }
-      }
-    }
-    if (node < 0) break;  // not in the tree: this is the leaf (mcts.py:123)
-    if (v.dbg && depth == 0) st_rows = __builtin_amdgcn_s_memtime();
-    int nsum = 0;
-#pragma unroll
-    for (int j = 0; j < APL; ++j) nsum += (int)(nraw[j] & NMASK);
-    nsum = group_sum_i32<LPD>(nsum);
-    const double sq = caro_sqrt((double)nsum);  // m.sqrt(sum(counts)), mcts.py:79
-    double best = -__builtin_huge_val();
-    int besta = 0x7fffffff;
-    if (depth == 0) {
-      // root: _add_noise (mcts.py:48-62) -> float64 probs, float64 scores
-      double nz[APL];
-      if (noise) {
-#pragma unroll
-        for (int j = 0; j < APL; ++j) {
-          const int a = l * APL + j;
-          nz[j] = a < A ? noise[((size_t)g * B + b) * A + a] : 0.0;
-        }
-      } else {
-        const uint64_t key = caro_noise_key(v.seed, uid, ply, (uint32_t)(mb_index * B + b));
-        noise_group<LPD, APL>(key, l, A, v.alpha, nz);
-      }
-      if (v.dbg) st_noise = __builtin_amdgcn_s_memtime();
-      const float keepf = (float)(1.0 - v.explore);
-#pragma unroll
-      for (int j = 0; j < APL; ++j) {
-        const int a = l * APL + j;
-        const int n = (int)(nraw[j] & NMASK);
-        const float keep = keepf * p[j];                            // py float * float32 -> float32
-        const double prob = (double)keep + v.explore * nz[j];       // float32 + float64 -> float64
-        const double u = ((c64 * prob) * sq) / (double)(1 + n);
-        double qd;
-        if (nraw[j] & NSTRONG) qd = (double)q[j];                   // np.float32 Q
-        else if (n > 0) qd = (double)__uint_as_float(row[AP + a]) / (double)n;  // python-float W / int
-        else qd = 0.0;
-        double sc = qd + u;
-        if (!R::legal(v.gp, cur, a)) sc = -__builtin_huge_val();
-        if (sc > best || (sc == best && a < besta)) {
-          best = sc;
-          besta = a;
-        }
-      }
-    } else {
-      const float sqf = (float)sq;
-#pragma unroll
-      for (int j = 0; j < APL; ++j) {
-        const int a = l * APL + j;
-        const int n = (int)(nraw[j] & NMASK);
-        float tt = c32 * p[j];
-        tt = tt * sqf;
-        tt = tt / (float)(1 + n);
-        double sc = (double)(q[j] + tt);
-        if (!R::legal(v.gp, cur, a)) sc = -__builtin_huge_val();
-        if (sc > best || (sc == best && a < besta)) {
-          best = sc;
-          besta = a;
-        }
-      }
-    }
-    // np.argmax: first maximum (mcts.py:136)
-#pragma unroll
-    for (int m = 1; m < LPD; m <<= 1) {
-      const double ob = __shfl_xor(best, m, LPD);
-      const int oa = __shfl_xor(besta, m, LPD);
-      if (ob > best || (ob == best && oa < besta)) {
-        best = ob;
-        besta = oa;
-      }
-    }
-    if (l == 0) {
-      pn[depth] = node;
-      pa[depth] = besta;
-    }
-    const bool won = R::move(v.gp, cur, besta, player);  // game.move, mcts.py:138
-    player ^= 1;
-    ++depth;
-    if (won) {  // mcts.py:140-142
-      status = ST_TERMINAL;
-      value = -1.0f;
-      break;
-    }
-    if (R::full(v.gp, cur)) {  // mcts.py:145-146
-      status = ST_TERMINAL;
-      value = 0.0f;
-      break;
-    }
-    slot = home_slot<R>(v, cur);
+  } else {
+    const uint64_t key = caro_noise_key(v.seed, v.uid[g], (uint32_t)v.ply[g], (uint32_t)(mb_index * B + b));
+    noise_group<LPD, APL>(key, l, A, v.alpha, nz);
   }
+  if (v.dbg) st_noise = __builtin_amdgcn_s_memtime();
 
+  bool live = descend_level<GEO, true>(v, d, t, tkeys, tedges, pn, pa, l, first, nz);
+  if (v.dbg) st_root = __builtin_amdgcn_s_memtime();
+  while (__any(live)) {
+    if (live) live = descend_level<GEO, false>(v, d, t, tkeys, tedges, pn, pa, l, first, nullptr);
+  }
   if (v.dbg) st_loop = __builtin_amdgcn_s_memtime();
+
+  const Board cur = d.cur;
+  const int status = d.status, depth = d.depth, player = d.player;
+  const float value = d.value;
   if (l == 0) {
 #pragma unroll
     for (int w = 0; w < KW; ++w) s_key[b][w] = cur.w[w];
@@ -398,18 +463,18 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
   __syncthreads();
   // planned-set de-duplication (mcts.py:272-278): first occurrence of a new leaf is kept
   if (l == 0) {
-    int first = 0;
+    int first_seen = 0;
     if (status == ST_LEAF) {
-      first = 1;
+      first_seen = 1;
       for (int bb = 0; bb < b; ++bb) {
         if (s_status[bb] != ST_LEAF) continue;
         bool eq = true;
 #pragma unroll
         for (int w = 0; w < KW; ++w) eq = eq && (s_key[bb][w] == cur.w[w]);
-        if (eq) first = 0;
+        if (eq) first_seen = 0;
       }
     }
-    s_first[b] = first;
+    s_first[b] = first_seen;
   }
   __syncthreads();
   if (l == 0) {
@@ -436,18 +501,19 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
     v.g_nleaf[g] = nleaf;
     v.g_tree[g] = t;
     v.g_class[g] = v.n_nets == 2 ? player0 : 0;
-    if (v.dbg) {  // cycles since kernel start: root rows arrived | noise generated | descents done | end; max depth
-      unsigned long long* d = v.dbg + (size_t)g * 8;
+    if (v.dbg) {  // cycles since kernel start: noise generated | root level done | descents done | end; max depth
+      unsigned long long* dd = v.dbg + (size_t)g * 8;
       int maxd = 0;
       for (int bb = 0; bb < B; ++bb) maxd = s_depth[bb] > maxd ? s_depth[bb] : maxd;
-      d[0] = st_rows - st0; d[1] = st_noise - st0; d[2] = st_loop - st0;
-      d[3] = __builtin_amdgcn_s_memtime() - st0; d[4] = (unsigned long long)maxd;
+      dd[0] = st_noise - st0; dd[1] = st_root - st0; dd[2] = st_loop - st0;
+      dd[3] = __builtin_amdgcn_s_memtime() - st0; dd[4] = (unsigned long long)maxd;
     }
-    unsigned long long* ctr = v.counters + (size_t)g * C_N;  // this block is the only writer of game g's row
-    ctr[C_SIMS] += (unsigned long long)B;
-    ctr[C_LEVELS] += (unsigned long long)levels;
-    ctr[C_TERMINALS] += (unsigned long long)term;
-    ctr[C_DROPPED] += (unsigned long long)drop;
+    // this block is the only writer of game g's tallies; adds without a return value do not wait for memory
+    unsigned long long* ctr = v.counters + (size_t)g * C_N;
+    atomicAdd(ctr + C_SIMS, (unsigned long long)B);
+    atomicAdd(ctr + C_LEVELS, (unsigned long long)levels);
+    atomicAdd(ctr + C_TERMINALS, (unsigned long long)term);
+    atomicAdd(ctr + C_DROPPED, (unsigned long long)drop);
     if (rows) {
       const int cls = v.n_nets == 2 ? player0 : 0;
       if (nleaf) atomicAdd(rows + cls, nleaf);
@@ -456,7 +522,6 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
     }
   }
   if (rows) {
-    __syncthreads();
     const int HW = v.HW;
     int local = 0;
     for (int bb = 0; bb < B; ++bb) {
@@ -468,7 +533,7 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
       const int who = s_player[bb];
       float* dst = planes + (size_t)rowi * 2 * HW;
       for (int i = tid; i < 2 * HW; i += blockDim.x) dst[i] = R::plane(v.gp, brd, who, i / HW, i % HW);
-      if (leaf_keys && tid < KW) leaf_keys[(size_t)rowi * KW + tid] = brd.w[tid];
+      if (leaf_keys && tid < KW) leaf_keys[(size_t)rowi * KW + tid] = s_key[bb][tid];
     }
   }
 }
@@ -522,7 +587,7 @@ __global__ void k_encode(View v, int B, float* __restrict__ planes, uint64_t* __
     const int who = v.d_player[di];
     float* dst = planes + (size_t)rowi * 2 * HW;
     for (int i = tid; i < 2 * HW; i += blockDim.x) dst[i] = R::plane(v.gp, brd, who, i / HW, i % HW);
-    if (leaf_keys && tid < KW) leaf_keys[(size_t)rowi * KW + tid] = brd.w[tid];
+    if (leaf_keys && tid < KW) leaf_keys[(size_t)rowi * KW + tid] = v.d_key[di * KW + tid];
   }
 }
 
@@ -552,10 +617,15 @@ __device__ __forceinline__ void backup_path(const View& v, int t, float value, b
 // flattened into (edge, +-value) entries in reference order (terminals by sim index, then new leaves first
 // seen; inside a path from the leaf upwards), the first entry of every distinct edge becomes its owner and
 // applies all entries of that edge in order, and the owners' read-modify-writes proceed in parallel.
+// The block is latency bound, so the code is laid out as four rounds of independent loads:
+//   1  per descent: status, path length, leaf rank, terminal value, leaf board
+//   2  per leaf: the key in its home slot, its net value;  3  the path entries (and the priors, off the chain)
+//   4  the edges the owners update.
 template <class GEO>
 __device__ __forceinline__ void expand_body(const View& v, int B, const float* __restrict__ probs,
                                             const float* __restrict__ values) {
   using R = typename GEO::R;
+  using Board = typename R::Board;
   constexpr int AP = GEO::AP, KW = GEO::KW;
   constexpr int MAXE = 512;  // entries held in LDS; longer queues fall back to the sequential form
   __shared__ int e_node[MAXE];
@@ -563,6 +633,14 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
   __shared__ float e_val[MAXE];
   __shared__ unsigned char e_strong[MAXE];
   __shared__ int s_total;
+  __shared__ uint64_t s_brd[MAXB][KW];
+  __shared__ int s_node[MAXB], s_row[MAXB];
+  __shared__ uint32_t s_home[MAXB];
+  __shared__ unsigned char s_free[MAXB];
+  __shared__ int q_len[MAXB], q_off[MAXB], q_b[MAXB];   // queue position -> length, entry offset, descent
+  __shared__ float q_val[MAXB];
+  __shared__ unsigned char q_strong[MAXB];
+  __shared__ int s_nq;
   const int g = blockIdx.x;
   if (v.done[g]) return;
   const int lane = threadIdx.x;
@@ -572,94 +650,76 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
   const int base = v.n_nodes[t];
   const bool overflow = base + nleaf > v.cap;
   const int A = v.A;
-  if (!overflow) {
-    // _create_node for the unique leaves.  The reference inserts them one after another (first-seen order); here
-    // the home slots of ALL leaves are fetched first (one memory latency for the block instead of one per leaf),
-    // then lane 0 places them in that same order: a leaf whose home slot is free and not taken by an earlier leaf
-    // of this minibatch needs no further memory access, only collisions walk the probe sequence.  Slot choice is
-    // therefore identical to sequential insertion.
-    __shared__ int s_node[MAXB], s_row[MAXB];
-    __shared__ uint32_t s_home[MAXB];
-    __shared__ unsigned char s_free[MAXB];
-    if (lane < B) {
-      const size_t di = (size_t)g * v.maxB + lane;
-      s_node[lane] = -2;  // not a leaf
-      if (v.d_status[di] == ST_LEAF) {
-        const typename R::Board brd = load_board<R>(v.d_key + di * KW);
-        const uint32_t hs = home_slot<R>(v, brd);
-        s_home[lane] = hs;
-        s_free[lane] = v.node_key[(tbase(v, t) + hs) * KW] == EMPTY_KEY;
-        s_row[lane] = off + v.d_local[di];
-        s_node[lane] = -1;
-      }
-    }
-    __syncthreads();
-    if (lane == 0) {
-      for (int b = 0; b < B; ++b) {
-        if (s_node[b] == -2) continue;
-        bool fast = s_free[b] != 0;
-        for (int bb = 0; bb < b && fast; ++bb) fast = !(s_node[bb] >= 0 && (uint32_t)s_node[bb] == s_home[b]);
-        const size_t di = (size_t)g * v.maxB + b;
-        const typename R::Board brd = load_board<R>(v.d_key + di * KW);
-        if (fast) {
-          uint64_t* k = v.node_key + (tbase(v, t) + s_home[b]) * KW;
-#pragma unroll
-          for (int w = KW - 1; w >= 0; --w) k[w] = brd.w[w];
-          s_node[b] = (int)s_home[b];
-        } else {
-          s_node[b] = insert_key<R>(v, t, brd);
-        }
-      }
-    }
-    __syncthreads();
-    // the four action rows of every new node, lanes over (leaf, action): one pass for B * AP <= block size
-    for (int idx = lane; idx < B * AP; idx += blockDim.x) {
-      const int b = idx / AP, a = idx - b * AP;
-      const int node = s_node[b];
-      if (node < 0) continue;  // not a leaf (a failed insert cannot happen while n_nodes <= cap < hcap)
-      uint32_t* row = v.edges + (tbase(v, t) + node) * 4 * AP;
-      row[a] = 0u;
-      row[AP + a] = 0u;
-      row[2 * AP + a] = 0u;
-      row[3 * AP + a] = a < A ? __float_as_uint(probs[(size_t)s_row[b] * A + a]) : 0u;
-    }
-  }
-  // Flatten the backup queue, lane-parallel.  Queue order (reference): terminals by sim index, then new
-  // leaves by first-seen index; inside one backup from the leaf upwards.  Lane b first loads descent b's
-  // record (one memory latency for all), a scan over the queue order gives every descent its entry offset,
-  // then lane j loads path entry j (one more latency for all).
-  __shared__ int q_len[MAXB], q_off[MAXB], q_b[MAXB];   // queue position -> length, entry offset, descent
-  __shared__ float q_val[MAXB];
-  __shared__ unsigned char q_strong[MAXB];
-  __shared__ int s_nq;
+  const size_t tb = tbase(v, t);
+  // ---- round 1: everything select left behind for descent `lane`
   int my_st = ST_DROPPED, my_len = 0, my_local = 0;
   float my_val = 0.f;
+  Board brd;
+#pragma unroll
+  for (int w = 0; w < KW; ++w) brd.w[w] = 0;
   if (lane < B) {
     const size_t di = (size_t)g * v.maxB + lane;
     my_st = v.d_status[di];
     my_len = v.path_len[di];
     my_local = v.d_local[di];
-    if (my_st == ST_TERMINAL) my_val = v.d_value[di];
-    else if (my_st == ST_LEAF && !overflow) my_val = values[off + my_local];
+    my_val = v.d_value[di];   // meaningful for terminals
+    brd = load_board<R>(v.d_key + di * KW);
   }
-  if (lane == 0) {
-    unsigned long long* ctr = v.counters + (size_t)g * C_N;
-    if (overflow) {
-      ctr[C_OVERFLOW] += 1ull;
-    } else {
-      v.n_nodes[t] = base + nleaf;
-      v.n_created[t] += nleaf;
-      ctr[C_EXPANSIONS] += (unsigned long long)nleaf;
+  const bool is_leaf = lane < B && my_st == ST_LEAF && !overflow;
+  // ---- round 2: home slot of the leaf, its value
+  if (lane < B) {
+    s_node[lane] = -2;  // not a leaf
+    if (is_leaf) {
+      const uint32_t hs = home_slot<R>(v, brd);
+      const uint64_t k0 = v.node_key[(tb + hs) * KW];
+      my_val = values[off + my_local];
+      s_home[lane] = hs;
+      s_free[lane] = k0 == EMPTY_KEY;
+      s_row[lane] = off + my_local;
+      s_node[lane] = -1;
+#pragma unroll
+      for (int w = 0; w < KW; ++w) s_brd[lane][w] = brd.w[w];
     }
   }
-  // queue position of descent `lane`: terminals keep their sim order, leaves follow in first-seen order
+  __syncthreads();
+  if (!overflow) {
+    // _create_node.  The reference inserts the leaves one after another (first-seen order); lane 0 places them in
+    // that same order: a leaf whose home slot is free and not taken by an earlier leaf of this minibatch needs no
+    // memory access at all, only collisions walk the probe sequence.  Slot choice = sequential insertion.
+    if (lane == 0) {
+      for (int b = 0; b < B; ++b) {
+        if (s_node[b] == -2) continue;
+        bool fast = s_free[b] != 0;
+        for (int bb = 0; bb < b && fast; ++bb) fast = !(s_node[bb] >= 0 && (uint32_t)s_node[bb] == s_home[b]);
+        Board lb;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) lb.w[w] = s_brd[b][w];
+        if (fast) {
+          uint64_t* k = v.node_key + (tb + s_home[b]) * KW;
+#pragma unroll
+          for (int w = KW - 1; w >= 0; --w) k[w] = lb.w[w];
+          s_node[b] = (int)s_home[b];
+        } else {
+          s_node[b] = insert_key<R>(v, t, lb);
+        }
+      }
+      unsigned long long* ctr = v.counters + (size_t)g * C_N;
+      v.n_nodes[t] = base + nleaf;
+      v.n_created[t] += nleaf;
+      atomicAdd(ctr + C_EXPANSIONS, (unsigned long long)nleaf);
+    }
+  } else if (lane == 0) {
+    atomicAdd(v.counters + (size_t)g * C_N + C_OVERFLOW, 1ull);
+  }
+  // Flatten the backup queue, lane-parallel.  Queue order (reference): terminals by sim index, then new
+  // leaves by first-seen index; inside one backup from the leaf upwards.
   const unsigned long long m_term = __ballot(lane < B && my_st == ST_TERMINAL);
-  const unsigned long long m_leaf = __ballot(lane < B && my_st == ST_LEAF && !overflow);
+  const unsigned long long m_leaf = __ballot(is_leaf);
   const int n_term = __popcll(m_term);
   const unsigned long long below = (1ull << lane) - 1ull;
   int qpos = -1;
   if (lane < B && my_st == ST_TERMINAL) qpos = __popcll(m_term & below);
-  else if (lane < B && my_st == ST_LEAF && !overflow) qpos = n_term + __popcll(m_leaf & below);
+  else if (is_leaf) qpos = n_term + __popcll(m_leaf & below);
   if (qpos >= 0) {
     q_len[qpos] = my_len;
     q_b[qpos] = lane;
@@ -667,7 +727,7 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
     q_strong[qpos] = my_st == ST_LEAF;
   }
   if (lane == 0) s_nq = n_term + __popcll(m_leaf);
-  __syncthreads();
+  __syncthreads();  // also publishes s_node of the new leaves
   const int nq = s_nq;
   if (lane == 0) {  // exclusive scan over at most B queue items
     int acc = 0;
@@ -679,6 +739,30 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
   }
   __syncthreads();
   const int total = s_total;
+  // ---- round 3: the path entries; next to them (off the dependent chain) the rows of the new nodes
+  if (total <= MAXE)
+    for (int j = lane; j < total; j += blockDim.x) {
+      int k = 0;
+      while (k + 1 < nq && q_off[k + 1] <= j) ++k;  // queue item of entry j
+      const int r = j - q_off[k];                    // r-th entry of that backup, counted from the leaf
+      const int i = q_len[k] - 1 - r;
+      const size_t di = (size_t)g * v.maxB + q_b[k];
+      e_node[j] = v.path_node[di * v.maxd + i];
+      e_act[j] = (short)v.path_act[di * v.maxd + i];
+      e_val[j] = (r & 1) ? q_val[k] : -q_val[k];     // cur = -value at the leaf's parent, sign flips each ply (mcts.py:238,246)
+      e_strong[j] = q_strong[k];
+    }
+  if (!overflow)
+    for (int idx = lane; idx < B * AP; idx += blockDim.x) {  // lanes over (leaf, action)
+      const int b = idx / AP, a = idx - b * AP;
+      const int node = s_node[b];
+      if (node < 0) continue;  // not a leaf (a failed insert cannot happen while n_nodes <= cap < hcap)
+      uint32_t* row = v.edges + (tb + node) * 4 * AP;
+      row[a] = 0u;
+      row[AP + a] = 0u;
+      row[2 * AP + a] = 0u;
+      row[3 * AP + a] = a < A ? __float_as_uint(probs[(size_t)s_row[b] * A + a]) : 0u;
+    }
   if (total > MAXE) {  // queue does not fit the LDS list: apply sequentially, in order (never at B*depth <= 512)
     if (lane == 0)
       for (int k = 0; k < nq; ++k) {
@@ -687,26 +771,15 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
       }
     return;
   }
-  for (int j = lane; j < total; j += blockDim.x) {
-    int k = 0;
-    while (k + 1 < nq && q_off[k + 1] <= j) ++k;  // queue item of entry j
-    const int r = j - q_off[k];                    // r-th entry of that backup, counted from the leaf
-    const int len = q_len[k];
-    const int i = len - 1 - r;
-    const size_t di = (size_t)g * v.maxB + q_b[k];
-    e_node[j] = v.path_node[di * v.maxd + i];
-    e_act[j] = (short)v.path_act[di * v.maxd + i];
-    e_val[j] = (r & 1) ? q_val[k] : -q_val[k];     // cur = -value at the leaf's parent, sign flips each ply (mcts.py:238,246)
-    e_strong[j] = q_strong[k];
-  }
   __syncthreads();
+  // ---- round 4: the owners' read-modify-writes
   const int n = total;
   for (int j = lane; j < n; j += blockDim.x) {
     const int node = e_node[j], a = e_act[j];
     bool owner = true;
     for (int k = 0; k < j; ++k) owner = owner && !(e_node[k] == node && e_act[k] == a);
     if (!owner) continue;
-    uint32_t* row = v.edges + (tbase(v, t) + node) * 4 * AP;
+    uint32_t* row = v.edges + (tb + node) * 4 * AP;
     const uint32_t nraw = row[a];
     int cnt = (int)(nraw & NMASK);
     uint32_t strong = nraw & NSTRONG;

@@ -6,13 +6,22 @@
 //   cell (column c, row r from the bottom) at bit 62-(6c+r) holding the token,
 //   3-bit free-slot count of column c at bits [3(6-c)+2 : 3(6-c)].
 //   Nothing is decoded into lists; moves, legality, the win test and the NN
-//   planes are computed on the packed word.
+//   planes are computed on the packed word.  The win test (connect_four.py:206-239:
+//   a run of four through the new stone, vertical / horizontal / both diagonals)
+//   is a branch-free shift-AND over the mover's stones: along a direction with bit
+//   stride s, x & x<<s & x<<2s & x<<3s flags every window of four, a row mask
+//   keeps windows from wrapping into the next column, and the windows that
+//   contain the new stone decide.
 // m,n,k game (reference lib/game/tictactoe/tictactoe.py, tictactoe_helpers.py):
 //   two bit-planes of n*n bits (cell i = row*n + col, row-major from the top
 //   left, as tictactoe.py:14-24 numbers the squares): plane 0 = cells holding
 //   token 0, plane 1 = cells holding token 1, W64 64-bit words each.  The
 //   reference's base-10 digit-string int (225 digits at 15x15) is converted at
-//   the Python edge only.
+//   the Python edge only.  check_win (tictactoe_helpers.py:7-179: any run >= k on
+//   the row, column, diagonal and anti-diagonal through the move) gathers each of
+//   the four lines into an n-bit word and finds a run with k-1 shift-ANDs; in the
+//   tree kernel the lanes of a descent gather the 4n cells with ONE ballot
+//   (move_group).
 #ifndef CARO_RULES_H
 #define CARO_RULES_H
 
@@ -20,6 +29,7 @@
 
 #if defined(__HIPCC__)
 #define CR_HD __host__ __device__ __forceinline__
+#define CR_D __device__ __forceinline__
 #else
 #define CR_HD inline
 #endif
@@ -46,11 +56,28 @@ CR_HD int popc64(uint64_t x) {
 #endif
 }
 
+#if defined(__HIPCC__)
+// bits [first, first + LPD) of a wave ballot: the lanes of one descent group
+template <int LPD>
+CR_D uint64_t group_bits(uint64_t ballot, int first) {
+  if constexpr (LPD == 64) return ballot;
+  else return (ballot >> first) & ((1ull << LPD) - 1ull);
+}
+#endif
+
 // ------------------------------------------------------------------ connect four
 struct C4Rules {
   static constexpr int KW = 1;
   static constexpr int A = 7, ROWS = 6, COLS = 7, HW = 42;
   using Board = BoardT<1>;
+  // the occupied cells, carried along a descent next to the state int (the int alone cannot tell an empty cell
+  // from a token-0 cell without the column heights)
+  struct Aux {
+    uint64_t occ;
+  };
+
+  static constexpr uint64_t ROWS012 = 0x71C71C71C7000000ULL;  // cells with r in {0,1,2}: 0b111000 per column group
+  static constexpr uint64_t ROWS345 = 0x0E38E38E38E00000ULL;  // cells with r in {3,4,5}: 0b000111 per column group
 
   static CR_HD Board initial(const GameParams&) {
     Board b;
@@ -60,46 +87,72 @@ struct C4Rules {
   static CR_HD int free_of(uint64_t s, int c) { return (int)((s >> (3 * (6 - c))) & 7ULL); }
   static CR_HD int height(uint64_t s, int c) { return 6 - free_of(s, c); }
   static CR_HD int cell(uint64_t s, int c, int r) { return (int)((s >> (62 - (6 * c + r))) & 1ULL); }
-  // cell (c,r) is occupied by `player`
-  static CR_HD bool is(uint64_t s, int c, int r, int player) {
-    return r >= 0 && r < height(s, c) && cell(s, c, r) == player;
-  }
   static CR_HD bool legal(const GameParams&, const Board& b, int a) {  // connect_four.py:157-165
     return a < 7 && free_of(b.w[0], a) > 0;
   }
   static CR_HD bool full(const GameParams&, const Board& b) { return (b.w[0] & 0x1fffffULL) == 0; }
 
-  // contiguous run through (col,row) along (dc=+-1, dr=delta): connect_four.py:206-239
-  static CR_HD bool line(uint64_t s, int col, int row, int player, int delta) {
-    int total = 1;
-    int cur = row - delta;
-    for (int c = col - 1; c >= 0; --c) {
-      if (!is(s, c, cur, player)) break;
-      if (++total == 4) return true;
-      cur -= delta;
+  // column c's cells are the 6 bits [57-6c, 62-6c], row 0 on top: h stones = the top h bits of the group
+  static CR_HD Aux aux_of(const GameParams&, const Board& b) {
+    const uint64_t s = b.w[0];
+    uint64_t occ = 0;
+    for (int c = 0; c < 7; ++c) {
+      const int h = height(s, c);
+      occ |= (uint64_t)((0x3Fu << (6 - h)) & 0x3Fu) << (57 - 6 * c);
     }
-    cur = row + delta;
-    for (int c = col + 1; c < 7; ++c) {
-      if (!is(s, c, cur, player)) break;
-      if (++total == 4) return true;
-      cur += delta;
-    }
-    return false;
+    return Aux{occ};
   }
-
-  // connect_four.py:241-265.  Returns won; the column must not be full.
-  static CR_HD bool move(const GameParams&, Board& b, int col, int player) {
+  // windows of four along bit stride s: bit b is set iff cells b, b-s, b-2s, b-3s are all set
+  static CR_HD uint64_t four(uint64_t x, int s) {
+    const uint64_t y = x & (x << s);
+    return y & (y << (2 * s));
+  }
+  // the window starts whose four cells include the cell `nb`
+  static CR_HD uint64_t span(uint64_t nb, int s) {
+    const uint64_t w = nb | (nb << s);
+    return w | (w << (2 * s));
+  }
+  // bit strides towards the next cell of a line: up 1, right 6, up-right 7, down-right 5.  Horizontal windows
+  // cannot wrap (beyond column 6 lie the counter bits, which x never holds); the others are cut by the start row.
+  static CR_HD uint64_t wins_dir(uint64_t x, uint64_t nb, int dir) {
+    const int s = dir == 0 ? 1 : dir == 1 ? 6 : dir == 2 ? 7 : 5;
+    const uint64_t m = dir == 1 ? ~0ULL : dir == 3 ? ROWS345 : ROWS012;
+    return four(x, s) & m & span(nb, s);
+  }
+  // put `player`'s stone into column `col` (must not be full); returns the stone's bit
+  static CR_HD uint64_t drop(Board& b, Aux& aux, int col, int player) {
     uint64_t s = b.w[0];
     const int h = height(s, col);
-    s |= (uint64_t)player << (62 - (6 * col + h));
+    const uint64_t nb = 1ULL << (62 - (6 * col + h));
+    s |= player ? nb : 0ULL;
     s -= 1ULL << (3 * (6 - col));
     b.w[0] = s;
-    bool won = false;
-    if (h >= 3)
-      won = cell(s, col, h - 1) == player && cell(s, col, h - 2) == player && cell(s, col, h - 3) == player;
-    if (!won) won = line(s, col, h, player, 0) || line(s, col, h, player, 1) || line(s, col, h, player, -1);
-    return won;
+    aux.occ |= nb;
+    return nb;
   }
+  static CR_HD uint64_t stones(const Board& b, const Aux& aux, int player) {
+    return (player ? b.w[0] : ~b.w[0]) & aux.occ;
+  }
+  // connect_four.py:241-265.  Returns won; the column must not be full.
+  static CR_HD bool move(const GameParams&, Board& b, Aux& aux, int col, int player) {
+    const uint64_t nb = drop(b, aux, col, player);
+    const uint64_t x = stones(b, aux, player);
+    return (wins_dir(x, nb, 0) | wins_dir(x, nb, 1) | wins_dir(x, nb, 2) | wins_dir(x, nb, 3)) != 0;
+  }
+  static CR_HD bool move(const GameParams& gp, Board& b, int col, int player) {
+    Aux aux = aux_of(gp, b);
+    return move(gp, b, aux, col, player);
+  }
+#if defined(__HIPCC__)
+  // the same move made by the LPD lanes of one descent (all hold the same board): lane l tests direction l & 3,
+  // one ballot joins the four.  `first` = the group's first lane in the wave.
+  template <int LPD>
+  static CR_D bool move_group(const GameParams&, Board& b, Aux& aux, int col, int player, int l, int first) {
+    const uint64_t nb = drop(b, aux, col, player);
+    const uint64_t hit = wins_dir(stones(b, aux, player), nb, l & 3);
+    return group_bits<LPD>(__ballot(hit != 0), first) != 0;
+  }
+#endif
 
   // value (0/1) of plane `p` at flat index i = row_idx*7 + c: connect_four.py:175-204
   static CR_HD float plane(const GameParams&, const Board& b, int who_move, int p, int i) {
@@ -112,15 +165,9 @@ struct C4Rules {
   }
   // every stone of `root` is also on `node` (a position reachable from root contains it): per column the
   // node is at least as high and agrees on the root's occupied rows
-  static CR_HD bool contains(const GameParams&, const Board& node, const Board& root) {
-    const uint64_t a = node.w[0], r = root.w[0];
-    for (int c = 0; c < 7; ++c) {
-      const int hr = height(r, c);
-      if (height(a, c) < hr) return false;
-      const uint64_t col_mask = ((1ULL << hr) - 1ULL) << (62 - (6 * c + hr - 1));  // rows 0..hr-1 of column c
-      if (hr > 0 && ((a ^ r) & col_mask)) return false;
-    }
-    return true;
+  static CR_HD bool contains(const GameParams& gp, const Board& node, const Board& root) {
+    const uint64_t ro = aux_of(gp, root).occ, no = aux_of(gp, node).occ;
+    return (ro & ~no) == 0 && ((node.w[0] ^ root.w[0]) & ro) == 0;
   }
   static CR_HD uint64_t hash(const Board& b) {
     uint64_t z = b.w[0] * 0x9E3779B97F4A7C15ULL;
@@ -136,66 +183,107 @@ template <int W64>
 struct MnkRules {
   static constexpr int KW = 2 * W64;
   using Board = BoardT<2 * W64>;
+  struct Aux {};  // the two planes are bitboards already
 
   static CR_HD Board initial(const GameParams&) {
     Board b;
     for (int i = 0; i < KW; ++i) b.w[i] = 0;
     return b;
   }
-  static CR_HD bool bit(const Board& b, int plane, int i) {
-    return (b.w[plane * W64 + (i >> 6)] >> (i & 63)) & 1ULL;
+  static CR_HD Aux aux_of(const GameParams&, const Board&) { return Aux{}; }
+  // word `wi` of plane `plane`, by selects over the (few) words: a runtime index into b.w would push the board
+  // out of registers
+  static CR_HD uint64_t word(const Board& b, int plane, int wi) {
+    uint64_t x = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < KW; ++j) x = (plane * W64 + wi == j) ? b.w[j] : x;
+    return x;
   }
+  static CR_HD uint64_t occupied_word(const Board& b, int wi) {
+    uint64_t x = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < W64; ++j) x = (wi == j) ? (b.w[j] | b.w[W64 + j]) : x;
+    return x;
+  }
+  static CR_HD bool bit(const Board& b, int plane, int i) { return (word(b, plane, i >> 6) >> (i & 63)) & 1ULL; }
   static CR_HD bool legal(const GameParams& gp, const Board& b, int a) {  // tictactoe.py:137-150
-    return a < gp.A && !bit(b, 0, a) && !bit(b, 1, a);
+    return a < gp.A && !((occupied_word(b, a >> 6) >> (a & 63)) & 1ULL);
   }
   static CR_HD bool full(const GameParams& gp, const Board& b) {
     int cnt = 0;
     for (int i = 0; i < W64; ++i) cnt += popc64(b.w[i] | b.w[W64 + i]);
     return cnt >= gp.A;
   }
-  // any run >= k of `player` along the whole line (r0 + t*dr, c0 + t*dc), t = 0..len-1:
-  // tictactoe_helpers.py:27-58 (k_in_a_row over the full row / column / diagonal)
-  static CR_HD bool run(const GameParams& gp, const Board& b, int player, int r0, int c0, int dr, int dc,
-                        int len) {
-    int cur = 0;
-    for (int t = 0; t < len; ++t) {
-      const int i = (r0 + t * dr) * gp.n + (c0 + t * dc);
-      cur = bit(b, player, i) ? cur + 1 : 0;
-      if (cur >= gp.k) return true;
-    }
-    return false;
-  }
-  // tictactoe.py:210-235: overwrite the square, then check_win over the four lines through it
-  static CR_HD bool move(const GameParams& gp, Board& b, int mv, int player) {
-    const int n = gp.n;
+  // tictactoe.py:226-233: the square is overwritten with the mover's token (the reference does not check it is empty)
+  static CR_HD void put(Board& b, int mv, int player) {
     const uint64_t m = 1ULL << (mv & 63);
     const int wi = mv >> 6;
-    b.w[wi] &= ~m;
-    b.w[W64 + wi] &= ~m;
-    b.w[player * W64 + wi] |= m;
-    const int row = mv / n, col = mv % n;
-    if (run(gp, b, player, row, 0, 0, 1, n)) return true;  // get_row
-    if (run(gp, b, player, 0, col, 1, 0, n)) return true;  // get_col
-    {                                                      // get_diag, helpers:86-132
-      const int d = row < col ? row : col;
-      const int r0 = row - d, c0 = col - d;
-      const int len = n - (r0 > c0 ? r0 : c0);
-      if (run(gp, b, player, r0, c0, 1, 1, len)) return true;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < W64; ++j) {
+      const uint64_t clr = (wi == j) ? ~m : ~0ULL, set = (wi == j) ? m : 0ULL;
+      b.w[j] = (b.w[j] & clr) | (player == 0 ? set : 0ULL);
+      b.w[W64 + j] = (b.w[W64 + j] & clr) | (player == 1 ? set : 0ULL);
     }
-    {  // get_antidiag, helpers:135-179: from the bottom-left end going up-right
-      int r0, c0;
-      if (row + col < n) {
-        r0 = row + col;
-        c0 = 0;
-      } else {
-        r0 = n - 1;
-        c0 = row + col - (n - 1);
+  }
+  // cell index of element t of line d through (row, col), or -1 when the line has no such element:
+  // d = 0 the row (get_row), 1 the column (get_col), 2 the diagonal (get_diag, helpers:86-132), 3 the
+  // anti-diagonal (get_antidiag, helpers:135-179; a run is a run in either direction of travel)
+  static CR_HD int line_cell(int n, int row, int col, int d, int t) {
+    int r, c;
+    if (d == 0) { r = row; c = t; }
+    else if (d == 1) { r = t; c = col; }
+    else if (d == 2) { const int m = row < col ? row : col; r = row - m + t; c = col - m + t; }
+    else { r = row + col - t; c = t; }
+    return (t < n && r >= 0 && r < n && c < n) ? r * n + c : -1;
+  }
+  // a run of >= k ones in the low n bits of f (k_in_a_row, helpers:27-58)
+  static CR_HD bool has_run(uint64_t f, int k) {
+    for (int i = 1; i < k; ++i) f &= f >> 1;
+    return f != 0;
+  }
+  // tictactoe.py:210-235: overwrite the square, then check_win over the four lines through it
+  static CR_HD bool move(const GameParams& gp, Board& b, Aux&, int mv, int player) {
+    put(b, mv, player);
+    const int n = gp.n, row = mv / n, col = mv % n;
+    for (int d = 0; d < 4; ++d) {
+      uint64_t f = 0;
+      for (int t = 0; t < n; ++t) {
+        const int i = line_cell(n, row, col, d, t);
+        f |= (uint64_t)(i >= 0 && bit(b, player, i)) << t;
       }
-      const int len = (r0 + 1) < (n - c0) ? (r0 + 1) : (n - c0);
-      if (run(gp, b, player, r0, c0, -1, 1, len)) return true;
+      if (has_run(f, gp.k)) return true;
     }
     return false;
   }
+  static CR_HD bool move(const GameParams& gp, Board& b, int mv, int player) {
+    Aux aux;
+    return move(gp, b, aux, mv, player);
+  }
+#if defined(__HIPCC__)
+  // The LPD lanes of one descent (all hold the same board) gather the four lines with one ballot: lane l looks at
+  // element l % NL of line l / NL (NL = LPD / 4 >= n for every geometry: n <= 4 | 16 lanes, 5 | 32, <= 15 | 64),
+  // the group's ballot bits are the four line words side by side, and a run of k is found in all four at once;
+  // `starts` keeps a run from straddling two lines when n == NL.
+  template <int LPD>
+  static CR_D bool move_group(const GameParams& gp, Board& b, Aux&, int mv, int player, int l, int first) {
+    constexpr int NL = LPD / 4;
+    put(b, mv, player);
+    const int n = gp.n, row = mv / n, col = mv % n;
+    const int i = line_cell(n, row, col, l / NL, l % NL);
+    uint64_t f = group_bits<LPD>(__ballot(i >= 0 && bit(b, player, i)), first);
+    for (int j = 1; j < gp.k; ++j) f &= f >> 1;
+    uint64_t starts = (1ull << (NL - gp.k + 1)) - 1ull;  // a run may start at elements 0 .. NL-k of a line
+    starts |= starts << NL;
+    starts |= starts << (2 * NL);
+    return (f & starts) != 0;
+  }
+#endif
   // tictactoe.py:164-176: plane 0 = who_move's tokens, plane 1 = the other token; no row flip
   static CR_HD float plane(const GameParams&, const Board& b, int who_move, int p, int i) {
     return bit(b, p == 0 ? who_move : 1 - who_move, i) ? 1.0f : 0.0f;

@@ -119,19 +119,23 @@ def play_games(game, n_games, replay_buffer, net1, net2=None, steps_before_tau_0
         zs = d["z"].cpu().numpy()[keep].tolist()
         replay_buffer.extend(zip(states, players, pis, zs))
 
-    started = G  # uids uid_base .. uid_base + started - 1 have been handed to a slot
-    while len(outcome) < n_games:
+    # slot g plays uids uid_base + g, + G, + 2G, ... (a drained slot restarts with its next uid when `recycle`)
+    slot_uid = [uid_base + g for g in range(G)]
+    waiting = set(range(uid_base, uid_base + n_games))  # wanted games without a result yet
+    while waiting:
         engine.search(mcts_searches, mcts_batch_size)
         engine.step()
-        recycle = started < n_games  # a drained slot restarts with the next unplayed uid
+        # keep recycling while some wanted game has not been handed to its slot yet; slots that run ahead of the
+        # others may then start a few games beyond the wanted range: they are played but not reported
+        recycle = any(slot_uid[(u - uid_base) % G] < u for u in waiting)
         d = engine.drain(recycle=recycle)
-        ng = int(d["games"].shape[0])
-        if ng:
-            if recycle:
-                started += ng  # may run past n_games by a few slots: those games are played but not reported
+        if int(d["games"].shape[0]):
             for uid, _first, result, steps in d["games"].cpu().numpy().tolist():
-                if uid <= last_uid:
+                if uid in waiting:
+                    waiting.discard(uid)
                     outcome[uid] = (int(result), int(steps))
+                if recycle:
+                    slot_uid[(uid - uid_base) % G] = uid + G
             if replay_buffer is not None:
                 consume(d)
         elif not recycle and engine.live_games() == 0:
