@@ -248,47 +248,56 @@ struct Descent {
 // (_add_noise, float64 scores, mcts.py:131-132); otherwise float32 scores.  Returns false when the descent has
 // ended (state not in the tree = the leaf, a win, or a full board).  Everything a group needs from its other lanes
 // travels by DPP / ballot; the only memory access is the node's row.
-template <class GEO, bool ROOT>
-__device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, int t, const uint64_t* __restrict__ tkeys,
-                                              const uint32_t* __restrict__ tedges, int32_t* __restrict__ pn,
-                                              int32_t* __restrict__ pa, int l, int first, const double* nz) {
-  using R = typename GEO::R;
-  constexpr int LPD = GEO::LPD, APL = GEO::APL, AP = GEO::AP, KW = GEO::KW;
-  // one latency per level: the key and the action rows of the home slot are loaded together
-  const uint32_t slot = home_slot<R>(v, d.cur);
+// What a level reads from memory: the key in the board's home slot and this lane's share of the action rows
+// N | W | Q | P of that slot (W only at the root), all issued together: one latency per level.
+template <class GEO>
+struct NodeRow {
+  uint32_t slot;
+  uint32_t nraw[GEO::APL], wraw[GEO::APL];
+  float q[GEO::APL], p[GEO::APL];
+  uint64_t k[GEO::KW];
+};
+template <class GEO, bool WITH_W>
+__device__ __forceinline__ void load_row(NodeRow<GEO>& r, const uint64_t* __restrict__ tkeys,
+                                         const uint32_t* __restrict__ tedges, uint32_t slot, int l) {
+  constexpr int APL = GEO::APL, AP = GEO::AP, KW = GEO::KW;
   const uint32_t* row = tedges + (size_t)slot * 4 * AP;
-  uint32_t nraw[APL], wraw[APL];
-  float q[APL], p[APL];
+  r.slot = slot;
 #pragma unroll
   for (int j = 0; j < APL; ++j) {
     const int a = l * APL + j;
-    nraw[j] = row[a];
-    if (ROOT) wraw[j] = row[AP + a];
-    q[j] = __uint_as_float(row[2 * AP + a]);
-    p[j] = __uint_as_float(row[3 * AP + a]);
+    r.nraw[j] = row[a];
+    r.wraw[j] = WITH_W ? row[AP + a] : 0u;
+    r.q[j] = __uint_as_float(row[2 * AP + a]);
+    r.p[j] = __uint_as_float(row[3 * AP + a]);
   }
+  const uint64_t* k = tkeys + (size_t)slot * KW;
+#pragma unroll
+  for (int w = 0; w < KW; ++w) r.k[w] = k[w];
+}
+
+template <class GEO, bool ROOT>
+__device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, int t, const uint64_t* __restrict__ tkeys,
+                                              const uint32_t* __restrict__ tedges, int32_t* __restrict__ pn,
+                                              int32_t* __restrict__ pa, int l, int first, const double* nz,
+                                              NodeRow<GEO>& r) {
+  using R = typename GEO::R;
+  constexpr int LPD = GEO::LPD, APL = GEO::APL, KW = GEO::KW;
+  if (!ROOT) load_row<GEO, false>(r, tkeys, tedges, home_slot<R>(v, d.cur), l);  // the root's row is loaded by the caller
+  uint32_t(&nraw)[APL] = r.nraw;
+  uint32_t(&wraw)[APL] = r.wraw;
+  float(&q)[APL] = r.q;
+  float(&p)[APL] = r.p;
   int node;
   {
-    const uint64_t* k = tkeys + (size_t)slot * KW;
-    const uint64_t k0 = k[0];
-    bool eq = k0 == d.cur.w[0];
+    bool eq = r.k[0] == d.cur.w[0];
 #pragma unroll
-    for (int w = 1; w < KW; ++w) eq = eq && (k[w] == d.cur.w[w]);
-    if (eq) node = (int)slot;
-    else if (k0 == EMPTY_KEY) node = -1;
+    for (int w = 1; w < KW; ++w) eq = eq && (r.k[w] == d.cur.w[w]);
+    if (eq) node = (int)r.slot;
+    else if (r.k[0] == EMPTY_KEY) node = -1;
     else {  // collision with another board: walk the probe sequence, then reload the rows
-      node = probe_from<R>(v, t, d.cur, (slot + 1u) & ((uint32_t)v.hcap - 1u));
-      if (node >= 0) {
-        row = tedges + (size_t)node * 4 * AP;
-#pragma unroll
-        for (int j = 0; j < APL; ++j) {
-          const int a = l * APL + j;
-          nraw[j] = row[a];
-          if (ROOT) wraw[j] = row[AP + a];
-          q[j] = __uint_as_float(row[2 * AP + a]);
-          p[j] = __uint_as_float(row[3 * AP + a]);
-        }
-      }
+      node = probe_from<R>(v, t, d.cur, (r.slot + 1u) & ((uint32_t)v.hcap - 1u));
+      if (node >= 0) load_row<GEO, ROOT>(r, tkeys, tedges, (uint32_t)node, l);
     }
   }
   if (node < 0) return false;  // not in the tree: this is the leaf (mcts.py:123)
@@ -402,6 +411,7 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
   __shared__ int s_first[MAXB];
   __shared__ int s_depth[MAXB];
   __shared__ int s_player[MAXB];
+  __shared__ float s_value[MAXB];
 
   if (v.done[g]) {
     if (tid == 0) {
@@ -429,7 +439,10 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
   const uint64_t* tkeys = v.node_key + tb * KW;
   const uint32_t* tedges = v.edges + tb * 4 * AP;
 
-  // the descent's Dirichlet row (only used if the root is in the tree; generated while the root's row is on its way)
+  // the root's row is requested first; the descent's Dirichlet row (only used if the root is in the tree) is
+  // generated while it is on its way
+  NodeRow<GEO> r;
+  load_row<GEO, true>(r, tkeys, tedges, home_slot<R>(v, d.cur), l);
   double nz[APL];
   if (noise) {
 #pragma unroll
@@ -443,84 +456,89 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
   }
   if (v.dbg) st_noise = __builtin_amdgcn_s_memtime();
 
-  bool live = descend_level<GEO, true>(v, d, t, tkeys, tedges, pn, pa, l, first, nz);
+  bool live = descend_level<GEO, true>(v, d, t, tkeys, tedges, pn, pa, l, first, nz, r);
   if (v.dbg) st_root = __builtin_amdgcn_s_memtime();
   while (__any(live)) {
-    if (live) live = descend_level<GEO, false>(v, d, t, tkeys, tedges, pn, pa, l, first, nullptr);
+    if (live) live = descend_level<GEO, false>(v, d, t, tkeys, tedges, pn, pa, l, first, nullptr, r);
   }
   if (v.dbg) st_loop = __builtin_amdgcn_s_memtime();
 
-  const Board cur = d.cur;
-  const int status = d.status, depth = d.depth, player = d.player;
-  const float value = d.value;
   if (l == 0) {
 #pragma unroll
-    for (int w = 0; w < KW; ++w) s_key[b][w] = cur.w[w];
-    s_status[b] = status;
-    s_depth[b] = depth;
-    s_player[b] = player;
+    for (int w = 0; w < KW; ++w) s_key[b][w] = d.cur.w[w];
+    s_status[b] = d.status;
+    s_depth[b] = d.depth;
+    s_player[b] = d.player;
+    s_value[b] = d.value;
   }
   __syncthreads();
-  // planned-set de-duplication (mcts.py:272-278): first occurrence of a new leaf is kept
-  if (l == 0) {
-    int first_seen = 0;
-    if (status == ST_LEAF) {
-      first_seen = 1;
-      for (int bb = 0; bb < b; ++bb) {
-        if (s_status[bb] != ST_LEAF) continue;
-        bool eq = true;
+  // From here on thread bb < B (all in the first wavefront) speaks for descent bb: planned-set de-duplication
+  // (mcts.py:272-278: the first occurrence of a new leaf is kept), ranks and tallies by ballot.
+  if (tid < 64) {
+    const int bb = tid;
+    const bool mine = bb < B;
+    const int st = mine ? s_status[bb] : ST_DROPPED;
+    const int dep = mine ? s_depth[bb] : 0;
+    Board key;
 #pragma unroll
-        for (int w = 0; w < KW; ++w) eq = eq && (s_key[bb][w] == cur.w[w]);
-        if (eq) first_seen = 0;
+    for (int w = 0; w < KW; ++w) key.w[w] = mine ? s_key[bb][w] : 0ull;
+    bool dup = false;
+    for (int o = 0; o < B; ++o) {  // the same LDS words for every lane: broadcast reads
+      bool eq = o < bb && s_status[o] == ST_LEAF;
+#pragma unroll
+      for (int w = 0; w < KW; ++w) eq = eq && (s_key[o][w] == key.w[w]);
+      dup = dup || eq;
+    }
+    const bool first_seen = st == ST_LEAF && !dup;
+    const unsigned long long m_first = __ballot(first_seen);
+    const unsigned long long m_term = __ballot(st == ST_TERMINAL);
+    const unsigned long long m_drop = __ballot(st == ST_LEAF && dup);
+    int levels, maxdep = 0;
+    if (blockDim.x >= 64) {  // a whole wavefront: cross-lane reduction
+      levels = group_sum_i32<64>(dep);
+      if (v.dbg) maxdep = group_allreduce_i32<64>(dep, [](int x, int y) { return x > y ? x : y; });
+    } else {                 // a partial wavefront (batch x lanes < 64): lanes that do not exist cannot be read
+      levels = 0;
+      for (int o = 0; o < B; ++o) {
+        levels += s_depth[o];
+        maxdep = s_depth[o] > maxdep ? s_depth[o] : maxdep;
       }
     }
-    s_first[b] = first_seen;
-  }
-  __syncthreads();
-  if (l == 0) {
-    int local = 0;
-    for (int bb = 0; bb < b; ++bb) local += s_first[bb];
-    const size_t di = (size_t)g * v.maxB + b;
-    int st = status;
-    if (status == ST_LEAF && !s_first[b]) st = ST_DROPPED;
-    v.d_status[di] = st;
-    v.d_value[di] = value;
-    v.d_local[di] = local;
-    v.d_player[di] = player;
-    v.path_len[di] = depth;
-    store_board<R>(v.d_key + di * KW, cur);
-  }
-  if (tid == 0) {
-    int nleaf = 0, levels = 0, term = 0, drop = 0;
-    for (int bb = 0; bb < B; ++bb) {
-      nleaf += s_first[bb];
-      levels += s_depth[bb];
-      term += s_status[bb] == ST_TERMINAL;
-      drop += (s_status[bb] == ST_LEAF && !s_first[bb]);
+    if (mine) {
+      const size_t di = (size_t)g * v.maxB + bb;
+      v.d_status[di] = (st == ST_LEAF && dup) ? ST_DROPPED : st;
+      v.d_value[di] = s_value[bb];
+      v.d_local[di] = __popcll(m_first & ((1ull << bb) - 1ull));
+      v.d_player[di] = s_player[bb];
+      v.path_len[di] = dep;
+      store_board<R>(v.d_key + di * KW, key);
+      s_first[bb] = first_seen;
     }
-    v.g_nleaf[g] = nleaf;
-    v.g_tree[g] = t;
-    v.g_class[g] = v.n_nets == 2 ? player0 : 0;
-    if (v.dbg) {  // cycles since kernel start: noise generated | root level done | descents done | end; max depth
-      unsigned long long* dd = v.dbg + (size_t)g * 8;
-      int maxd = 0;
-      for (int bb = 0; bb < B; ++bb) maxd = s_depth[bb] > maxd ? s_depth[bb] : maxd;
-      dd[0] = st_noise - st0; dd[1] = st_root - st0; dd[2] = st_loop - st0;
-      dd[3] = __builtin_amdgcn_s_memtime() - st0; dd[4] = (unsigned long long)maxd;
-    }
-    // this block is the only writer of game g's tallies; adds without a return value do not wait for memory
-    unsigned long long* ctr = v.counters + (size_t)g * C_N;
-    atomicAdd(ctr + C_SIMS, (unsigned long long)B);
-    atomicAdd(ctr + C_LEVELS, (unsigned long long)levels);
-    atomicAdd(ctr + C_TERMINALS, (unsigned long long)term);
-    atomicAdd(ctr + C_DROPPED, (unsigned long long)drop);
-    if (rows) {
-      const int cls = v.n_nets == 2 ? player0 : 0;
-      if (nleaf) atomicAdd(rows + cls, nleaf);
-      v.g_off[g] = g * B;
-      v.g_pack[g] = nleaf | (cls << 8);
+    if (tid == 0) {
+      const int nleaf = __popcll(m_first);
+      v.g_nleaf[g] = nleaf;
+      v.g_tree[g] = t;
+      v.g_class[g] = v.n_nets == 2 ? player0 : 0;
+      if (v.dbg) {  // cycles since kernel start: noise generated | root level done | descents done | end; max depth
+        unsigned long long* dd = v.dbg + (size_t)g * 8;
+        dd[0] = st_noise - st0; dd[1] = st_root - st0; dd[2] = st_loop - st0;
+        dd[3] = __builtin_amdgcn_s_memtime() - st0; dd[4] = (unsigned long long)maxdep;
+      }
+      // this block is the only writer of game g's tallies; adds without a return value do not wait for memory
+      unsigned long long* ctr = v.counters + (size_t)g * C_N;
+      atomicAdd(ctr + C_SIMS, (unsigned long long)B);
+      atomicAdd(ctr + C_LEVELS, (unsigned long long)levels);
+      atomicAdd(ctr + C_TERMINALS, (unsigned long long)__popcll(m_term));
+      atomicAdd(ctr + C_DROPPED, (unsigned long long)__popcll(m_drop));
+      if (rows) {
+        const int cls = v.n_nets == 2 ? player0 : 0;
+        if (nleaf) atomicAdd(rows + cls, nleaf);
+        v.g_off[g] = g * B;
+        v.g_pack[g] = nleaf | (cls << 8);
+      }
     }
   }
+  if (rows) __syncthreads();  // s_first for the plane writers
   if (rows) {
     const int HW = v.HW;
     int local = 0;
