@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 runs of tools/profile_r02.sh (gpurun_out/prof_r02/) into profiles/.
+
+    python tools/prof_summary.py gpurun_out/prof_r02 r02_a
+
+bench.py plays a 16-game copy of its configuration before the clock starts (first-use costs); its small launches
+are in the traces too.  Only the launches of the full-size engine are summarised: per kernel, the dispatches with
+the largest grid.  Outputs:
+  profiles/<tag>_kernel_stats.csv   per-kernel calls / avg / min / max / share, from the kernel trace (--stats run)
+  profiles/pmc_r02.json             HBM bytes per launch (FETCH_SIZE x2 on the read side, the gfx950 correction of
+                                    MI355X_MICROARCH.md; WRITE_SIZE as is; KiB units) and the MFMA-busy fraction
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+SHORT = ["k_tree", "k_net_forward_w", "k_net_forward_3x", "k_net_forward", "k_select", "k_expand_backup", "k_encode",
+         "k_step", "k_drain_copy", "k_drain_scan", "k_evict", "k_net_hash"]
+
+
+def short(name):
+    for k in SHORT:
+        if k in name:
+            return k
+    return None
+
+
+def rows(dirname, pattern):
+    for f in glob.glob(os.path.join(dirname, "**", pattern), recursive=True):
+        yield from csv.DictReader(open(f))
+
+
+def full_size(recs, grid_key):
+    """keep, per kernel, the dispatches with that kernel's largest grid"""
+    big = defaultdict(int)
+    for r in recs:
+        big[r["k"]] = max(big[r["k"]], int(r[grid_key]))
+    return [r for r in recs if int(r[grid_key]) == big[r["k"]]]
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    root = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    # ---- kernel trace of the --stats run
+    recs = []
+    for r in rows(os.path.join(src, "stats"), "*kernel_trace.csv"):
+        k = short(r["Kernel_Name"])
+        if k:
+            recs.append({"k": k, "g": r["Grid_Size_X"], "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+                         "t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"])})
+    recs = full_size(recs, "g")
+    per = defaultdict(list)
+    for r in recs:
+        per[r["k"]].append(r["ns"])
+    total = sum(sum(v) for v in per.values())
+    span = (max(r["t1"] for r in recs) - min(r["t0"] for r in recs)) if recs else 0
+    out = os.path.join(root, "profiles", tag + "_kernel_stats.csv")
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "
+                "--no-extra-configs --no-profile; launches of the full-size engine only (largest grid per kernel); "
+                "busy = sum of kernel time / span first..last launch = %.3f\n" % (total / span if span else 0))
+        f.write("kernel,calls,total_us,avg_us,min_us,max_us,share\n")
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            f.write("%s,%d,%.1f,%.2f,%.2f,%.2f,%.4f\n" % (k, len(v), sum(v) / 1e3, sum(v) / len(v) / 1e3, min(v) / 1e3,
+                                                          max(v) / 1e3, sum(v) / total))
+    print(open(out).read())
+    # ---- counters
+    def counters(sub, names):
+        acc = []
+        for r in rows(os.path.join(src, sub), "*counter_collection.csv"):
+            k = short(r["Kernel_Name"])
+            if k and r["Counter_Name"] in names:
+                acc.append({"k": k, "g": r["Grid_Size"], "c": r["Counter_Name"], "v": float(r["Counter_Value"]),
+                            "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+        return full_size(acc, "g")
+
+    fe, wr = counters("pmc_fetch", {"FETCH_SIZE"}), counters("pmc_write", {"WRITE_SIZE"})
+    kernels = {}
+    for k in sorted({r["k"] for r in fe} | {r["k"] for r in wr}):
+        f = [r["v"] for r in fe if r["k"] == k]
+        w = [r["v"] for r in wr if r["k"] == k]
+        fa, wa = sum(f) / max(1, len(f)), sum(w) / max(1, len(w))
+        kernels[k] = {"launches_fetch_pass": len(f), "launches_write_pass": len(w), "FETCH_SIZE_KiB_per_launch": fa,
+                      "WRITE_SIZE_KiB_per_launch": wa, "hbm_bytes_per_launch_raw": (fa + wa) * 1024.0,
+                      "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
+    mf = counters("pmc_mfma", {"SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"})
+    mfma = {}
+    for k in sorted({r["k"] for r in mf}):
+        get = lambda c: [r["v"] for r in mf if r["k"] == k and r["c"] == c]
+        busy, gui = get("SQ_VALU_MFMA_BUSY_CYCLES"), get("GRBM_GUI_ACTIVE")
+        dur = [r["ns"] for r in mf if r["k"] == k and r["c"] == "GRBM_GUI_ACTIVE"]
+        if not busy or not gui:
+            continue
+        b, g = sum(busy) / len(busy), sum(gui) / len(gui)
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: kernel cycles = g / 8; 1024 SIMDs each with one MFMA pipe
+        mfma[k] = {"launches": len(busy), "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": b,
+                   "GRBM_GUI_ACTIVE_per_launch_sum_of_8_XCDs": g,
+                   "avg_duration_us_under_the_profiler": sum(dur) / len(dur) / 1e3,
+                   "mfma_busy_fraction": b / (g / 8.0 * 1024.0)}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES "
+                         "GRBM_GUI_ACTIVE (separate passes, each with --kernel-trace only) -- python3 bench.py --steps 3 "
+                         "--warmup 2 --no-cpu-baseline --no-extra-configs --no-profile; launches of the full-size engine",
+               "correction": "read side x2 (gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads); KiB units",
+               "kernels": kernels, "mfma_utilisation": mfma,
+               "mfma_note": "busy cycles of the MFMA pipe summed over the 1024 SIMDs / (kernel cycles x 1024)"},
+              open(os.path.join(root, "profiles", "pmc_r02.json"), "w"), indent=1)
+    for k, v in kernels.items():
+        print("%-18s fetch %10.1f KiB  write %10.1f KiB  -> %12.0f B/launch  (%d launches)" %
+              (k, v["FETCH_SIZE_KiB_per_launch"], v["WRITE_SIZE_KiB_per_launch"], v["hbm_bytes_per_launch"],
+               v["launches_fetch_pass"]))
+    for k, v in mfma.items():
+        print("%-18s MFMA busy %.3f (%.1f us under the profiler)" % (k, v["mfma_busy_fraction"],
+                                                                     v["avg_duration_us_under_the_profiler"]))
+
+
+if __name__ == "__main__":
+    main()
