@@ -496,10 +496,15 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     for (int d = 0; d < 3; ++d) {
       const int nx = tx + d - 1;
       const bool okx = nx >= 0 && nx < p.W;
-      const int rowa = oka && okx ? tbi * HW + ya * p.W + nx : ZROW;
-      const int rowb = okb && okx ? tbi * HW + yb * p.W + nx : ZROW;
-      oa[d] = rowa * NF + (((h * 8 + kq) ^ (rowa & 15)) << 2);
-      ob[d] = rowb * NF + (((h * 8 + kq) ^ (rowb & 15)) << 2);
+      // A cell outside the board reads the zero row.  All 16 granules of that row are zero, so the lane may take
+      // ANY of them: it takes the one its own (virtual) row would have used, which keeps the 16 lanes of a
+      // ds_read_b128 group on 16 different banks (they all have different row residues by construction of the tile
+      // table; sending every outside cell to one fixed granule made it collide with the lane owning that residue).
+      const int va = tbi * HW + ya * p.W + nx, vb = tbi * HW + yb * p.W + nx;
+      const int rowa = oka && okx ? va : ZROW;
+      const int rowb = okb && okx ? vb : ZROW;
+      oa[d] = rowa * NF + (((h * 8 + kq) ^ (va & 15)) << 2);
+      ob[d] = rowb * NF + (((h * 8 + kq) ^ (vb & 15)) << 2);
     }
   };
   const float* wlane = wbuf + (h * 64 + ct * 32 + i) * 32;
