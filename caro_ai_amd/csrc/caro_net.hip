@@ -68,7 +68,7 @@ struct NetParams {
   const float* w_p;     // [A][2*HW]
   const float* b_p;     // [A]
   const uint4* w3;      // 3xbf16 mode: [45 taps][1536 granules] LDS image of the split residual weights, or null
-  const float* ww;      // f32w mode: [5][4 p][3 dx][4096] transformed residual weights (LDS image order), or null
+  const float* ww;      // f32w mode: [5][3 dx][2 granule halves] chunks of [4 p][2 h][64 co][16] transformed residual weights (LDS image order of trunk_w), or null
   const uint32_t* wtab; // f32w mode: [128] tile of MFMA row (row tile, lane): board | ty << 8 | x << 16 | valid << 24
   int ncu, TB2, TB4;    // f32w mode: compute units; boards per workgroup of the 2- / 4-way K-split overflow tiles (0: off)
 };
@@ -437,10 +437,42 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
 // of 128 rows), K = 4 transformed taps p x 3 dx x 64 channels, U[p][dx] = sum_ky G[p][ky] w[ky][dx] is
 // packed by the host (float64 sum, one rounding).  The transformed input d_a +- d_b is formed in registers
 // from two LDS reads when the A operand is loaded, so nothing but the activations themselves lives in LDS.
-// Wave w owns row tile w>>1 x col tile w&1 (32 tiles x 32 channels): accumulator M for the running p, and
-// Y0/Y1 for the two output rows, 48 accumulator registers.  Weight chunk = the 3 dx taps of one p.
-constexpr int WTAPS = NRES * 12;          // 60
-constexpr int WNCHUNK = WTAPS / TPC;      // 20
+// Wave w owns row tile w>>1 x col tile w&1 (32 tiles x 32 channels) and keeps FOUR accumulators, one per
+// transformed tap p.  The stream is ordered so that all four p of one (dx, channel granule) are processed
+// together: the four input rows d0..d3 of a tile are read once (4 ds_read_b128) and give V0 = d0-d2, V1 = d1+d2,
+// V2 = d2-d1, V3 = d1-d3; with the four weight granules (4 ds_read_b128) that is 16 MFMAs for 8 LDS reads.
+// Measured (tools/micro/mfma_shadow.hip, mfma_pfused.hip): on this stream a wave-wide ds_read_b128 costs the SIMD
+// ~13 cycles of matrix-pipe time on top of the 64 of an MFMA, whatever the prefetch distance, barriers or
+// priorities; one p at a time (2 rows + 1 weight granule per 4 MFMAs, 0.75 reads per MFMA) ran at 76 cycles
+// per MFMA, this order (0.5 reads per MFMA) at 68-70.  The sequence of MFMAs into each accumulator -- dx, then
+// channel granule, then k -- and the output transform are those of the one-p-at-a-time form, so the results
+// are bit-identical to it.
+// Weight chunk = one dx, four channel granules of each lane half, all four p: [p][h][co][16 floats] = 32 KiB,
+// 6 chunks per layer, a ring of three LDS buffers.
+constexpr int WTAPS = NRES * 12;          // 60 transformed taps of 4096 floats
+constexpr int WCH = 4 * 2 * 64 * 16;      // floats per chunk (8192)
+constexpr int WNCHUNK = NRES * 6;         // 30
+constexpr int WNBUF = 3;
+static_assert(WNBUF * WCH == 2 * TPC * WCHUNK, "the ring takes the place of the two three-tap buffers");
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned lds_addr(const void* q) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)q;
+}
+// 16 bytes per lane global -> LDS, not tracked by the compiler (it would wait for vmcnt(0) in front of every later
+// ds_read): lane l of the wave writes lds_wave_base + 16 l.  The issuer waits (vmcnt(0)) before the barrier that
+// publishes the data.
+__device__ __forceinline__ void dma_b128(const void* gsrc, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_wave_base), "v"(gsrc) : "memory");
+}
+// chunk c of the transformed weights -> ring buffer c % WNBUF (every thread moves 4 x 16 bytes)
+__device__ __forceinline__ void fetch_chunk(const float* ww, int c, unsigned wring, int tid) {
+  const float4* src = reinterpret_cast<const float4*>(ww + (size_t)c * WCH) + tid;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(wring + (unsigned)(c % WNBUF) * (WCH * 4) + (unsigned)(tid >> 6) * 1024u);
+#pragma unroll
+  for (int m = 0; m < WCH / 4 / NT; ++m) dma_b128(src + m * NT, dst + m * NT * 16);
+}
 
 template <int KS>
 __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* wbuf, int nb, int tid) {
@@ -448,13 +480,13 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
   const int HW = p.HW;
   const int wave = tid >> 6, lane = tid & 63;
   const int i = lane & 31, h = lane >> 5;
-  // KS = 1: wave = row tile (wave >> 1) x col tile (wave & 1), all of K.  KS = 2 / 4 (workgroups of the second
-  // round of a launch that overflows one round, see k_net_forward_w): 4 / KS row tiles, and KS waves share one
-  // (row tile, col tile), wave kq taking the channel granules Q with Q % KS == kq; their partial sums meet in LDS
-  // before the in-place epilogue.
+  // KS = 1: wave = row tile (wave >> 1) x col tile (wave & 1), all of K.  KS = 2 / 4 (small launches and the
+  // second round of a launch that overflows one round, see k_net_forward_w): 4 / KS row tiles, and KS waves share
+  // one (row tile, col tile), wave kq taking the channel granules G with G % KS == kq; their partial sums meet in
+  // LDS before the in-place epilogue.
   constexpr int NRT = 4 / KS;        // row tiles
-  constexpr int SPT = 8 / KS;        // operand sets per tap and wave
-  constexpr int NS = 3 * SPT;        // operand sets per chunk and wave
+  constexpr int NQ = 4 / KS;         // operand sets per chunk and wave
+  constexpr int NSET = 6 * NQ;       // operand sets per layer and wave
   const int ct = wave & 1, rt = (wave >> 1) % NRT, kq = (wave >> 1) / NRT;
   // this lane's tile.  KS = 1: which tile sits on which MFMA row is a host-built table: a ds_read_b128 is served
   // in 16-lane groups, a group is conflict-free when its 16 activation rows differ mod 16 (the swizzle key), and
@@ -473,140 +505,141 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     tty = rem / p.W; tx = rem - tty * p.W;
     tvalid = mt < nb * tpb;
   }
-  const int bswz = ((i >> 1) & 7) ^ kq;  // kq folded into the weight granule index (its low log2(KS) bits are free)
   // output side: with the WEIGHTS as first MFMA operand a lane's 16 accumulator registers are 4 groups of 4
   // consecutive channels (ct*32 + 8q + 4h + 0..3) of ITS tile, so the epilogue moves float4s
   const int orow0 = tbi * HW + 2 * tty * p.W + tx;  // activation row of output row 2ty
   const bool ovalid0 = tvalid, ovalid1 = tvalid && 2 * tty + 1 < p.H;
-  f32x16 accM, accY0, accY1;
+  // LDS byte address of (input row r of the tile = board row 2ty-1+r, column tx+dx-1, granule 8h + kq) with the
+  // row's swizzle key folded in; the granule G of a set is XORed in afterwards ((8h + G) ^ key == ((8h) ^ key) ^ G).
+  // A cell outside the board reads the zero row.  All 16 granules of that row are zero, so the lane may take ANY
+  // of them: it takes the one its own (virtual) row would have used, which keeps the 16 lanes of a ds_read_b128
+  // group on 16 different banks (they all have different row residues by construction of the tile table).
+  const unsigned abase = lds_addr(act);
+  unsigned ra[4][3];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    accM[e] = 0.f;
-    accY0[e] = 0.f;
-    accY1[e] = 0.f;
-  }
-  // float offset of (row, granule 8h) with the row's swizzle key folded in, for the three dx taps of transformed tap
-  // pp; the granule index Q of a set is XORed in afterwards ((8h + Q) ^ key == ((8h) ^ key) ^ Q)
-  auto tap_offsets = [&](int pp, int* oa, int* ob) {
-    const int ja = pp == 0 ? 0 : (pp == 2 ? 2 : 1);
-    const int jb = pp == 0 ? 2 : (pp == 1 ? 2 : (pp == 2 ? 1 : 3));
-    const int ya = 2 * tty - 1 + ja, yb = 2 * tty - 1 + jb;
-    const bool oka = tvalid && ya >= 0 && ya < p.H, okb = tvalid && yb >= 0 && yb < p.H;
+  for (int r = 0; r < 4; ++r) {
+    const int y = 2 * tty - 1 + r;
+    const bool oky = tvalid && y >= 0 && y < p.H;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const int nx = tx + d - 1;
-      const bool okx = nx >= 0 && nx < p.W;
-      // A cell outside the board reads the zero row.  All 16 granules of that row are zero, so the lane may take
-      // ANY of them: it takes the one its own (virtual) row would have used, which keeps the 16 lanes of a
-      // ds_read_b128 group on 16 different banks (they all have different row residues by construction of the tile
-      // table; sending every outside cell to one fixed granule made it collide with the lane owning that residue).
-      const int va = tbi * HW + ya * p.W + nx, vb = tbi * HW + yb * p.W + nx;
-      const int rowa = oka && okx ? va : ZROW;
-      const int rowb = okb && okx ? vb : ZROW;
-      oa[d] = rowa * NF + (((h * 8 + kq) ^ (va & 15)) << 2);
-      ob[d] = rowb * NF + (((h * 8 + kq) ^ (vb & 15)) << 2);
+      const int v = tbi * HW + y * p.W + nx;
+      const int row = oky && nx >= 0 && nx < p.W ? v : ZROW;
+      ra[r][d] = abase + (unsigned)(row * NF + (((h * 8 + kq) ^ (v & 15)) << 2)) * 4u;
     }
-  };
-  const float* wlane = wbuf + (h * 64 + ct * 32 + i) * 32;
-  int offa[3], offb[3];
-  tap_offsets(0, offa, offb);
-  float4 xa, xs, xb, ya_, ys, yb_;
-  // The MFMA stream of a layer is ONE software pipeline over its 96 operand sets (4 p x 3 dx x 8 granules): the
-  // reads of set s+1 are issued before the four MFMAs of set s, across chunk boundaries too.  The two workgroup
-  // barriers a weight chunk needs sit inside the stream, where only the skew between waves is paid:
-  //   after tap 0: every wave has left the previous chunk -> its buffer is free -> write the staged next chunk
-  //   after tap 1: the next chunk is visible              -> its first operands can be prefetched during tap 2
-  for (int c = 0; c < WNCHUNK; ++c) {  // chunk = the three dx taps of one transformed tap p
-    const int cur = c & 1;
-    const int layer = c >> 2, pp = c & 3;
-    const bool has_next = c + 1 < WNCHUNK;
-    const float sg = pp == 1 ? 1.f : -1.f;
-    const float* wbase = wlane + cur * TPC * WCHUNK;
-    const float* wnext = wlane + (cur ^ 1) * TPC * WCHUNK;
-    int noffa[3], noffb[3];
-// operand set S of this wave: tap S / SPT, channel granule (S % SPT) * KS (+ kq, folded into the offsets)
-#define CARO_LOADW(A_, S_, B_, S)                                                                          \
-  A_ = *reinterpret_cast<const float4*>(act + (offa[(S) / SPT] ^ ((((S) % SPT) * KS) << 2)));               \
-  S_ = *reinterpret_cast<const float4*>(act + (offb[(S) / SPT] ^ ((((S) % SPT) * KS) << 2)));               \
-  B_ = *reinterpret_cast<const float4*>(wbase + ((S) / SPT) * WCHUNK + (((((S) % SPT) * KS) ^ bswz) << 2));
-// the four transformed operands first, then the four MFMAs back to back: interleaving v_fma / v_mfma pairs costs
-// ~6 % of the trunk (each MFMA then waits on the VALU result just ahead of it)
-#define CARO_MFMAW(A_, S_, B_)                                                                        \
-  {                                                                                                  \
-    const float v0 = fmaf(sg, S_.x, A_.x), v1 = fmaf(sg, S_.y, A_.y), v2 = fmaf(sg, S_.z, A_.z),     \
-                v3 = fmaf(sg, S_.w, A_.w);                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    accM = __builtin_amdgcn_mfma_f32_32x32x2f32(B_.x, v0, accM, 0, 0, 0);                            \
-    accM = __builtin_amdgcn_mfma_f32_32x32x2f32(B_.y, v1, accM, 0, 0, 0);                            \
-    accM = __builtin_amdgcn_mfma_f32_32x32x2f32(B_.z, v2, accM, 0, 0, 0);                            \
-    accM = __builtin_amdgcn_mfma_f32_32x32x2f32(B_.w, v3, accM, 0, 0, 0);                            \
   }
-    if (pp == 0) {  // first chunk of a layer: nothing was prefetched across the in-place epilogue
-      CARO_LOADW(xa, xs, xb, 0)
-    }
-#pragma unroll
-    for (int s_ = 0; s_ < NS; s_ += 2) {
-      CARO_LOADW(ya_, ys, yb_, s_ + 1)
-      __builtin_amdgcn_sched_barrier(0);
-      CARO_MFMAW(xa, xs, xb)
-      __builtin_amdgcn_sched_barrier(0);
-      if (s_ + 2 < NS) {
-        CARO_LOADW(xa, xs, xb, s_ + 2)
-      } else if (pp != 3) {  // set 0 of the next chunk (same layer: the activations do not change)
-        xa = *reinterpret_cast<const float4*>(act + noffa[0]);
-        xs = *reinterpret_cast<const float4*>(act + noffb[0]);
-        xb = *reinterpret_cast<const float4*>(wnext + (bswz << 2));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      CARO_MFMAW(ya_, ys, yb_)
-      __builtin_amdgcn_sched_barrier(0);
-      if (s_ == SPT - 2) {
-        __syncthreads();  // every wave has left chunk c-1: the other buffer is free
-        if (has_next) {
-          // next chunk: global -> LDS directly (no staging registers); each wave instruction moves 1 KiB, the LDS
-          // image is the packed order.  The barrier after tap 1 waits for them (vmcnt(0)) and publishes them.
-          const float4* src = reinterpret_cast<const float4*>(p.ww + (size_t)(c + 1) * TPC * WCHUNK) + tid;
-          float* dstw = wbuf + (cur ^ 1) * TPC * WCHUNK + wave * 256;
-#pragma unroll
-          for (int m = 0; m < 2 * TPC; ++m)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(src + m * NT),
-                (__attribute__((address_space(3))) void*)(dstw + m * NT * 4), 16, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (s_ == 2 * SPT - 2) {
-        __syncthreads();  // chunk c+1 is visible to every wave
-        tap_offsets((pp + 1) & 3, noffa, noffb);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#undef CARO_LOADW
-#undef CARO_MFMAW
-    // output transform: Y0 += {1,1,1,0}[p] * M,  Y1 += {0,1,-1,-1}[p] * M
-    const float c0 = pp == 3 ? 0.f : 1.f;
-    const float c1 = pp == 0 ? 0.f : (pp == 1 ? 1.f : -1.f);
+  // this lane's weight row in ring buffer 0: [p = 0][h][co = ct*32 + i], granule swizzle (co >> 2) & 3 = (i >> 2) & 3
+  // (the 16 lanes of a ds_read_b128 group hold every residue of i mod 4 four times, with four different (i >> 2) & 3)
+  const unsigned wlane = lds_addr(wbuf) + (unsigned)((h * 64 + ct * 32 + i) * 16 + ((kq ^ ((i >> 2) & 3)) << 2)) * 4u;
+  const unsigned wring = lds_addr(wbuf);
+
+  f4v D0, D1, D2, D3, W0, W1, W2, W3;  // operand set A
+  f4v E0, E1, E2, E3, X0, X1, X2, X3;  // operand set B
+// operand set T of the layer: chunk T / NQ (dx = chunk >> 1, granule half = chunk & 1), granule (T % NQ) * KS of the half
+#define CARO_ALOAD(A0, A1, A2, A3, B0, B1, B2, B3, T)                                                        \
+  {                                                                                                          \
+    constexpr int cc_ = (T) / NQ, dx_ = cc_ >> 1, g8_ = (cc_ & 1) * 4 + ((T) % NQ) * KS;                     \
+    const unsigned wa_ = (wlane + (unsigned)(cc_ % WNBUF) * (WCH * 4)) ^ ((unsigned)(((T) % NQ) * KS) << 4); \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A0) : "v"(ra[0][dx_] ^ (g8_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A1) : "v"(ra[1][dx_] ^ (g8_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A2) : "v"(ra[2][dx_] ^ (g8_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(A3) : "v"(ra[3][dx_] ^ (g8_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(B0) : "v"(wa_));                                               \
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(B1) : "v"(wa_));                                   \
+    asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(B2) : "v"(wa_));                                  \
+    asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(B3) : "v"(wa_));                                  \
+  }
+// the reads of a set are complete when at most N later LDS operations are outstanding (LDS returns in order)
+#define CARO_AWAIT(N, A0, A1, A2, A3, B0, B1, B2, B3)                                                        \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                   \
+               : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3));
+// the four transformed operands, then 16 MFMAs on four independent accumulators
+#define CARO_BURST(A0, A1, A2, A3, B0, B1, B2, B3)                                                           \
+  {                                                                                                          \
+    const f4v v0 = A0 - A2, v1 = A1 + A2, v2 = A2 - A1, v3 = A1 - A3;                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.x, v0.x, accM0, 0, 0, 0);                                \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.x, v1.x, accM1, 0, 0, 0);                                \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.x, v2.x, accM2, 0, 0, 0);                                \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.x, v3.x, accM3, 0, 0, 0);                                \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.y, v0.y, accM0, 0, 0, 0);                                \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.y, v1.y, accM1, 0, 0, 0);                                \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.y, v2.y, accM2, 0, 0, 0);                                \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.y, v3.y, accM3, 0, 0, 0);                                \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.z, v0.z, accM0, 0, 0, 0);                                \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.z, v1.z, accM1, 0, 0, 0);                                \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.z, v2.z, accM2, 0, 0, 0);                                \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.z, v3.z, accM3, 0, 0, 0);                                \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.w, v0.w, accM0, 0, 0, 0);                                \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.w, v1.w, accM1, 0, 0, 0);                                \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.w, v2.w, accM2, 0, 0, 0);                                \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.w, v3.w, accM3, 0, 0, 0);                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  }
+// One step of the layer's software pipeline: set T is in (A.., B..), set T+1 goes into (NA.., NB..) ahead of the
+// MFMAs of set T.  At the first set of a chunk (T % NQ == 0) sits the ONE workgroup barrier of the chunk:
+//   every read this wave has issued is complete (lgkmcnt(0)), its share of chunk c+1 has arrived (vmcnt(0), issued a
+//   whole chunk ago) -> barrier -> chunk c+1 is visible to every wave and no wave reads chunk c-1 any more -> chunk
+//   c+2 is fetched into that buffer.
+#define CARO_STEP(T, A0, A1, A2, A3, B0, B1, B2, B3, NA0, NA1, NA2, NA3, NB0, NB1, NB2, NB3)                 \
+  if ((T) % NQ == 0) {                                                                                       \
+    CARO_AWAIT(0, A0, A1, A2, A3, B0, B1, B2, B3)                                                            \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+    __syncthreads();                                                                                         \
+    if (c0 + (T) / NQ + 2 < WNCHUNK) fetch_chunk(p.ww, c0 + (T) / NQ + 2, wring, tid);                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if ((T) + 1 < NSET) CARO_ALOAD(NA0, NA1, NA2, NA3, NB0, NB1, NB2, NB3, ((T) + 1) % NSET)                 \
+  } else if ((T) + 1 < NSET) {                                                                               \
+    CARO_ALOAD(NA0, NA1, NA2, NA3, NB0, NB1, NB2, NB3, ((T) + 1) % NSET)                                     \
+    CARO_AWAIT(8, A0, A1, A2, A3, B0, B1, B2, B3)                                                            \
+  } else {                                                                                                   \
+    CARO_AWAIT(0, A0, A1, A2, A3, B0, B1, B2, B3)                                                            \
+  }                                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                         \
+  CARO_BURST(A0, A1, A2, A3, B0, B1, B2, B3)
+
+  for (int layer = 0; layer < NRES; ++layer) {
+    const int c0 = layer * 6;  // first chunk of the layer; 6 % WNBUF == 0, so chunk c0 + k sits in buffer k % WNBUF
+    f32x16 accM0, accM1, accM2, accM3;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      accY0[e] = fmaf(c0, accM[e], accY0[e]);
-      accY1[e] = fmaf(c1, accM[e], accY1[e]);
-      accM[e] = 0.f;
+      accM0[e] = 0.f;
+      accM1[e] = 0.f;
+      accM2[e] = 0.f;
+      accM3[e] = 0.f;
     }
+    CARO_ALOAD(D0, D1, D2, D3, W0, W1, W2, W3, 0)
+#define CARO_PAIR(T)                                                                                         \
+  CARO_STEP(T, D0, D1, D2, D3, W0, W1, W2, W3, E0, E1, E2, E3, X0, X1, X2, X3)                               \
+  CARO_STEP((T) + 1, E0, E1, E2, E3, X0, X1, X2, X3, D0, D1, D2, D3, W0, W1, W2, W3)
+    CARO_PAIR(0) CARO_PAIR(2) CARO_PAIR(4)
+    if constexpr (NSET > 6) { CARO_PAIR(6) CARO_PAIR(8) CARO_PAIR(10) }
+    if constexpr (NSET > 12) { CARO_PAIR(12) CARO_PAIR(14) CARO_PAIR(16) CARO_PAIR(18) CARO_PAIR(20) CARO_PAIR(22) }
+#undef CARO_PAIR
+    // output transform: Y0 += {1,1,1,0}[p] * M_p,  Y1 += {0,1,-1,-1}[p] * M_p, p = 0..3 in this order
+    f32x16 accY0, accY1;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      offa[d] = noffa[d];
-      offb[d] = noffb[d];
+    for (int e = 0; e < 16; ++e) {
+      float y0 = fmaf(1.f, accM0[e], 0.f), y1 = fmaf(0.f, accM0[e], 0.f);
+      y0 = fmaf(1.f, accM1[e], y0); y1 = fmaf(1.f, accM1[e], y1);
+      y0 = fmaf(1.f, accM2[e], y0); y1 = fmaf(-1.f, accM2[e], y1);
+      y0 = fmaf(0.f, accM3[e], y0); y1 = fmaf(-1.f, accM3[e], y1);
+      accY0[e] = y0;
+      accY1[e] = y1;
     }
-    if (pp == 3) {
-      __syncthreads();  // every wave has read this layer's input activations: they may be overwritten
-      if (KS > 1) {
-        // partial sums of the waves kq > 0 -> the weight buffer just read (free until the next chunk's fetch,
-        // which waits for the barrier after that chunk's first tap) -> added by the wave kq == 0 of the same tile
-        float* red = wbuf + cur * TPC * WCHUNK;
-        constexpr int NTASK = 2 * NRT;
-        const int task = rt * 2 + ct;
-        if (kq > 0) {
-          float* dst = red + ((kq - 1) * NTASK + task) * 2048 + lane;
+    __syncthreads();  // every wave has read this layer's input activations: they may be overwritten
+    if (KS > 1) {
+      // partial sums of the waves kq > 0 -> ring buffer 2 (it held the layer's last chunk; the next fetch into it is
+      // issued at the barrier of the next layer's second chunk) -> added by the wave kq == 0 of the same tile, in the
+      // order kq = 1, 2, 3.  The buffer holds four partials of 8 KiB: with KS = 4 the third wave goes second.
+      float* red = wbuf + 2 * WCH;
+      constexpr int NTASK = 2 * NRT;
+      const int task = rt * 2 + ct;
+#pragma unroll
+      for (int round = 0; round < (KS == 4 ? 2 : 1); ++round) {
+        const int k_lo = round == 0 ? 1 : 3, k_hi = round == 0 ? (KS == 4 ? 2 : KS - 1) : 3;
+        if (kq >= k_lo && kq <= k_hi) {
+          float* dst = red + ((kq - k_lo) * NTASK + task) * 2048 + lane;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             dst[e * 64] = accY0[e];
@@ -615,9 +648,8 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
         }
         __syncthreads();
         if (kq == 0) {
-#pragma unroll
-          for (int k = 1; k < KS; ++k) {
-            const float* src = red + ((k - 1) * NTASK + task) * 2048 + lane;
+          for (int k = k_lo; k <= k_hi; ++k) {
+            const float* src = red + ((k - k_lo) * NTASK + task) * 2048 + lane;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               accY0[e] += src[e * 64];
@@ -625,43 +657,43 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
             }
           }
         }
+        if (KS == 4 && round == 0) __syncthreads();  // the partials of kq = 1, 2 have been read
       }
-      const bool writer = kq == 0;
-      // in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89); only real cells are written, the rest stay 0
-      const float* bias = p.b_res + layer * NF + ct * 32 + 4 * h;
-      const int g0 = ct * 8 + h;  // granule of group q is g0 + 2q
-      float* row0p = act + orow0 * NF;
-      float* row1p = row0p + p.W * NF;
-      const int k0 = orow0 & 15, k1 = (orow0 + p.W) & 15;
-      float4 old0[4], old1[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        old0[q] = ovalid0 ? *reinterpret_cast<const float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        old1[q] = ovalid1 ? *reinterpret_cast<const float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 bq = *reinterpret_cast<const float4*>(bias + 8 * q);
-        float4 n0, n1;
-        n0.x = old0[q].x + leaky(accY0[4 * q] + bq.x, slope);
-        n0.y = old0[q].y + leaky(accY0[4 * q + 1] + bq.y, slope);
-        n0.z = old0[q].z + leaky(accY0[4 * q + 2] + bq.z, slope);
-        n0.w = old0[q].w + leaky(accY0[4 * q + 3] + bq.w, slope);
-        n1.x = old1[q].x + leaky(accY1[4 * q] + bq.x, slope);
-        n1.y = old1[q].y + leaky(accY1[4 * q + 1] + bq.y, slope);
-        n1.z = old1[q].z + leaky(accY1[4 * q + 2] + bq.z, slope);
-        n1.w = old1[q].w + leaky(accY1[4 * q + 3] + bq.w, slope);
-        if (ovalid0 && writer) *reinterpret_cast<float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) = n0;
-        if (ovalid1 && writer) *reinterpret_cast<float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) = n1;
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        accY0[e] = 0.f;
-        accY1[e] = 0.f;
-      }
-      __syncthreads();  // new activations visible to every wave
     }
+    const bool writer = kq == 0;
+    // in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89); only real cells are written, the rest stay 0
+    const float* bias = p.b_res + layer * NF + ct * 32 + 4 * h;
+    const int g0 = ct * 8 + h;  // granule of group q is g0 + 2q
+    float* row0p = act + orow0 * NF;
+    float* row1p = row0p + p.W * NF;
+    const int k0 = orow0 & 15, k1 = (orow0 + p.W) & 15;
+    float4 old0[4], old1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      old0[q] = ovalid0 ? *reinterpret_cast<const float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      old1[q] = ovalid1 ? *reinterpret_cast<const float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bq = *reinterpret_cast<const float4*>(bias + 8 * q);
+      float4 n0, n1;
+      n0.x = old0[q].x + leaky(accY0[4 * q] + bq.x, slope);
+      n0.y = old0[q].y + leaky(accY0[4 * q + 1] + bq.y, slope);
+      n0.z = old0[q].z + leaky(accY0[4 * q + 2] + bq.z, slope);
+      n0.w = old0[q].w + leaky(accY0[4 * q + 3] + bq.w, slope);
+      n1.x = old1[q].x + leaky(accY1[4 * q] + bq.x, slope);
+      n1.y = old1[q].y + leaky(accY1[4 * q + 1] + bq.y, slope);
+      n1.z = old1[q].z + leaky(accY1[4 * q + 2] + bq.z, slope);
+      n1.w = old1[q].w + leaky(accY1[4 * q + 3] + bq.w, slope);
+      if (ovalid0 && writer) *reinterpret_cast<float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) = n0;
+      if (ovalid1 && writer) *reinterpret_cast<float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) = n1;
+    }
+    __syncthreads();  // new activations visible to every wave
   }
+#undef CARO_STEP
+#undef CARO_BURST
+#undef CARO_AWAIT
+#undef CARO_ALOAD
 }
 
 __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams p1,
@@ -670,7 +702,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
                                                            float* __restrict__ probs, float* __restrict__ values,
                                                            unsigned long long* __restrict__ stamps,
                                                            const int32_t* __restrict__ gpack, int gG, int gB) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  __shared__ __attribute__((aligned(256))) float lds[LDS_FLOATS];  // trunk_w XORs granule bits into LDS addresses
   float* act = lds;
   float* wbuf = lds + ACT;
 
@@ -735,21 +767,21 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   const int R = nb * HW;  // real rows
   const int tid = threadIdx.x;
 
+  // the first two weight chunks are on their way into ring buffers 0 and 1 while conv_in runs; its scratch (the
+  // conv_in weights, the row map) sits in buffer 2, which is fetched into only after the trunk's first barrier
+  fetch_chunk(p.ww, 0, lds_addr(wbuf), tid);
+  fetch_chunk(p.ww, 1, lds_addr(wbuf), tid);
+  float* win = wbuf + 2 * WCH;
   for (int k = tid; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = tid; k < 9 * 2 * NF; k += NT) wbuf[k] = p.w_in[k];
-  int* smap = reinterpret_cast<int*>(wbuf + 1536);  // [TB] plane / output row of every board of this tile
+  for (int k = tid; k < 9 * 2 * NF; k += NT) win[k] = p.w_in[k];
+  int* smap = reinterpret_cast<int*>(win + 1536);  // [TB] plane / output row of every board of this tile
   tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
-  conv_in_f32(p, planes, smap, act, wbuf, R, tid);
+  conv_in_f32(p, planes, smap, act, win, R, tid);
   const int slot_v = tid < nb ? smap[tid] : 0;
-  __syncthreads();
   unsigned long long t_trunk0 = 0;
   if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
-  {
-    const float4* src = reinterpret_cast<const float4*>(p.ww);
-#pragma unroll
-    for (int m = 0; m < 2 * TPC; ++m) reinterpret_cast<float4*>(wbuf)[tid + NT * m] = src[tid + NT * m];
-  }
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // conv_in's output and the two chunks are visible to every wave
 
   if (ks == 1) trunk_w<1>(p, act, wbuf, nb, tid);
   else if (ks == 2) trunk_w<2>(p, act, wbuf, nb, tid);
@@ -1258,8 +1290,27 @@ int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats
   if (hipSetDevice(n->device) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
   if (!n->ww_dev && hipMalloc((void**)&n->ww_dev, want * sizeof(float)) != hipSuccess)
     return nfail(CARO_E_NOMEM, "hipMalloc failed");
-  if (hipMemcpy(n->ww_dev, ww_host, want * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
-    return nfail(CARO_E_HIP, "hipMemcpy failed");
+  {
+    // The kernel streams the weights in chunks of (layer, dx, granule half): [p][h][co][4 granules of 4 k] with the
+    // granule index XORed by (co >> 2) & 3 (trunk_w); the caller's image is [layer][p][dx][h][co][8 granules of 4 k]
+    // with the granule index XORed by (co >> 1) & 7 (the order of the plain residual weights).
+    std::vector<float> img((size_t)want);
+    for (int layer = 0; layer < cnet::NRES; ++layer)
+      for (int dx = 0; dx < 3; ++dx)
+        for (int hq = 0; hq < 2; ++hq)
+          for (int pp = 0; pp < 4; ++pp)
+            for (int h = 0; h < 2; ++h)
+              for (int co = 0; co < 64; ++co)
+                for (int g = 0; g < 4; ++g) {
+                  const float* src = ww_host + ((size_t)(layer * 4 + pp) * 3 + dx) * cnet::WCHUNK + (h * 64 + co) * 32 +
+                                     (((hq * 4 + g) ^ ((co >> 1) & 7)) << 2);
+                  float* dst = img.data() + ((size_t)(layer * 3 + dx) * 2 + hq) * cnet::WCH +
+                               ((pp * 2 + h) * 64 + co) * 16 + ((g ^ ((co >> 2) & 3)) << 2);
+                  for (int j = 0; j < 4; ++j) dst[j] = src[j];
+                }
+    if (hipMemcpy(n->ww_dev, img.data(), want * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+      return nfail(CARO_E_HIP, "hipMemcpy failed");
+  }
   const int H = n->p.H, W = n->p.W, HW = n->p.HW;
   const int tpb = ((H + 1) / 2) * W;
   if (tpb > 128) return nfail(CARO_E_INVAL, "board too large for the 128-tile workgroup");
