@@ -124,50 +124,73 @@ __device__ __forceinline__ void conv_in_f32(const NetParams& p, const float* __r
 // 1x1 heads, the two FC heads, tanh and the softmax (lib/model.py:44-67, lib/mcts.py:216) from the trunk
 // output in `act`; `scratch` = the (now free) weight stage.  probs / values are the launch's output rows;
 // `slot_v` = output row of board `tid` (threads tid < nb), re-published through the scratch for the prob rows.
+// The head parameters [w_head 3x64][b_head 3][w_v1 20 HW][b_v1 20][w_v2 20][b_v2 1][w_p A x 2HW][b_p A] are one
+// contiguous block of the packed buffer.  STAGED: the block already sits in LDS at scratch + HEAD_STAGE_AT (k_net_forward_w
+// fetches it during the trunk's last chunks when it fits) -- the dot products then never wait for L2.
+// Every output is the same fma chain in the same order in both forms; only who computes what changed: the value and
+// the policy rows of the FC stage, and the tanh and the softmax terms, run on different waves side by side.
+constexpr int HEAD_STAGE_AT = 4096;   // floats into the scratch
+constexpr int HEAD_STAGE_MAX = 4096;  // floats
+__device__ __forceinline__ int head_span(int HW, int A) { return 3 * NF + 3 + 20 * HW + 20 + 20 + 1 + A * 2 * HW + A; }
+
+template <bool STAGED>
 __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, float* scratch,
                                           float* __restrict__ probs, float* __restrict__ values, int slot_v, int nb,
                                           int R, int tid) {
-  const int HW = p.HW;
+  const int HW = p.HW, A = p.A;
   const float slope = p.slope;
+  const float* hp = STAGED ? scratch + HEAD_STAGE_AT : p.w_head;
+  const float* w_head = hp;
+  const float* b_head = w_head + 3 * NF;
+  const float* w_v1 = b_head + 3;
+  const float* b_v1 = w_v1 + 20 * HW;
+  const float* w_v2 = b_v1 + 20;
+  const float* b_v2 = w_v2 + 20;
+  const float* w_p = b_v2 + 1;
+  const float* b_p = w_p + (size_t)A * 2 * HW;
   float* feat = scratch;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
-  int* omap = reinterpret_cast<int*>(scratch + 768 + 20 * 32 + 1024 + 64);  // [TB] output rows, behind `stat`
-  if (tid < nb) omap[tid] = slot_v;
-  {
-    const int r = tid;
-    if (r < R) {
-      float s0 = p.b_head[0], s1 = p.b_head[1], s2 = p.b_head[2];
-      for (int g = 0; g < 16; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(act + r * NF + ((g ^ (r & 15)) << 2));
-        const int c = g * 4;
-        s0 = fmaf(v.x, p.w_head[c], s0); s0 = fmaf(v.y, p.w_head[c + 1], s0);
-        s0 = fmaf(v.z, p.w_head[c + 2], s0); s0 = fmaf(v.w, p.w_head[c + 3], s0);
-        s1 = fmaf(v.x, p.w_head[NF + c], s1); s1 = fmaf(v.y, p.w_head[NF + c + 1], s1);
-        s1 = fmaf(v.z, p.w_head[NF + c + 2], s1); s1 = fmaf(v.w, p.w_head[NF + c + 3], s1);
-        s2 = fmaf(v.x, p.w_head[2 * NF + c], s2); s2 = fmaf(v.y, p.w_head[2 * NF + c + 1], s2);
-        s2 = fmaf(v.z, p.w_head[2 * NF + c + 2], s2); s2 = fmaf(v.w, p.w_head[2 * NF + c + 3], s2);
-      }
-      feat[r] = leaky(s0, slope);
-      feat[256 + r] = leaky(s1, slope);
-      feat[512 + r] = leaky(s2, slope);
-    }
-  }
-  __syncthreads();
+#if defined(CARO_EXP) && CARO_EXP == 20  // timing experiment: phase stamps of the heads behind the staged block
+  unsigned long long* hst = reinterpret_cast<unsigned long long*>(scratch + HEAD_STAGE_AT + HEAD_STAGE_MAX + 8);
+#define CARO_HST(n) if (tid == 0) hst[n] = __builtin_amdgcn_s_memtime();
+#else
+#define CARO_HST(n)
+#endif
+  CARO_HST(0)
   float* hid = feat + 768;              // [TB][20]
   float* logit = feat + 768 + 20 * 32;  // [TB * A] (TB * A <= 1024, see caro_net_create)
-  // value head: Linear(HW,20) + LeakyReLU
+  float* stat = logit + 256 * 4;        // [TB][2] max, sum  (logit region sized 1024 floats)
+  int* omap = reinterpret_cast<int*>(stat + 64);  // [TB] output rows
+  float* ebuf = stat + 128;             // [TB * A] exp(logit - max)
+  if (tid < nb) omap[tid] = slot_v;
+  // the 1x1 convolutions: 3 R dot products of 64 (row r, plane o), each a chain in channel order, dealt to all threads
+  for (int q = tid; q < 3 * R; q += NT) {
+    const int o = q / R, r = q - o * R;
+    const float* wo = w_head + o * NF;
+    float s0 = b_head[o];
+    for (int g = 0; g < 16; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(act + r * NF + ((g ^ (r & 15)) << 2));
+      const float4 w = *reinterpret_cast<const float4*>(wo + g * 4);
+      s0 = fmaf(v.x, w.x, s0); s0 = fmaf(v.y, w.y, s0);
+      s0 = fmaf(v.z, w.z, s0); s0 = fmaf(v.w, w.w, s0);
+    }
+    feat[o * 256 + r] = leaky(s0, slope);
+  }
+  __syncthreads();
+  CARO_HST(1)
+  // value head: Linear(HW,20) + LeakyReLU -- threads from 0 up
   for (int k = tid; k < nb * 20; k += NT) {
     const int bi = k / 20, u = k - bi * 20;
-    float s = p.b_v1[u];
-    const float* w = p.w_v1 + u * HW;
+    float s = b_v1[u];
+    const float* w = w_v1 + u * HW;
     const float* f = feat + bi * HW;
     for (int c = 0; c < HW; ++c) s = fmaf(f[c], w[c], s);
     hid[k] = leaky(s, slope);
   }
-  // policy head: Linear(2*HW, A) on the (c, y, x)-flattened planes
-  for (int k = tid; k < nb * p.A; k += NT) {
-    const int bi = k / p.A, a = k - bi * p.A;
-    float s = p.b_p[a];
-    const float* w = p.w_p + (size_t)a * 2 * HW;
+  // policy head: Linear(2*HW, A) on the (c, y, x)-flattened planes -- threads from the middle up, beside the value rows
+  for (int k = (tid + NT / 2) % NT; k < nb * A; k += NT) {
+    const int bi = k / A, a = k - bi * A;
+    float s = b_p[a];
+    const float* w = w_p + (size_t)a * 2 * HW;
     const float* f0 = feat + 256 + bi * HW;
     const float* f1 = feat + 512 + bi * HW;
     for (int c = 0; c < HW; ++c) s = fmaf(f0[c], w[c], s);
@@ -175,23 +198,33 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
     logit[k] = s;
   }
   __syncthreads();
-  // Linear(20,1) + tanh; softmax statistics per board
-  float* stat = logit + 256 * 4;  // [TB][2] max, sum  (logit region sized 1024 floats)
-  if (tid < nb) {
-    float s = p.b_v2[0];
-    for (int u = 0; u < 20; ++u) s = fmaf(hid[tid * 20 + u], p.w_v2[u], s);
-    values[slot_v] = tanhf(s);
+  CARO_HST(2)
+  // Linear(20,1) + tanh on the last wave; beside it the softmax terms exp(logit - max), one thread per action
+  {
+    const int vt = tid - (NT - 64);
+    if (vt >= 0 && vt < nb) {
+      float s = b_v2[0];
+      for (int u = 0; u < 20; ++u) s = fmaf(hid[vt * 20 + u], w_v2[u], s);
+      values[omap[vt]] = tanhf(s);
+    }
+  }
+  for (int k = tid; k < nb * A; k += NT) {
+    const int bi = k / A;
     float mx = -3.4e38f;
-    for (int a = 0; a < p.A; ++a) mx = fmaxf(mx, logit[tid * p.A + a]);
+    for (int a = 0; a < A; ++a) mx = fmaxf(mx, logit[bi * A + a]);
+    ebuf[k] = expf(logit[k] - mx);
+  }
+  __syncthreads();
+  if (tid < nb) {  // the sum in action order, as a sequential softmax does
     float sum = 0.f;
-    for (int a = 0; a < p.A; ++a) sum += expf(logit[tid * p.A + a] - mx);
-    stat[2 * tid] = mx;
+    for (int a = 0; a < A; ++a) sum += ebuf[tid * A + a];
     stat[2 * tid + 1] = sum;
   }
   __syncthreads();
-  for (int k = tid; k < nb * p.A; k += NT) {
-    const int bi = k / p.A;
-    probs[(size_t)omap[bi] * p.A + (k - bi * p.A)] = expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
+  CARO_HST(3)
+  for (int k = tid; k < nb * A; k += NT) {
+    const int bi = k / A;
+    probs[(size_t)omap[bi] * A + (k - bi * A)] = ebuf[k] / stat[2 * bi + 1];
   }
 }
 
@@ -416,7 +449,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
   // `act` now holds the trunk output; the weight stage is free scratch
-  heads_f32(p, act, wbuf, probs, values, slot_v, nb, R, tid);
+  heads_f32<false>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
     stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
@@ -474,8 +507,17 @@ __device__ __forceinline__ void fetch_chunk(const float* ww, int c, unsigned wri
   for (int m = 0; m < WCH / 4 / NT; ++m) dma_b128(src + m * NT, dst + m * NT * 16);
 }
 
+// the head parameters (heads_f32<true>) -> ring buffer 0 + HEAD_STAGE_AT, issued when that buffer has seen its last
+// chunk; over-reads up to 8 KiB past the block (the packed buffer is padded by a whole tap chunk)
+__device__ __forceinline__ void fetch_heads(const float* hp, int hspan, unsigned wring, int tid) {
+  const float4* src = reinterpret_cast<const float4*>(hp) + tid;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(wring + HEAD_STAGE_AT * 4u + (unsigned)(tid >> 6) * 1024u);
+  dma_b128(src, dst);
+  if (hspan > NT * 4) dma_b128(src + NT, dst + NT * 16);
+}
+
 template <int KS>
-__device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* wbuf, int nb, int tid) {
+__device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* wbuf, int nb, int tid, int hspan) {
   const float slope = p.slope;
   const int HW = p.HW;
   const int wave = tid >> 6, lane = tid & 63;
@@ -580,13 +622,17 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
 // MFMAs of set T.  At the first set of a chunk (T % NQ == 0) sits the ONE workgroup barrier of the chunk:
 //   every read this wave has issued is complete (lgkmcnt(0)), its share of chunk c+1 has arrived (vmcnt(0), issued a
 //   whole chunk ago) -> barrier -> chunk c+1 is visible to every wave and no wave reads chunk c-1 any more -> chunk
-//   c+2 is fetched into that buffer.
+//   c+2 is fetched into that buffer.  (For a layer's first chunk the barrier is the one that ends the previous
+//   layer's epilogue, or the kernel's barrier after conv_in.)
 #define CARO_STEP(T, A0, A1, A2, A3, B0, B1, B2, B3, NA0, NA1, NA2, NA3, NB0, NB1, NB2, NB3)                 \
   if ((T) % NQ == 0) {                                                                                       \
     CARO_AWAIT(0, A0, A1, A2, A3, B0, B1, B2, B3)                                                            \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
-    __syncthreads();                                                                                         \
+    if ((T) != 0) { /* a layer's first chunk: the barrier that published its input activations did this */   \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+      __syncthreads();                                                                                       \
+    }                                                                                                        \
     if (c0 + (T) / NQ + 2 < WNCHUNK) fetch_chunk(p.ww, c0 + (T) / NQ + 2, wring, tid);                       \
+    else if (c0 + (T) / NQ + 2 == WNCHUNK && hspan) fetch_heads(p.w_head, hspan, wring, tid);                \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     if ((T) + 1 < NSET) CARO_ALOAD(NA0, NA1, NA2, NA3, NB0, NB1, NB2, NB3, ((T) + 1) % NSET)                 \
   } else if ((T) + 1 < NSET) {                                                                               \
@@ -688,7 +734,10 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
       if (ovalid0 && writer) *reinterpret_cast<float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) = n0;
       if (ovalid1 && writer) *reinterpret_cast<float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) = n1;
     }
-    __syncthreads();  // new activations visible to every wave
+    // new activations visible to every wave; it is also the chunk barrier of the next layer's first chunk (this
+    // wave's share of its second chunk has arrived, nobody reads this layer's last chunks any more)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
 #undef CARO_STEP
 #undef CARO_BURST
@@ -783,17 +832,24 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // conv_in's output and the two chunks are visible to every wave
 
-  if (ks == 1) trunk_w<1>(p, act, wbuf, nb, tid);
-  else if (ks == 2) trunk_w<2>(p, act, wbuf, nb, tid);
-  else trunk_w<4>(p, act, wbuf, nb, tid);
+  // head parameters staged in LDS during the trunk's last chunks when they fit (heads_f32)
+  const int hspan = head_span(HW, p.A) <= HEAD_STAGE_MAX ? head_span(HW, p.A) : 0;
+  if (ks == 1) trunk_w<1>(p, act, wbuf, nb, tid, hspan);
+  else if (ks == 2) trunk_w<2>(p, act, wbuf, nb, tid, hspan);
+  else trunk_w<4>(p, act, wbuf, nb, tid, hspan);
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
-  heads_f32(p, act, wbuf, probs, values, slot_v, nb, R, tid);
+  if (hspan) heads_f32<true>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
+  else heads_f32<false>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
     stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
     stamps[4 * blockIdx.x + 2] = t_trunk0 - t_c0;
     stamps[4 * blockIdx.x + 3] = t_trunk1 - t_c0;
+#if defined(CARO_EXP) && CARO_EXP == 20
+    const unsigned long long* hst = reinterpret_cast<const unsigned long long*>(wbuf + HEAD_STAGE_AT + HEAD_STAGE_MAX + 8);
+    stamps[4 * blockIdx.x + 1] = (hst[1] - hst[0]) | (hst[2] - hst[1]) << 20 | (hst[3] - hst[2]) << 40;
+#endif
   }
 }
 
