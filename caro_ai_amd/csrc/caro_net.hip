@@ -516,6 +516,20 @@ __device__ __forceinline__ void fetch_heads(const float* hp, int hspan, unsigned
   if (hspan > NT * 4) dma_b128(src + NT, dst + NT * 16);
 }
 
+// timing experiments (tools/build_exp.sh N; the results are wrong, only the clock is read): 21 no chunk barriers,
+// 22 no weight fetches, 23 neither.  Measured at 1434 leaves: trunk 296 k cycles, 293 k / 289 k / 281 k without.  The
+// fetches cost what their 960 KiB per workgroup take of the LDS write port (128 B per cycle: 7.5 k cycles); issuing them
+// in the shadow of the MFMAs instead of in front of a chunk's first burst changed nothing.
+#if defined(CARO_EXP) && (CARO_EXP == 21 || CARO_EXP == 23)
+#define CARO_CHUNK_BARRIER
+#else
+#define CARO_CHUNK_BARRIER __syncthreads();
+#endif
+#if defined(CARO_EXP) && (CARO_EXP == 22 || CARO_EXP == 23)
+#define CARO_FETCH_ON 0
+#else
+#define CARO_FETCH_ON 1
+#endif
 template <int KS>
 __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* wbuf, int nb, int tid, int hspan) {
   const float slope = p.slope;
@@ -629,9 +643,9 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     CARO_AWAIT(0, A0, A1, A2, A3, B0, B1, B2, B3)                                                            \
     if ((T) != 0) { /* a layer's first chunk: the barrier that published its input activations did this */   \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
-      __syncthreads();                                                                                       \
+      CARO_CHUNK_BARRIER                                                                                     \
     }                                                                                                        \
-    if (c0 + (T) / NQ + 2 < WNCHUNK) fetch_chunk(p.ww, c0 + (T) / NQ + 2, wring, tid);                       \
+    if (CARO_FETCH_ON && c0 + (T) / NQ + 2 < WNCHUNK) fetch_chunk(p.ww, c0 + (T) / NQ + 2, wring, tid);      \
     else if (c0 + (T) / NQ + 2 == WNCHUNK && hspan) fetch_heads(p.w_head, hspan, wring, tid);                \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     if ((T) + 1 < NSET) CARO_ALOAD(NA0, NA1, NA2, NA3, NB0, NB1, NB2, NB3, ((T) + 1) % NSET)                 \
