@@ -589,30 +589,47 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
   const unsigned wlane = lds_addr(wbuf) + (unsigned)((h * 64 + ct * 32 + i) * 16 + ((kq ^ ((i >> 2) & 3)) << 2)) * 4u;
   const unsigned wring = lds_addr(wbuf);
 
-  f4v D0, D1, D2, D3, W0, W1, W2, W3;  // operand set A
-  f4v E0, E1, E2, E3, X0, X1, X2, X3;  // operand set B
+  f4v D0, D1, D2, D3;                  // the four input rows of the operand set in flight
+  f4v W0, W1, W2, W3, X0, X1, X2, X3;  // its weight granules: two sets, the MFMAs read one while the other loads
 // operand set T of the layer: chunk T / NQ (dx = chunk >> 1, granule half = chunk & 1), granule (T % NQ) * KS of the half
-#define CARO_ALOAD(A0, A1, A2, A3, B0, B1, B2, B3, T)                                                        \
+#define CARO_ALOAD(B0, B1, B2, B3, T)                                                                        \
   {                                                                                                          \
     constexpr int cc_ = (T) / NQ, dx_ = cc_ >> 1, g8_ = (cc_ & 1) * 4 + ((T) % NQ) * KS;                     \
     const unsigned wa_ = (wlane + (unsigned)(cc_ % WNBUF) * (WCH * 4)) ^ ((unsigned)(((T) % NQ) * KS) << 4); \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(A0) : "v"(ra[0][dx_] ^ (g8_ << 4)));                           \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(A1) : "v"(ra[1][dx_] ^ (g8_ << 4)));                           \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(A2) : "v"(ra[2][dx_] ^ (g8_ << 4)));                           \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(A3) : "v"(ra[3][dx_] ^ (g8_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(D0) : "v"(ra[0][dx_] ^ (g8_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(D1) : "v"(ra[1][dx_] ^ (g8_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(D2) : "v"(ra[2][dx_] ^ (g8_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(D3) : "v"(ra[3][dx_] ^ (g8_ << 4)));                           \
     asm volatile("ds_read_b128 %0, %1" : "=v"(B0) : "v"(wa_));                                               \
     asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(B1) : "v"(wa_));                                   \
     asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(B2) : "v"(wa_));                                  \
     asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(B3) : "v"(wa_));                                  \
   }
-// the reads of a set are complete when at most N later LDS operations are outstanding (LDS returns in order)
-#define CARO_AWAIT(N, A0, A1, A2, A3, B0, B1, B2, B3)                                                        \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                   \
-               : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3));
-// the four transformed operands, then 16 MFMAs on four independent accumulators
-#define CARO_BURST(A0, A1, A2, A3, B0, B1, B2, B3)                                                           \
+// every LDS read this wave has issued is complete (the compiler does not know of the reads above)
+#define CARO_AWAIT(B0, B1, B2, B3)                                                                           \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(D0), "+v"(D1), "+v"(D2), "+v"(D3), "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3));
+// One step of the layer's software pipeline.  Set T has been requested a whole burst ago: wait for it, form the four
+// transformed operands (the row registers are free again), request set T+1 -- rows into the same registers, weights
+// into the other set -- and issue the 16 MFMAs of set T on four independent accumulators.
+// At the first set of a chunk (T % NQ == 0) sits the ONE workgroup barrier of the chunk:
+//   every read this wave has issued is complete, its share of chunk c+1 has arrived (vmcnt(0), issued a whole chunk
+//   ago) -> barrier -> chunk c+1 is visible to every wave and no wave reads chunk c-1 any more -> chunk c+2 is
+//   fetched into that buffer.  (For a layer's first chunk the barrier is the one that ends the previous layer's
+//   epilogue, or the kernel's barrier after conv_in.)
+#define CARO_STEP(T, B0, B1, B2, B3, NB0, NB1, NB2, NB3)                                                     \
+  CARO_AWAIT(B0, B1, B2, B3)                                                                                 \
+  if ((T) % NQ == 0) {                                                                                       \
+    if ((T) != 0) {                                                                                          \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+      CARO_CHUNK_BARRIER                                                                                     \
+    }                                                                                                        \
+    if (CARO_FETCH_ON && c0 + (T) / NQ + 2 < WNCHUNK) fetch_chunk(p.ww, c0 + (T) / NQ + 2, wring, tid);      \
+    else if (c0 + (T) / NQ + 2 == WNCHUNK && hspan) fetch_heads(p.w_head, hspan, wring, tid);                \
+  }                                                                                                          \
   {                                                                                                          \
-    const f4v v0 = A0 - A2, v1 = A1 + A2, v2 = A2 - A1, v3 = A1 - A3;                                        \
+    const f4v v0 = D0 - D2, v1 = D1 + D2, v2 = D2 - D1, v3 = D1 - D3;                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if ((T) + 1 < NSET) CARO_ALOAD(NB0, NB1, NB2, NB3, ((T) + 1) % NSET)                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.x, v0.x, accM0, 0, 0, 0);                                \
     accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.x, v1.x, accM1, 0, 0, 0);                                \
@@ -632,31 +649,6 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.w, v3.w, accM3, 0, 0, 0);                                \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
   }
-// One step of the layer's software pipeline: set T is in (A.., B..), set T+1 goes into (NA.., NB..) ahead of the
-// MFMAs of set T.  At the first set of a chunk (T % NQ == 0) sits the ONE workgroup barrier of the chunk:
-//   every read this wave has issued is complete (lgkmcnt(0)), its share of chunk c+1 has arrived (vmcnt(0), issued a
-//   whole chunk ago) -> barrier -> chunk c+1 is visible to every wave and no wave reads chunk c-1 any more -> chunk
-//   c+2 is fetched into that buffer.  (For a layer's first chunk the barrier is the one that ends the previous
-//   layer's epilogue, or the kernel's barrier after conv_in.)
-#define CARO_STEP(T, A0, A1, A2, A3, B0, B1, B2, B3, NA0, NA1, NA2, NA3, NB0, NB1, NB2, NB3)                 \
-  if ((T) % NQ == 0) {                                                                                       \
-    CARO_AWAIT(0, A0, A1, A2, A3, B0, B1, B2, B3)                                                            \
-    if ((T) != 0) { /* a layer's first chunk: the barrier that published its input activations did this */   \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
-      CARO_CHUNK_BARRIER                                                                                     \
-    }                                                                                                        \
-    if (CARO_FETCH_ON && c0 + (T) / NQ + 2 < WNCHUNK) fetch_chunk(p.ww, c0 + (T) / NQ + 2, wring, tid);      \
-    else if (c0 + (T) / NQ + 2 == WNCHUNK && hspan) fetch_heads(p.w_head, hspan, wring, tid);                \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if ((T) + 1 < NSET) CARO_ALOAD(NA0, NA1, NA2, NA3, NB0, NB1, NB2, NB3, ((T) + 1) % NSET)                 \
-  } else if ((T) + 1 < NSET) {                                                                               \
-    CARO_ALOAD(NA0, NA1, NA2, NA3, NB0, NB1, NB2, NB3, ((T) + 1) % NSET)                                     \
-    CARO_AWAIT(8, A0, A1, A2, A3, B0, B1, B2, B3)                                                            \
-  } else {                                                                                                   \
-    CARO_AWAIT(0, A0, A1, A2, A3, B0, B1, B2, B3)                                                            \
-  }                                                                                                          \
-  __builtin_amdgcn_sched_barrier(0);                                                                         \
-  CARO_BURST(A0, A1, A2, A3, B0, B1, B2, B3)
 
   for (int layer = 0; layer < NRES; ++layer) {
     const int c0 = layer * 6;  // first chunk of the layer; 6 % WNBUF == 0, so chunk c0 + k sits in buffer k % WNBUF
@@ -668,10 +660,23 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
       accM2[e] = 0.f;
       accM3[e] = 0.f;
     }
-    CARO_ALOAD(D0, D1, D2, D3, W0, W1, W2, W3, 0)
+    // the per-set addresses (ra ^ granule) are re-formed in every layer: hoisted out of the layer loop they would take
+    // a hundred registers
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) asm volatile("" : "+v"(ra[r][d]));
+    // the per-set addresses (ra ^ granule) are re-formed in every layer: hoisted out of the layer loop -- as the compiler
+    // would -- they take a hundred registers and the kernel spills (4 MB of scratch writes per launch); neither keeping
+    // part of them, nor packed adds for the transforms, nor a table of weight addresses changed the trunk's time
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) asm volatile("" : "+v"(ra[r][d]));
+    CARO_ALOAD(W0, W1, W2, W3, 0)
 #define CARO_PAIR(T)                                                                                         \
-  CARO_STEP(T, D0, D1, D2, D3, W0, W1, W2, W3, E0, E1, E2, E3, X0, X1, X2, X3)                               \
-  CARO_STEP((T) + 1, E0, E1, E2, E3, X0, X1, X2, X3, D0, D1, D2, D3, W0, W1, W2, W3)
+  CARO_STEP(T, W0, W1, W2, W3, X0, X1, X2, X3)                                                               \
+  CARO_STEP((T) + 1, X0, X1, X2, X3, W0, W1, W2, W3)
     CARO_PAIR(0) CARO_PAIR(2) CARO_PAIR(4)
     if constexpr (NSET > 6) { CARO_PAIR(6) CARO_PAIR(8) CARO_PAIR(10) }
     if constexpr (NSET > 12) { CARO_PAIR(12) CARO_PAIR(14) CARO_PAIR(16) CARO_PAIR(18) CARO_PAIR(20) CARO_PAIR(22) }
@@ -754,7 +759,6 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     __syncthreads();
   }
 #undef CARO_STEP
-#undef CARO_BURST
 #undef CARO_AWAIT
 #undef CARO_ALOAD
 }

@@ -35,7 +35,8 @@ def _boards(L, shape, seed):
 
 
 @pytest.mark.parametrize("shape,A,weights", [((2, 6, 7), 7, "best_026_12000.dat"), ((2, 3, 3), 9, "best_005_00900.dat"),
-                                             ((2, 15, 15), 225, None), ((2, 5, 5), 25, None), ((2, 10, 10), 100, None)])
+                                             ((2, 15, 15), 225, None), ((2, 5, 5), 25, None), ((2, 10, 10), 100, None),
+                                             ((2, 6, 6), 36, None)])  # 6x6: the largest head block that is staged in LDS (two transfers)
 @pytest.mark.parametrize("L", [1, 5, 6, 7, 29, 300])
 @pytest.mark.parametrize("mode", ["f32", "f32w", "3xbf16"])
 def test_hip_net_matches_torch_fp32(shape, A, weights, L, mode):

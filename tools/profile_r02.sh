@@ -3,7 +3,7 @@
 # PMC passes (HBM bytes, MFMA busy), each in its own rocprofv3 run as the pool requires.  Output: gpurun_out/prof_r02/
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/prof_r02
+OUT=$ROOT/gpurun_out/${1:-prof_r02}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra-configs"
