@@ -217,7 +217,9 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
 int caro_net_enable_3xbf16(caro_net* n, const uint16_t* w3_host, int64_t n_u16);
 /* f32w mode: the 3x3 convolutions in row-Winograd F(2,3) form (float32 MFMA, two thirds of the multiplies;
  * results differ from the direct form by float32 rounding only).  ww_host = [5][4][3][4096] floats from
- * caro_ai_amd/net_hip.py:pack_net_w.  Lowers caro_net_boards_per_workgroup if 128 / (ceil(H/2)*W) is smaller. */
+ * caro_ai_amd/net_hip.py:pack_net_w ([layer][transformed tap p][dx], each in the order of the plain tap chunks); the
+ * library re-orders them into the chunks its kernel streams ([layer][dx][granule half][p]) at upload.
+ * Lowers caro_net_boards_per_workgroup if 128 / (ceil(H/2)*W) is smaller. */
 int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats);
 void caro_net_destroy(caro_net* n);
 int caro_net_boards_per_workgroup(const caro_net* n);
