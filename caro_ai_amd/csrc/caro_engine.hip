@@ -842,9 +842,13 @@ __global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ n
     expand_body<GEO>(v, B, probs, values);
     __syncthreads();  // the block's own tree updates are visible to its descents
   }
-  if (v.dbg && threadIdx.x == 0) v.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime() - t0;  // expand + backup
+  const unsigned long long t1 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  if (v.dbg && threadIdx.x == 0 && !do_select) v.dbg[(size_t)blockIdx.x * 8 + 5] = t1 - t0;  // the closing launch: expand + backup alone
   if (do_select) select_body<GEO>(v, B, mb_index, noise, rows_cur, planes, leaf_keys);
-  if (v.dbg && threadIdx.x == 0) v.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime() - t0;  // whole block
+  if (v.dbg && threadIdx.x == 0 && do_select) {  // a launch in the middle of a move: expand + backup | whole block
+    v.dbg[(size_t)blockIdx.x * 8 + 6] = t1 - t0;
+    v.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - t0;
+  }
 }
 
 // ------------------------------------------------------------------ policy / step

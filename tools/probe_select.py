@@ -20,13 +20,19 @@ out = np.zeros(G * 8, np.uint64)
 _lib.check(L.caro_debug_read(eng.h, out.ctypes.data, out.size, None))
 d = out.reshape(G, 8).astype(np.float64)
 rows, noise, loop, end, maxd = d[:, 0], d[:, 1], d[:, 2], d[:, 3], d[:, 4]
-q = lambda x: np.percentile(x, [50, 90, 100]).round(0)
-print("cycles since kernel start (median / p90 / max over %d waves), last minibatch of a move:" % G)
+q = lambda x: np.percentile(x, [50, 90, 99, 100]).round(0)
+print("cycles since kernel start (median / p90 / p99 / max over %d waves), last minibatch of a move:" % G)
 print("  root rows + key arrived", q(rows))
 print("  noise generated        ", q(noise), " -> noise gen alone", q(noise - rows))
 print("  all descents done      ", q(loop), " -> descent loop after the root level", q(loop - noise))
 print("  end of kernel          ", q(end), " -> dedupe + result writes", q(end - loop))
-if d[:, 6].max() > 0:  # fused k_tree: expand + backup of the previous minibatch precedes the descents in the same block
-    print("  k_tree: expand+backup  ", q(d[:, 5]), " whole block", q(d[:, 6]), " select part", q(d[:, 6] - d[:, 5]))
+if d[:, 7].max() > 0:  # fused k_tree: expand + backup of the previous minibatch precedes the descents in the same block
+    print("  k_tree, last launch with descents: expand + backup", q(d[:, 6]), " whole block", q(d[:, 7]))
+    print("  k_tree, closing launch: expand + backup alone", q(d[:, 5]))
 print("  max depth in the wave  ", q(maxd), " cycles per level after the root (median)", np.median((loop - noise) / np.maximum(1, maxd - 1)).round(0))
+if d[:, 7].max() > 0:
+    order = np.argsort(-d[:, 7])[:12]
+    print("  the 12 slowest blocks: whole | expand+backup | descents: to the root level | loop | tail | max depth")
+    for b in order:
+        print("   %7.0f | %7.0f | %7.0f | %7.0f | %7.0f | %3.0f" % (d[b, 7], d[b, 6], noise[b], loop[b] - noise[b], end[b] - loop[b], maxd[b]))
 eng.close()
