@@ -7,23 +7,22 @@
 // minibatch) and ~45 launches; MIOpen has no gfx950 database in this image.
 // Here the grid is sized for the maximum and every workgroup reads L itself.
 //
-// Structure (one workgroup = 512 threads = 8 waves = one CU, two waves per SIMD so that one wave's
-// MFMAs cover the other's LDS operand reads; TB boards):
+// Three kernels share conv_in, the heads and the launch interface:
+//   k_net_forward_w  (default)  3x3 convolutions in row-Winograd F(2,3) form, float32 MFMA -- see trunk_w
+//   k_net_forward               direct 3x3 form, float32 MFMA (the round-1 kernel; `--net hip`)
+//   k_net_forward_3x (opt-in)   direct form on the bf16 pipe with three-way split operands
+// Common structure (one workgroup = 512 threads = 8 waves = one CU, two waves per SIMD; TB boards):
 //   rows r = board*HW + cell, at most 255 real rows; row 255 is a permanent zero
 //   row (3x3 padding).  Activations X[row][64] float32 stay in LDS for the whole
 //   trunk in ONE 64 KiB buffer (XOR-swizzled 16-byte granules) that is updated in
 //   place: a layer's outputs live in the MFMA accumulators until every wave has
-//   finished reading the layer's input, then overwrite it.  The
-//   3x3 convolutions are implicit GEMMs on v_mfma_f32_32x32x2_f32:
-//       M = 256 rows (8 row tiles), N = 64 (2 col tiles), K = 9 taps x 64 channels,
-//   wave w owns row tile w x both col tiles (2 accumulators of 16 regs).
+//   finished reading the layer's input, then overwrite it.  The 3x3 convolutions
+//   are implicit GEMMs on v_mfma_f32_32x32x2_f32 with the WEIGHTS as first operand.
 //   K order inside a tap: MFMA k-half h = lane>>5 carries channel 32h + j, so a
-//   lane's A operands for 4 consecutive k-steps are one ds_read_b128.
-//   Weights stream from L2 in chunks of three taps (3 x 64x64 floats = 48 KiB)
-//   through a double-buffered LDS stage: global loads for chunk c+1 are issued
-//   before the MFMAs of chunk c and written to the other buffer after them
-//   (issue-early / write-late), so there is one workgroup barrier per chunk
-//   plus two per layer around the in-place epilogue.
+//   lane's operands for 4 consecutive k-steps are one ds_read_b128.
+//   Weights stream from L2 through the other 96 KiB of LDS (k_net_forward: two buffers of three taps, staged through
+//   registers; k_net_forward_w: a ring of three 32 KiB chunks filled by global_load_lds, one workgroup barrier per
+//   chunk plus two per layer around the in-place epilogue).
 //   conv_in (K = 18), the 1x1 heads, the two FC heads, tanh and the softmax
 //   run on the VALU in the same kernel.
 // float32 throughout: MFMA f32 is an exact fma chain in k order.
