@@ -174,3 +174,19 @@ def test_pair_launch_equals_two_single_launches(mode):
         assert torch.equal(pa, pb) and torch.equal(va, vb), (l0, l1)
         assert (pa[rows:] == -1).all()
     n0.close(); n1.close()
+
+
+def test_default_net_kernel_bits_are_the_committed_ones():
+    """k_net_forward_w is deterministic and its arithmetic is pinned: the outputs for fixed inputs at every tile class
+    hash to the digests recorded by tests/golden/make_net_digest.py (round 2's re-ordered trunk left all of them as
+    the round-1 kernel produced them)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_net_digest", os.path.join(GOLDEN, "make_net_digest.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(GOLDEN, "net_hip_digest.json")))
+    got = mod.digests()
+    assert set(got) == set(want)
+    bad = sorted(k for k in want if got[k] != want[k])
+    assert not bad, bad
