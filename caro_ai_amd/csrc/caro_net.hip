@@ -494,7 +494,8 @@ __device__ __forceinline__ unsigned lds_addr(const void* q) {
 }
 // 16 bytes per lane global -> LDS, not tracked by the compiler (it would wait for vmcnt(0) in front of every later
 // ds_read): lane l of the wave writes lds_wave_base + 16 l.  The issuer waits (vmcnt(0)) before the barrier that
-// publishes the data.
+// publishes the data.  M0 is a reserved register: the compiler loads it right in front of each of its own uses and keeps
+// nothing alive in it, so it is not on the clobber list (hipcc warns if it is).
 __device__ __forceinline__ void dma_b128(const void* gsrc, unsigned lds_wave_base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_wave_base), "v"(gsrc) : "memory");
 }
