@@ -66,6 +66,7 @@ struct NetParams {
   const float* b_v2;    // [1]
   const float* w_p;     // [A][2*HW]
   const float* b_p;     // [A]
+  const float* w_pT;    // [2*HW][A]: w_p transposed (made at upload), for boards whose head block is not staged in LDS
   const uint4* w3;      // 3xbf16 mode: [45 taps][1536 granules] LDS image of the split residual weights, or null
   const float* ww;      // f32w mode: [5][3 dx][2 granule halves] chunks of [4 p][2 h][64 co][16] transformed residual weights (LDS image order of trunk_w), or null
   const uint32_t* wtab; // f32w mode: [128] tile of MFMA row (row tile, lane): board | ty << 8 | x << 16 | valid << 24
@@ -131,6 +132,7 @@ __device__ __forceinline__ void conv_in_f32(const NetParams& p, const float* __r
 constexpr int HEAD_STAGE_AT = 4096;   // floats into the scratch
 constexpr int HEAD_STAGE_MAX = 4096;  // floats
 __device__ __forceinline__ int head_span(int HW, int A) { return 3 * NF + 3 + 20 * HW + 20 + 20 + 1 + A * 2 * HW + A; }
+static inline int head_span_host(int HW, int A) { return 3 * NF + 3 + 20 * HW + 20 + 20 + 1 + A * 2 * HW + A; }
 
 template <bool STAGED>
 __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, float* scratch,
@@ -138,14 +140,28 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
                                           int R, int tid) {
   const int HW = p.HW, A = p.A;
   const float slope = p.slope;
-  const float* hp = STAGED ? scratch + HEAD_STAGE_AT : p.w_head;
+  // !STAGED (boards from 7x7 up): the parameters up to b_v2 (at most 4 740 floats) are copied to the place of the staged
+  // block now, all loads in flight together: the 20 threads of a board's value head each walked a row of w_v1 in global
+  // memory (225 dependent batches of loads at 15x15)
+  constexpr int NSM = (3 * NF + 3 + 20 * 225 + 20 + 20 + 1 + NT - 1) / NT;  // floats per thread at the largest board
+  const int nsmall = 3 * NF + 3 + 20 * HW + 20 + 20 + 1;
+  if (!STAGED) {
+    float tmp[NSM];
+#pragma unroll
+    for (int u = 0; u < NSM; ++u) tmp[u] = tid + u * NT < nsmall ? p.w_head[tid + u * NT] : 0.f;
+#pragma unroll
+    for (int u = 0; u < NSM; ++u)
+      if (tid + u * NT < nsmall) scratch[HEAD_STAGE_AT + tid + u * NT] = tmp[u];
+    __syncthreads();
+  }
+  const float* hp = scratch + HEAD_STAGE_AT;
   const float* w_head = hp;
   const float* b_head = w_head + 3 * NF;
   const float* w_v1 = b_head + 3;
   const float* b_v1 = w_v1 + 20 * HW;
   const float* w_v2 = b_v1 + 20;
   const float* b_v2 = w_v2 + 20;
-  const float* w_p = b_v2 + 1;
+  const float* w_p = STAGED ? b_v2 + 1 : p.w_head + nsmall;
   const float* b_p = w_p + (size_t)A * 2 * HW;
   float* feat = scratch;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
 #if defined(CARO_EXP) && CARO_EXP == 20  // timing experiment: phase stamps of the heads behind the staged block
@@ -189,11 +205,23 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
   for (int k = (tid + NT / 2) % NT; k < nb * A; k += NT) {
     const int bi = k / A, a = k - bi * A;
     float s = b_p[a];
-    const float* w = w_p + (size_t)a * 2 * HW;
     const float* f0 = feat + 256 + bi * HW;
     const float* f1 = feat + 512 + bi * HW;
-    for (int c = 0; c < HW; ++c) s = fmaf(f0[c], w[c], s);
-    for (int c = 0; c < HW; ++c) s = fmaf(f1[c], w[HW + c], s);
+    if (STAGED || !p.w_pT) {
+      const float* w = w_p + (size_t)a * 2 * HW;
+      for (int c = 0; c < HW; ++c) s = fmaf(f0[c], w[c], s);
+      for (int c = 0; c < HW; ++c) s = fmaf(f1[c], w[HW + c], s);
+    } else {
+      // large boards (the matrix is 405 KB at 15x15 and stays in L2): the same chain from the TRANSPOSED matrix, so
+      // that the threads of a wave -- consecutive outputs a -- read consecutive floats.  Row-major, every lane walked
+      // its own 1.8 KB row: 64 cache lines per wave instruction.
+      const float* w = p.w_pT + a;
+#pragma unroll 16
+      for (int c = 0; c < HW; ++c) s = fmaf(f0[c], w[(size_t)c * A], s);
+      w += (size_t)HW * A;
+#pragma unroll 16
+      for (int c = 0; c < HW; ++c) s = fmaf(f1[c], w[(size_t)c * A], s);
+    }
     logit[k] = s;
   }
   __syncthreads();
@@ -210,13 +238,25 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
   for (int k = tid; k < nb * A; k += NT) {
     const int bi = k / A;
     float mx = -3.4e38f;
-    for (int a = 0; a < A; ++a) mx = fmaxf(mx, logit[bi * A + a]);
+    const float* lg = logit + bi * A;
+    int a = 0;
+    for (; a + 8 <= A; a += 8) {  // eight reads in flight
+      const float t0 = lg[a], t1 = lg[a + 1], t2 = lg[a + 2], t3 = lg[a + 3], t4 = lg[a + 4], t5 = lg[a + 5], t6 = lg[a + 6], t7 = lg[a + 7];
+      mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, t0), fmaxf(t1, t2)), fmaxf(fmaxf(t3, t4), fmaxf(t5, t6))), t7);
+    }
+    for (; a < A; ++a) mx = fmaxf(mx, lg[a]);
     ebuf[k] = expf(logit[k] - mx);
   }
   __syncthreads();
   if (tid < nb) {  // the sum in action order, as a sequential softmax does
     float sum = 0.f;
-    for (int a = 0; a < A; ++a) sum += ebuf[tid * A + a];
+    const float* eb = ebuf + tid * A;
+    int a = 0;
+    for (; a + 8 <= A; a += 8) {  // eight reads in flight, the adds in action order
+      const float t0 = eb[a], t1 = eb[a + 1], t2 = eb[a + 2], t3 = eb[a + 3], t4 = eb[a + 4], t5 = eb[a + 5], t6 = eb[a + 6], t7 = eb[a + 7];
+      sum += t0; sum += t1; sum += t2; sum += t3; sum += t4; sum += t5; sum += t6; sum += t7;
+    }
+    for (; a < A; ++a) sum += eb[a];
     stat[2 * tid + 1] = sum;
   }
   __syncthreads();
@@ -1244,6 +1284,7 @@ struct caro_net {
   uint4* w3_dev;  // split residual weights (3xbf16 mode), or null
   float* ww_dev;  // transformed residual weights (f32w mode), or null
   uint32_t* wtab_dev;  // tile table (f32w mode), or null
+  float* wpT_dev;      // policy matrix transposed, or null
   int device;
 };
 
@@ -1300,6 +1341,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   n->w3_dev = nullptr;
   n->ww_dev = nullptr;
   n->wtab_dev = nullptr;
+  n->wpT_dev = nullptr;
   const size_t pad = (size_t)cnet::TPC * cnet::WCHUNK;  // k_net_forward reads one chunk past the last tap
   if (hipMalloc((void**)&n->dev, (n_floats + pad) * sizeof(float)) != hipSuccess) {
     delete n;
@@ -1331,7 +1373,23 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   p.w3 = nullptr;
   p.ww = nullptr;
   p.wtab = nullptr;
+  p.w_pT = nullptr;
   p.ncu = 0; p.TB2 = 0; p.TB4 = 0;
+  if (cnet::head_span_host(HW, A) > cnet::HEAD_STAGE_MAX) {  // the policy matrix column-major for the large-board heads
+    const size_t np = (size_t)A * 2 * HW;
+    const float* wp_host = packed_host + (p.w_p - n->dev);
+    std::vector<float> t(np);
+    for (int a = 0; a < A; ++a)
+      for (int c = 0; c < 2 * HW; ++c) t[(size_t)c * A + a] = wp_host[(size_t)a * 2 * HW + c];
+    if (hipMalloc((void**)&n->wpT_dev, np * sizeof(float)) != hipSuccess ||
+        hipMemcpy(n->wpT_dev, t.data(), np * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+      if (n->wpT_dev) (void)hipFree(n->wpT_dev);
+      (void)hipFree(n->dev);
+      delete n;
+      return nfail(CARO_E_NOMEM, "hipMalloc / hipMemcpy failed");
+    }
+    p.w_pT = n->wpT_dev;
+  }
   *out = n;
   return 0;
 }
@@ -1448,6 +1506,7 @@ void caro_net_destroy(caro_net* n) {
   if (n->w3_dev) (void)hipFree(n->w3_dev);
   if (n->ww_dev) (void)hipFree(n->ww_dev);
   if (n->wtab_dev) (void)hipFree(n->wtab_dev);
+  if (n->wpT_dev) (void)hipFree(n->wpT_dev);
   if (n->dev) (void)hipFree(n->dev);
   delete n;
 }
@@ -1469,6 +1528,7 @@ int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro
   n->w3_dev = nullptr;
   n->ww_dev = nullptr;
   n->wtab_dev = nullptr;
+  n->wpT_dev = nullptr;
   n->p.H = H; n->p.W = W; n->p.HW = H * W; n->p.A = A; n->p.TB = 4;
   *out = n;
   return 0;
