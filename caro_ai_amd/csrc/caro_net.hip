@@ -876,11 +876,17 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
 
   // the first two weight chunks are on their way into ring buffers 0 and 1 while conv_in runs; its scratch (the
   // conv_in weights, the row map) sits in buffer 2, which is fetched into only after the trunk's first barrier
+  float* win = wbuf + 2 * WCH;
+  // conv_in's weights first (1152 floats: the first five waves move 16 bytes per lane, b_in and a few floats more
+  // come along), then the two chunks: the wait below is for the oldest transfer only
+  if (tid < 320) dma_b128(reinterpret_cast<const float4*>(p.w_in) + tid,
+                          __builtin_amdgcn_readfirstlane(lds_addr(win) + (unsigned)(tid >> 6) * 1024u));
   fetch_chunk(p.ww, 0, lds_addr(wbuf), tid);
   fetch_chunk(p.ww, 1, lds_addr(wbuf), tid);
-  float* win = wbuf + 2 * WCH;
-  for (int k = tid; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = tid; k < 9 * 2 * NF; k += NT) win[k] = p.w_in[k];
+  // rows of boards this tile does not have, the spare rows and the zero row stay zero for ever; the others are written
+  // by conv_in
+  for (int k = tid + (R * NF) / 4; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 2 x 4 chunk transfers of this thread may still be on their way
   int* smap = reinterpret_cast<int*>(win + 1536);  // [TB] plane / output row of every board of this tile
   tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
   conv_in_f32(p, planes, smap, act, win, R, tid);
