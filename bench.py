@@ -138,6 +138,63 @@ def cpu_baseline(game_name, S, B, sbt0, weights, seconds, procs):
     return out
 
 
+# ------------------------------------------------------------------ N > 1 without torchrun
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: start the N ranks ourselves (one child process per GPU,
+    the environment torchrun would give them), relay what they print, return the worst exit code.  This parent
+    never initialises the GPU (`device_count()` does not, on this image) and skips the CPU baseline."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("CARO_SHARE_GPU"):
+        print("[bench] --gpus %d but %d visible GPU(s); set CARO_SHARE_GPU=1 (+ CARO_DIST_BACKEND=gloo) to rehearse "
+              "on fewer" % (n, have), file=sys.stderr)
+        return 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n),
+               LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rcs = []
+    for p in procs:  # stdout / stderr are inherited: rank 0's JSON line lands on our stdout as it is
+        try:
+            rcs.append(p.wait(timeout=1500))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(124)
+    worst = max(rcs, key=abs) if rcs else 1
+    if worst:
+        print("[bench] rank exit codes: %s" % rcs, file=sys.stderr)
+    return worst
+
+
+def dist_record(world, device, value_local):
+    """what the collective layer really is in this run: backend, world size, each rank's device and own value"""
+    import socket
+    import torch.distributed as dist
+    mine = {"rank": int(os.environ.get("RANK", "0")), "device": str(device),
+            "device_name": torch.cuda.get_device_name(device), "pid": os.getpid(), "host": socket.gethostname(),
+            "value": value_local}
+    if world == 1:
+        return {"backend": None, "world_size": 1, "ranks": [mine]}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, mine)
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+            "collectives": "RCCL over xGMI" if dist.get_backend() == "nccl" else "gloo (rehearsal, host memory)",
+            "ranks": ranks}
+
+
 # ------------------------------------------------------------------ one timed configuration
 class Leg:
     """One BASELINE.json configuration: engine + nets + the move loop."""
@@ -266,7 +323,9 @@ class Leg:
         tmax = torch.tensor([dt], dtype=torch.float64, device=self.device)
         parallel.allreduce_sum(tot)
         parallel.allreduce_max(tmax)
-        return self._report(steps, warmup, float(tmax.item()), [float(x) for x in tot.tolist()], delta, prof)
+        rep = self._report(steps, warmup, float(tmax.item()), [float(x) for x in tot.tolist()], delta, prof)
+        rep["value_local"] = delta["expansions"] / dt  # this rank's own rate on its own clock
+        return rep
 
     def _report(self, steps, warmup, dt, tot, delta, prof):
         args, game, G, S, B = self.args, self.game, self.G, self.S, self.B
@@ -341,6 +400,7 @@ class Leg:
                                       % (self.world, args.gather_every)},
             "per_gpu": exp_all / dt / self.world,
             "sims_per_s": sims_all / dt, "plies_per_s": plies_all / dt, "games_per_s": fin_all / dt,
+            "games_finished": int(fin_all), "live_nodes": self.live_nodes(),
             "net_rows_per_s": exp_all / dt, "mean_depth": levels_all / max(1.0, sims_all),
             "expansions_per_sim": exp_all / max(1.0, sims_all),
             "algorithmic_GBps": (levels_all * bytes_per_level + exp_all * bytes_per_exp) / dt / 1e9,
@@ -350,6 +410,29 @@ class Leg:
             "idle_frac": (1.0 - kernel_us / 1e3 / ms_per_step) if kernel_us else None,
             "roofline": roofline, "roofline_tree": roofline_tree,
         }
+
+    def live_nodes(self):
+        """nodes held per tree right now (after eviction, if on): mean / max over the games"""
+        if self.n_streams > 1:
+            return None
+        ts = self.eng.tree_live()
+        return {"mean": float(ts.mean()), "max": int(ts.max()), "cap": int(self.eng.cfg.node_cap)}
+
+    def sustained(self, moves):
+        """`moves` further moves of the same engine, finished games recycled: steady-state rate on its own clock"""
+        self.barrier()
+        c0 = self.eng.counters()
+        t0 = time.perf_counter()
+        for i in range(moves):
+            self.one_step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        c1 = self.eng.counters()
+        d = {k: c1[k] - c0[k] for k in c1}
+        return {"moves": moves, "seconds": dt, "value": d["expansions"] / dt, "unit": "node-expansions/s",
+                "ms_per_step": dt * 1e3 / moves, "games_finished": d["finished"], "games_per_s": d["finished"] / dt,
+                "plies": d["plies"], "overflows": d["overflows"], "mean_depth": d["levels"] / max(1, d["sims"]),
+                "note": "continues the headline engine after the timed steps; not part of `value`"}
 
     def close(self):
         self.eng.close()
@@ -388,7 +471,16 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the kernels")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the config4 (15x15) / config5 (arena) legs that follow the headline loop at N = 1")
+    ap.add_argument("--sustained-moves", type=int, default=200,
+                    help="N = 1 headline: moves of the `sustained` sub-record that follows the timed loop (0 = skip)")
+    ap.add_argument("--config4-warmup", type=int, default=40,
+                    help="moves played at full size before config4's timed moves (mid-game measurement)")
+    ap.add_argument("--config4-steps", type=int, default=8)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: become the launcher (nothing in this process has touched the GPU yet)
+        sys.exit(self_launch(args.gpus))
 
     from caro_ai_amd import parallel
 
@@ -402,7 +494,11 @@ def main():
         cpu_line = cpu_baseline(args.game, args.searches, args.batch, 10, w, args.cpu_seconds, procs)
 
     rank, local_rank, world = parallel.init()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        print("[bench] --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or run "
+              "`python bench.py --gpus %d` with WORLD_SIZE unset (it starts the ranks itself)"
+              % (args.gpus, world, args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
     # one rank per GPU; CARO_SHARE_GPU=1 maps every rank to cuda:0 (rehearsal of the N > 1 path on a 1-GPU box)
     device = torch.device("cuda", 0 if os.environ.get("CARO_SHARE_GPU") else local_rank)
     torch.cuda.set_device(device)
@@ -410,13 +506,22 @@ def main():
     leg = Leg(args, args.game, args.games, args.searches, args.batch, args.arena, rank, world, device,
               evict=args.evict, node_cap=args.node_cap)
     res = leg.run(args.steps, args.warmup, profile=not args.no_profile)
+    dist_rec = dist_record(world, device, res.pop("value_local"))
+    sustained = None
+    if world == 1 and headline and args.sustained_moves > 0:
+        # the timed region above is ~0.1 s; the same engine keeps playing: a steady-state figure with finished games
+        # recycled all along (its own clock, not part of `value`)
+        sustained = leg.sustained(args.sustained_moves)
     leg.close()
 
-    extras = {}
+    extras, extras_rc = {}, 0
     if world == 1 and headline and not args.no_extra_configs and args.net in NET_KERNEL and args.streams == 1:
-        # BASELINE.json configs 5 and 4 at full size, a few moves each (parity of both is tests/ business)
+        # BASELINE.json configs 5 and 4 at full size (parity of both is tests/ business).  config 4 is measured in
+        # MID-GAME: --config4-warmup moves at full size first, so that trees are deep, eviction has work to do and
+        # games finish inside the timed moves.
         for key, spec, st, wu in (("config5", dict(game_name="c4", G=512, S=100, B=8, arena=True), 6, 3),
-                                  ("config4", dict(game_name="gomoku15", G=1024, S=50, B=8, arena=False), 2, 1)):
+                                  ("config4", dict(game_name="gomoku15", G=1024, S=50, B=8, arena=False),
+                                   args.config4_steps, args.config4_warmup)):
             try:
                 x = Leg(args, rank=rank, world=world, device=device, **spec)
                 r = x.run(st, wu, profile=not args.no_profile, label=key)
@@ -424,10 +529,14 @@ def main():
                 del x
                 torch.cuda.empty_cache()
                 extras[key] = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "data",
-                                                 "sims_per_s", "games_per_s", "mean_depth", "overflows", "evict",
+                                                 "sims_per_s", "games_per_s", "games_finished", "mean_depth",
+                                                 "expansions_per_sim", "overflows", "evict", "live_nodes",
                                                  "kernel_ms_per_step", "roofline", "roofline_tree")}
-            except Exception as e:  # the headline line must survive a failing side leg
+            except Exception as e:  # the headline line survives a failing side leg, but says so: extras_rc != 0
+                import traceback
+                traceback.print_exc()
                 extras[key] = {"error": repr(e)}
+                extras_rc = 1
 
     if rank == 0:
         out = {"metric": "self-play MCTS node-expansions/sec/GPU (Connect4, 200 sims/move); 1->8 GPU scaling"
@@ -437,9 +546,12 @@ def main():
                "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.net != "hip3x" else "f32 (3x3 conv products as 3-way split bf16, f32 accumulate)"}
         out.update({k: v for k, v in res.items() if k not in out})
+        out["dist"] = dist_rec
+        out["sustained"] = sustained
         out["cpu_baseline"] = cpu_line
         out.update(extras)
-        print(json.dumps(out))
+        out["extras_rc"] = extras_rc
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

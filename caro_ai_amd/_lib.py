@@ -87,6 +87,7 @@ _SIGNATURES = {
     "caro_profile_begin": (C.c_int, [_P, C.c_int, _P]),
     "caro_profile_end": (None, [_P, C.c_int, _P]),
     "caro_tree_sizes": (C.c_int, [_P, _P, _P]),
+    "caro_tree_live": (C.c_int, [_P, _P, _P]),
     "caro_lookup_nodes": (C.c_int, [_P, C.c_int64] + [_P] * 10),
     "caro_get_roots": (C.c_int, [_P] * 6),
     "caro_poke_nodes": (C.c_int, [_P, C.c_int64] + [_P] * 9),

@@ -1300,6 +1300,11 @@ __global__ void k_tree_sizes(View v, int32_t* out) {
   if (i < v.G * v.n_stores) out[i] = v.n_created[i];
 }
 
+__global__ void k_tree_live(View v, int32_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < v.G * v.n_stores) out[i] = v.n_nodes[i];
+}
+
 template <class GEO>
 __global__ void k_get_roots(View v, uint64_t* keys, int32_t* players, int32_t* ply, uint64_t* uid) {
   constexpr int KW = GEO::KW;
@@ -2006,6 +2011,14 @@ int caro_tree_sizes(caro_engine* h, int32_t* out, void* stream) {
   if (!h || !out) return fail(CARO_E_INVAL, "null argument");
   const int T = h->v.G * h->v.n_stores;
   hipLaunchKernelGGL(k_tree_sizes, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->v, out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int caro_tree_live(caro_engine* h, int32_t* out, void* stream) {
+  if (!h || !out) return fail(CARO_E_INVAL, "null argument");
+  const int T = h->v.G * h->v.n_stores;
+  hipLaunchKernelGGL(k_tree_live, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->v, out);
   HIPCHK(hipGetLastError());
   return 0;
 }

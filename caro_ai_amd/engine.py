@@ -256,6 +256,12 @@ class SelfPlayEngine:
         _lib.check(self.L.caro_tree_sizes(self.h, _ptr(out), self._stream()))
         return out.cpu().numpy().reshape(self.G, self.n_stores)
 
+    def tree_live(self):
+        """nodes each tree holds now (what node_cap bounds; tree_sizes() = nodes ever created = len(MCTS))"""
+        out = torch.empty(self.G * self.n_stores, dtype=torch.int32, device=self.device)
+        _lib.check(self.L.caro_tree_live(self.h, _ptr(out), self._stream()))
+        return out.cpu().numpy().reshape(self.G, self.n_stores)
+
     def roots(self):
         keys = torch.empty((self.G, self.KW), dtype=torch.int64, device=self.device)
         pl = torch.empty(self.G, dtype=torch.int32, device=self.device)

@@ -7,6 +7,15 @@ This is the single-game, latency-shaped entry (play.py, play_session,
 train.evaluate call it once per move); throughput comes from running many
 games through `caro_ai_amd.engine.SelfPlayEngine` / `lib.utils.play_games`.
 
+Two ways through `search_batch`:
+  fused      `net` is this package's `lib.model.Net` in eval mode and `device` is a GPU: the net runs as the
+             fused HIP kernel (`HipNet`, cached per net and weight version), the Dirichlet rows of the WHOLE
+             search_batch are drawn from numpy up front -- in the reference's order and number -- and ONE
+             `caro_search_batch` call enqueues every minibatch (k_tree -> net kernel); the host synchronises once.
+  step-wise  any other evaluator (a foreign module, a subclass with its own forward, a net in train mode, a net
+             on the CPU): per minibatch `caro_select` -> leaf count -> `net(planes)` -> `caro_expand_backup`,
+             which is the reference's own sequence (lib/mcts.py:248-287).
+
 Randomness follows the reference exactly: one `np.random.dirichlet([ALPHA]*A)`
 draw per descent that starts at an expanded root (lib/mcts.py:131-132,56-57),
 taken from numpy's global state in the same order and handed to the kernel as
@@ -52,6 +61,7 @@ class MCTS:
         self._tree_device = tree_device
         self._node_cap = node_cap
         self._eng = None
+        self._hip = {}  # id(net) -> (weights version, HipNet)
 
     # ------------------------------------------------------------ engine plumbing
     def _engine(self) -> SelfPlayEngine:
@@ -123,9 +133,63 @@ class MCTS:
         val = float(value.item()) if status == 1 else None
         return val, self.game.from_key(leaf.cpu().numpy().view(np.uint64)), leaf_player, states, actions
 
+    # ------------------------------------------------------------ fused path (one C call per search_batch)
+    @staticmethod
+    def _weights_version(net):
+        """changes whenever a parameter or batch-norm buffer is written in place (optimizer step, load_state_dict)
+        or replaced (`.to()`): tensor version counters + storage addresses"""
+        return tuple((t._version, t.data_ptr()) for t in net.state_dict(keep_vars=True).values())
+
+    def _fused_net(self, net, device):
+        """the HipNet of `net` if this call may take the fused path, else None"""
+        from caro_ai_amd.lib.model import Net
+        if not isinstance(net, Net) or type(net).forward is not Net.forward or net.training:
+            return None
+        if not str(device).startswith("cuda"):
+            return None
+        eng = self._engine()
+        if torch.device(device).index not in (None, eng.device.index):
+            return None
+        ver = self._weights_version(net)
+        hit = self._hip.get(id(net))
+        if hit is None or hit[0] != ver:
+            from caro_ai_amd.net_hip import HipNet
+            if hit is not None:
+                hit[1].close()
+            hit = (ver, HipNet(net, str(eng.device)))
+            self._hip[id(net)] = hit
+        return hit[1]
+
+    def _noise_table(self, count, batch_size, state_int):
+        """The Dirichlet rows a whole search_batch consumes, drawn from numpy's global stream exactly as the
+        reference draws them: one row per descent that starts at an EXPANDED root (lib/mcts.py:123,131-132), i.e.
+        none for a first minibatch that finds the root unexpanded (its descents return the root itself, Q6) and
+        `batch_size` for every other minibatch.  `dirichlet(alpha, size=n)` fills its rows one after another from
+        the same gamma stream, so it equals n single calls (tests/test_cpu_product.py checks that)."""
+        A = self.game.action_space
+        table = np.zeros((count, 1, batch_size, A))
+        skip = 1 if self.is_leaf(state_int) else 0
+        n = (count - skip) * batch_size
+        if n > 0:
+            table[skip:] = np.random.dirichlet([cfg.ALPHA] * A, size=n).reshape(count - skip, 1, batch_size, A)
+        return table
+
     def search_batch(self, count: int, batch_size: int, state_int: StateInt, player: int, net, device: str = "cpu"):
-        for _ in range(count):
-            self.search_minibatch(batch_size, state_int, player, net, device)
+        hip = self._fused_net(net, device) if count > 0 else None
+        if hip is None:
+            for _ in range(count):
+                self.search_minibatch(batch_size, state_int, player, net, device)
+            return
+        eng = self._engine()
+        assert batch_size <= eng.max_batch, "mcts_batch_size above %d is not supported for this game" % eng.max_batch
+        noise = self._noise_table(count, batch_size, state_int)
+        eng.set_roots([state_int], [player])
+        nz = torch.from_numpy(noise).to(eng.device)
+        _lib.check(eng.L.caro_search_batch(eng.h, hip.h, None, count, batch_size, C.c_void_p(nz.data_ptr()),
+                                           C.c_void_p(eng.planes.data_ptr()), C.c_void_p(eng.leaf_keys.data_ptr()),
+                                           C.c_void_p(eng._probs.data_ptr()), C.c_void_p(eng._values.data_ptr()),
+                                           eng._stream()))
+        self._check_overflow()  # reads the counters: the one host synchronisation of the search
 
     def search_minibatch(self, batch_size: int, state_int: StateInt, player: int, net, device: str = "cpu") -> None:
         eng = self._engine()

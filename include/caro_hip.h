@@ -182,6 +182,9 @@ int caro_live_games(caro_engine* h, int32_t* live, void* stream);
 /* ---- inspection (tests, MCTS shim: the four public dicts of lib/mcts.py:29-36) ---- */
 /* len(MCTS) per tree: out_dev i32[G*n_stores] */
 int caro_tree_sizes(caro_engine* h, int32_t* out_dev, void* stream);
+/* nodes a tree HOLDS right now (= len(MCTS) without eviction; with caro_config.evict what survived the last
+ * k_evict plus what the current move added -- the figure node_cap bounds): out_dev i32[G*n_stores] */
+int caro_tree_live(caro_engine* h, int32_t* out_dev, void* stream);
 /* look up M (game, store, key) triples: found_dev i32[M]; N i32[M,A]; W,Q,P f32[M,A]; strong i32[M,A]
  * (strong = W has absorbed a float32 net value; 0 = still an exact Python float) */
 int caro_lookup_nodes(caro_engine* h, int64_t M, const int32_t* game_dev, const int32_t* store_dev,

@@ -145,3 +145,18 @@ def test_synth_net_twins_agree():
             o.L.oracle_synth_eval(o.h, salt, 17, planes.ctypes.data, Pc.ctypes.data, vc.ctypes.data)
             assert np.array_equal(Ps, Pc) and np.array_equal(vs, vc)
             assert (salt == 0) == np.array_equal(Ps, P)
+
+
+def test_batched_dirichlet_consumes_numpy_stream_like_single_calls():
+    """lib/mcts.py `_noise_table` draws all rows of a search_batch with ONE np.random.dirichlet(alpha, size=n);
+    the reference draws them one call per descent (lib/mcts.py:56).  Same global stream, same rows, same state
+    afterwards -- for every action count in use."""
+    import numpy as np
+    for A in (7, 9, 225):
+        np.random.seed(1234 + A)
+        one = np.stack([np.random.dirichlet([0.3] * A) for _ in range(40)])
+        after_one = np.random.random()
+        np.random.seed(1234 + A)
+        many = np.random.dirichlet([0.3] * A, size=40)
+        after_many = np.random.random()
+        assert np.array_equal(one.view(np.uint64), many.view(np.uint64)) and after_one == after_many

@@ -114,12 +114,13 @@ def test_rules_kernels_vs_reference(name):
 
 
 # ------------------------------------------------------------------ engine vs recorded reference games
-def _play_and_check_golden(d, g, form, explicit_noise=False):
+def _play_and_check_golden(d, g, form, explicit_noise=False, **engine_kw):
     from oracle.oracle import noise_row
     game = _game_of(d)
     A = game.action_space
+    engine_kw.setdefault("node_cap", g["searches"] * g["batch"] * g["plies"] + 64)
     eng = _engine(game, 1, [_synth(game, form)], n_stores=g["n_stores"], max_batch=g["batch"], steps_before_tau_0=g["steps_before_tau_0"],
-                  seed=g["seed"], uid_base=g["uid"], node_cap=g["searches"] * g["batch"] * g["plies"] + 64)
+                  seed=g["seed"], uid_base=g["uid"], **engine_kw)
     eng.reset([g["first_player"]])
     S, B = g["searches"], g["batch"]
     for ply in range(g["plies"]):
@@ -171,6 +172,19 @@ def test_engine_replays_reference_games(name, form):
     d = load_golden(name)
     for g in d["games"]:
         _play_and_check_golden(d, g, form)
+
+
+def test_config4_table_net_games_400_sims_with_eviction(form):
+    """BASELINE config 4's per-game settings -- TicTacToe(15, 5), 50 x 8 = 400 sims/move, tau = 1 for 10 plies --
+    with the engine as config 4 runs it: eviction on, 4 096 live nodes per tree.  Whole games recorded from the
+    REFERENCE (65-75 plies, 6-8 k nodes created; tests/golden/make_golden_r3.py): root N / W / Q / dtype flag,
+    nodes ever created, pi, moves, z, result -- all bit exact (ref lib/game/tictactoe/tictactoe.py:210-235,
+    lib/utils.py:25-108)."""
+    d = load_golden("synth_mnk15_400.json.gz")
+    assert len(d["games"]) >= 2
+    for g in d["games"]:
+        assert (g["searches"], g["batch"]) == (50, 8) and g["plies"] > 30
+        _play_and_check_golden(d, g, form, node_cap=4096, evict=True)
 
 
 def test_explicit_noise_table_path(form):
@@ -334,6 +348,65 @@ def test_full_size_1024_games_invariants(form):
             assert not won
         assert game.from_key(keys[gidx]) == s
     eng.close()
+
+
+def test_config4_full_size_whole_games_with_eviction():
+    """BASELINE config 4 at its real size: 1024 concurrent 15 x 15 k = 5 games, 50 x 8 sims/move, eviction with a
+    4 096-node cap, slots recycled until >= 1024 games have finished (table net on the device: the launches
+    are bench.py's, only the evaluator is the exact one).  Size-independent properties -- nothing overflows at
+    any point of a whole game, the sims identity holds, every finished game is a legal game -- and a sample of
+    the finished games equals the oracle's game of the same uid ply by ply (states, pi, z, result, steps)."""
+    d = {"kind": "mnk", "n": 15, "k": 5}
+    game = _game_of(d)
+    G, S, B, seed = 1024, 50, 8, 9
+    eng = _engine(game, G, [_synth(game, "fused")], max_batch=B, steps_before_tau_0=10, seed=seed, uid_base=0,
+                  node_cap=4096, evict=True, searches_hint=S)
+    kept, games, moves, finished = {}, [], 0, 0
+    live_max = 0
+    while finished < 1024:
+        eng.search(S, B)
+        if moves % 8 == 0:
+            live_max = max(live_max, int(eng.tree_live().max()))  # before the move's eviction: the peak
+        eng.step()
+        moves += 1
+        dr = eng.drain(recycle=True)
+        ng = dr["games"].shape[0]
+        if ng:
+            gr = dr["games"].cpu().numpy()
+            finished += ng
+            games.append(gr)
+            off = 0
+            z, st = dr["z"].cpu().numpy(), None
+            for uid, first, result, steps in gr.tolist():
+                n = steps + 1
+                # z alternates back from the last mover: +1 / -1 for a win, all 0 for a draw (utils.py:101-106)
+                zz = z[off:off + n]
+                assert zz[0] == (1 if result != 0 else 0) and (np.abs(zz) == abs(int(zz[0]))).all()
+                if uid % 64 == 0:  # first and later generations of a slot alike
+                    st = dr["states"].cpu().numpy() if st is None else st
+                    kept[uid] = (first, result, steps, st[off:off + n].copy(),
+                                 dr["pi"][off:off + n].cpu().numpy(), zz.copy())
+                off += n
+            assert off == z.shape[0]
+        assert moves < 600
+    c = eng.counters()
+    eng.close()
+    games = np.concatenate(games)
+    assert c["overflows"] == 0 and live_max <= 4096
+    assert c["sims"] == moves * G * S * B
+    assert c["expansions"] + c["terminals"] + c["dropped"] == c["sims"]
+    assert c["finished"] == len(games) >= 1024 and len(set(games[:, 0].tolist())) == len(games)
+    assert (games[:, 3] >= 8).all() and (games[:, 3] < 225).all()  # k = 5: no game ends before the 9th ply
+    print("config 4 full size: %d moves, %d games finished, peak live nodes %d, sims %d, expansions %d"
+          % (moves, len(games), live_max, c["sims"], c["expansions"]))
+    assert len(kept) >= 12
+    ref = _oracle_games(d, kept.keys(), seed, 10, S, B, 1)
+    for uid, (first, result, steps, st, pi, z) in kept.items():
+        r = ref[uid]
+        assert (first, result, steps) == (r["first"], r["result"], r["steps"]), uid
+        assert game.from_keys(st.view(np.uint64)) == r["states"][::-1], uid
+        assert np.array_equal(pi, r["pi"][::-1]), uid
+        assert z.tolist() == r["z"][::-1].tolist(), uid
 
 
 # ------------------------------------------------------------------ node eviction is result-neutral

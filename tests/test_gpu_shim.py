@@ -136,6 +136,94 @@ def test_play_game_numpy_stream_matches_oracle():
     assert o.noise_pos() == len(rec_noise)
 
 
+def test_play_game_fused_path_numpy_stream_matches_oracle():
+    """The low-latency form of the single-game API: a real `Net` in eval mode on the GPU makes
+    `MCTS.search_batch` take ONE `caro_search_batch` call per move (k_tree -> fused net kernel) with the Dirichlet
+    rows of the whole search pre-drawn from numpy.  The draws must be the reference's in number and order
+    (none for a minibatch that meets an unexpanded root, lib/mcts.py:123,131): replaying the recorded draws
+    through the oracle -- fed by the same HIP net on the same leaf boards -- gives the same game bit for bit."""
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.mcts import MCTS
+    from caro_ai_amd.lib.utils import play_game
+    from caro_ai_amd.net_hip import HipNet
+    from oracle.oracle import Oracle
+    g = ConnectFour()
+    net, = _real_nets(g, ["best_026_12000.dat"])
+    rec_noise, rec_u = [], []
+    real_dir, real_choice = np.random.dirichlet, np.random.choice
+
+    def dir_(alpha, size=None):
+        r = real_dir(alpha, size)
+        rec_noise.extend(np.atleast_2d(r))
+        return r
+
+    def choice_(a, p=None):
+        if p is None:
+            return real_choice(a)
+        u = np.random.random()
+        rec_u.append(u)
+        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+        cdf /= cdf[-1]
+        return int(np.searchsorted(cdf, u, side="right"))
+
+    stores = [MCTS(g), MCTS(g)]
+    np.random.dirichlet, np.random.choice = dir_, choice_
+    try:
+        np.random.seed(321)
+        rb = collections.deque()
+        r, steps = play_game(g, stores, rb, net, net, 4, 10, 8, net1_plays_first=False, device="cuda:0")
+    finally:
+        np.random.dirichlet, np.random.choice = real_dir, real_choice
+    assert all(len(t._hip) == 1 for t in stores), "the fused path was not taken"
+    hip = HipNet(net, "cuda:0")
+
+    def fn(planes, states, players):
+        P, v = hip(torch.from_numpy(np.ascontiguousarray(planes)).to("cuda:0"))
+        return P.cpu().numpy(), v.cpu().numpy()
+
+    o = Oracle(Oracle.C4, n_stores=2)
+    o.set_net(0, fn)
+    o.set_net(1, fn)
+    o.set_noise_table(np.array(rec_noise))
+    o.set_uniform_table(np.array(rec_u))
+    ref = o.play_game(4, 10, 8, 1)
+    assert (r, steps) == (ref["result"], ref["steps"])
+    hist = list(rb)[::-1]
+    assert [h[0] for h in hist] == ref["states"]
+    assert [h[1] for h in hist] == ref["players"].tolist()
+    assert [h[3] for h in hist] == ref["z"].tolist()
+    assert np.array_equal(np.array([h[2] for h in hist]), ref["pi"])
+    assert o.noise_pos() == len(rec_noise)  # every pre-drawn row is one the reference would have drawn
+    assert sum(len(t) for t in stores) == o.store_len(0) + o.store_len(1)
+
+
+def test_fused_path_follows_weight_updates_and_falls_back():
+    """HipNet cache: rebuilt when the weights change in place; train-mode nets, CPU devices and subclasses with
+    their own forward keep the step-wise (reference-sequence) path"""
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.mcts import MCTS
+    g = ConnectFour()
+    net, = _real_nets(g, ["best_026_12000.dat"])
+    t = MCTS(g)
+    s = g.initial_state
+    np.random.seed(1)
+    t.search_batch(3, 8, s, 0, net, device="cuda:0")
+    first = t._hip[id(net)][1]
+    t.search_batch(3, 8, s, 0, net, device="cuda:0")
+    assert t._hip[id(net)][1] is first
+    p_before = t.probs[s].copy()
+    with torch.no_grad():
+        net.policy[0].bias.add_(torch.linspace(-1, 1, 7, device="cuda:0"))
+    t.clear()
+    t.search_batch(3, 8, s, 0, net, device="cuda:0")
+    assert t._hip[id(net)][1] is not first
+    assert np.abs(t.probs[s] - p_before).max() > 1e-3
+    t2 = MCTS(g)
+    assert t2._fused_net(net.train(), "cuda:0") is None
+    assert t2._fused_net(net.eval(), "cpu") is None
+    assert t2._fused_net(_synth_module(g).eval(), "cuda:0") is None
+
+
 def test_play_games_fills_replay_buffer_like_the_reference():
     from caro_ai_amd.lib.game.tictactoe import TicTacToe
     from caro_ai_amd.lib.model import Net
@@ -334,6 +422,79 @@ def test_real_weights_gpu_net_arena_800_sims(inference):
     assert total >= 100 and same / total >= 0.99 and max_dpi <= 0.15
     # tau = 0: the move is the argmax of N, so a ply with the reference's N plays the reference's move
     assert followed >= 6
+
+
+# ------------------------------------------------------------------ BASELINE config 4: 15 x 15, k = 5, 50 x 8 sims/move
+def _seeded_net_15(d):
+    """the repo's own Net under the committed seed -- the state_dict the reference's Net was
+    loaded with when tests/golden/make_golden_r3.py recorded the games (the fixture's SHA-256 proves it)"""
+    from tests.test_oracle_golden import seeded_net_15, state_dict_sha256
+    net = seeded_net_15(d["weights_seed"])
+    assert state_dict_sha256(net.state_dict()) == d["weights_sha256"]
+    return net
+
+
+def test_config4_conv_net_exact_with_reference_net_arithmetic():
+    """G3 at config 4's per-game settings, exact: the reference's TicTacToe(15, 5) games at 50 x 8 sims/move with
+    the conv net (ref lib/game/tictactoe/tictactoe.py:210-235, lib/utils.py:25-108) against the HIP tree walk --
+    eviction on, 4 096 live nodes per tree, as config 4 runs -- with the reference's net arithmetic (the same torch
+    CPU forward on the same leaf batches): root N every ply, pi (float64), z, result, steps bit for bit."""
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    torch.set_num_threads(1)
+    d = load_golden("real_mnk15.json.gz")
+    g = TicTacToe(d["n"], d["k"])
+    net = _seeded_net_15(d)
+    for gm in d["games"][:3]:
+        assert (gm["searches"], gm["batch"]) == (50, 8)
+        eng = SelfPlayEngine(g, 1, evaluators=[_cpu_torch_evaluator(net)], n_stores=gm["n_stores"],
+                             max_batch=gm["batch"], steps_before_tau_0=gm["steps_before_tau_0"], seed=gm["seed"],
+                             uid_base=gm["uid"], node_cap=4096, evict=True)
+        eng.reset([gm["first_player"]])
+        for ply in range(gm["plies"]):
+            assert str(g.from_key(eng.roots()[0][0])) == gm["states"][ply]
+            eng.search(gm["searches"], gm["batch"])
+            pi, counts = eng.policy()
+            assert counts[0].cpu().tolist() == gm["trace"][ply]["N"], (gm["uid"], ply)
+            assert pi[0].cpu().numpy().tolist() == gm["pi"][ply]
+            assert eng.tree_sizes()[0][0] == gm["trace"][ply]["nodes"]  # len(MCTS): nodes ever created
+            assert eng.tree_live()[0][0] <= 4096
+            eng.step()
+        dr = eng.drain(recycle=False)
+        uid, first, result, steps = dr["games"][0].cpu().tolist()
+        assert (result, steps) == (gm["result"], gm["steps"])
+        assert dr["z"].cpu().tolist() == gm["z"][::-1]
+        assert eng.counters()["overflows"] == 0
+        eng.close()
+
+
+@pytest.mark.parametrize("inference", ["hipw", "hip"])
+def test_config4_conv_net_on_gpu_vs_reference_games(inference):
+    """The same recorded games against the engine with the net ON THE GPU (fused HIP kernel, large-board tiles),
+    all games in one engine, eviction + 4 096-node cap.  Stated tolerance as for Connect4: >= 99 %
+    of the compared plies carry the reference's root visit vector, |d pi| <= 0.15 elsewhere, and a game that
+    matched at every ply ends with the recorded result and step count."""
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    d = load_golden("real_mnk15.json.gz")
+    g = TicTacToe(d["n"], d["k"])
+    net = _seeded_net_15(d).to("cuda:0")
+    games = d["games"]
+    gm0 = games[0]
+    G = len(games)
+    assert [gm["uid"] for gm in games] == list(range(gm0["uid"], gm0["uid"] + G))
+    eng = SelfPlayEngine(g, G, net1=net, max_batch=gm0["batch"], inference=inference, seed=gm0["seed"],
+                         steps_before_tau_0=gm0["steps_before_tau_0"], uid_base=gm0["uid"], first_player_mode=2,
+                         node_cap=4096, evict=True, searches_hint=gm0["searches"])
+    total, same, max_dpi, followed, log = _compare_with_recorded_games(d, eng, g, max(gm["plies"] for gm in games))
+    assert eng.counters()["overflows"] == 0
+    eng.close()
+    print("\n".join(log))
+    print("%s 15x15: identical root-N plies %d / %d (%.2f %%), max |dpi| elsewhere %.4f, %d / %d games followed to "
+          "the end" % (inference, same, total, 100.0 * same / total, max_dpi, followed, G))
+    assert total >= 200
+    assert same / total >= 0.99 and max_dpi <= 0.15
+    assert followed >= G - 2
 
 
 def test_play_cli_round_robin(capsys):

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Latency of one bot move of the single-game API: `Session.move_bot` =
+`MCTS.search_batch(BOT_MCTS_SEARCHES=40, BOT_MCTS_BATCH_SIZE=8)` + the tau = 0 policy + the move
+(reference lib/play_session.py:28-36), Connect4, shipped best_026_12000.dat.
+
+    python tools/measure_move_latency.py --reference     # build container: the reference's own Session on the CPU
+    python tools/measure_move_latency.py                 # GPU box: this package's Session (fused path)
+    python tools/measure_move_latency.py --stepwise      # GPU box: the step-wise path (net in train mode keeps it)
+
+A game is bot vs a seeded random "human"; every bot move is timed (wall clock around move_bot, which ends with
+host-visible results), games are repeated until --moves bot moves were taken.  One JSON line on stdout.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+WEIGHTS = os.path.join(ROOT, "tests", "golden", "weights", "best_026_12000.dat")
+
+
+def run(Session, game, n_moves, seed, after=None, **kw):
+    rng = np.random.default_rng(seed)
+    np.random.seed(seed)
+    times, nodes = [], []
+    while len(times) < n_moves:
+        s = Session(game, WEIGHTS, True, **kw)
+        if after is not None:
+            after(s)
+        while len(times) < n_moves:
+            legal = game.possible_moves(s.state)
+            if not legal or s.move_player(int(legal[int(rng.integers(len(legal)))])):
+                break
+            if not game.possible_moves(s.state):
+                break
+            n0 = len(s.mcts_store)
+            t0 = time.perf_counter()
+            won = s.move_bot()
+            times.append(time.perf_counter() - t0)
+            nodes.append(len(s.mcts_store) - n0)
+            if won:
+                break
+    t = np.array(times) * 1e3
+    return {"bot_moves": len(times), "ms_mean": float(t.mean()), "ms_median": float(np.median(t)),
+            "ms_p90": float(np.percentile(t, 90)), "ms_min": float(t.min()), "ms_max": float(t.max()),
+            "ms_first_move": float(t[0]), "new_nodes_per_move": float(np.mean(nodes)), "sims_per_move": 40 * 8}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", action="store_true")
+    ap.add_argument("--stepwise", action="store_true")
+    ap.add_argument("--moves", type=int, default=60)
+    ap.add_argument("--threads", type=int, default=1)
+    args = ap.parse_args()
+    import torch
+    torch.set_num_threads(args.threads)
+    if args.reference:
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, "/root/reference")
+        from lib.game.connect_four.connect_four import ConnectFour
+        from lib.play_session import Session
+        out = run(Session, ConnectFour(), args.moves, 7)
+        out.update(what="reference lib/play_session.py Session.move_bot, CPU, torch threads = %d (the reference "
+                        "leaves its net in train mode: batch-norm over the <= 8 leaf rows)" % args.threads,
+                   host="build container: 8 vCPU Intel Xeon @ 2.10 GHz")
+    else:
+        sys.path.insert(0, ROOT)
+        from caro_ai_amd.lib.game.connect_four import ConnectFour
+        from caro_ai_amd.lib.play_session import Session
+        game = ConnectFour()
+        after = (lambda s: s.model.train()) if args.stepwise else None
+        run(Session, game, 6, 3, after=after)  # code objects, allocator, first-use costs
+        out = run(Session, game, args.moves, 7, after=after)
+        out.update(what="caro_ai_amd.lib.play_session.Session.move_bot on cuda:0, %s"
+                        % ("step-wise path (caro_select -> torch module -> caro_expand_backup per minibatch)"
+                           if args.stepwise else "fused path (one caro_search_batch per move: k_tree -> HIP net kernel)"),
+                   device=torch.cuda.get_device_name(0))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
