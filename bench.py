@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
 MFMA_BF16_PEAK_TFS = 2500.0 # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 PMC_FILE = os.path.join("profiles", "pmc_r02.json")
-CPU_RATIO_FILE = os.path.join("profiles", "cpu_ratio_r02.json")
+CPU_RATIO_FILE = os.path.join("profiles", "cpu_ratio_r03.json")
 NET_KERNEL = {"hip": "k_net_forward", "hipw": "k_net_forward_w", "hip3x": "k_net_forward_3x"}
 
 

@@ -36,6 +36,7 @@
 #include "../../include/caro_hip.h"
 #include "../../include/caro_noise.h"
 #include "caro_rules.h"
+#include "caro_variants.h"
 
 namespace caro {
 
@@ -96,18 +97,6 @@ struct View {
   int32_t* dr_sel;
   int64_t* dr_tot;  // [2] tuples, games
 };
-
-template <class R_, int LPD_, int APL_>
-struct Geo {
-  using R = R_;
-  static constexpr int LPD = LPD_, APL = APL_, AP = LPD_ * APL_, KW = R_::KW;
-};
-using GeoC4 = Geo<C4Rules, 8, 1>;
-using GeoM16 = Geo<MnkRules<1>, 16, 1>;
-using GeoM32 = Geo<MnkRules<1>, 32, 1>;
-using GeoM64 = Geo<MnkRules<1>, 64, 1>;
-using GeoM128 = Geo<MnkRules<2>, 64, 2>;
-using GeoM256 = Geo<MnkRules<4>, 64, 4>;
 
 // ------------------------------------------------------------------ device helpers
 template <class R>
@@ -1388,68 +1377,6 @@ static int fail(int code, const std::string& msg) {
       return fail(CARO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                     \
   } while (0)
 
-enum Variant { V_C4, V_M16, V_M32, V_M64, V_M128, V_M256, V_BAD };
-
-static Variant pick_variant(int kind, int n) {
-  if (kind == CARO_GAME_CONNECT4) return V_C4;
-  if (kind != CARO_GAME_MNK || n < 2 || n > 15) return V_BAD;
-  const int A = n * n;
-  if (A <= 16) return V_M16;
-  if (A <= 32) return V_M32;
-  if (A <= 64) return V_M64;
-  if (A <= 128) return V_M128;
-  return V_M256;
-}
-static int variant_kw(Variant v) {
-  switch (v) {
-    case V_C4: return 1;
-    case V_M16: case V_M32: case V_M64: return 2;
-    case V_M128: return 4;
-    case V_M256: return 8;
-    default: return 0;
-  }
-}
-static int variant_lpd(Variant v) {
-  switch (v) {
-    case V_C4: return 8;
-    case V_M16: return 16;
-    case V_M32: return 32;
-    default: return 64;
-  }
-}
-static int variant_ap(Variant v) {
-  switch (v) {
-    case V_C4: return 8;
-    case V_M16: return 16;
-    case V_M32: return 32;
-    case V_M64: return 64;
-    case V_M128: return 128;
-    case V_M256: return 256;
-    default: return 0;
-  }
-}
-static GameParams make_gp(int kind, int n, int k) {
-  GameParams gp;
-  gp.kind = kind;
-  if (kind == CARO_GAME_CONNECT4) {
-    gp.n = 0; gp.k = 4; gp.A = 7; gp.rows = 6; gp.cols = 7;
-  } else {
-    gp.n = n; gp.k = k; gp.A = n * n; gp.rows = n; gp.cols = n;
-  }
-  return gp;
-}
-
-#define DISPATCH(var, EXPR)                                          \
-  switch (var) {                                                     \
-    case V_C4: { using GEO = GeoC4; EXPR; } break;                   \
-    case V_M16: { using GEO = GeoM16; EXPR; } break;                 \
-    case V_M32: { using GEO = GeoM32; EXPR; } break;                 \
-    case V_M64: { using GEO = GeoM64; EXPR; } break;                 \
-    case V_M128: { using GEO = GeoM128; EXPR; } break;               \
-    case V_M256: { using GEO = GeoM256; EXPR; } break;               \
-    default: return fail(CARO_E_INVAL, "unsupported game geometry"); \
-  }
-
 struct caro_engine {
   caro_config cfg;
   Variant var;
@@ -1524,61 +1451,7 @@ const char* caro_last_error(void) { return g_err.c_str(); }
 void caro__set_error(const char* msg) { g_err = msg ? msg : ""; }  // for the other translation units
 int caro_version(void) { return 100; }
 
-int caro_key_words(int kind, int n) { return variant_kw(pick_variant(kind, n)); }
-int caro_action_space(int kind, int n) { return kind == CARO_GAME_CONNECT4 ? 7 : n * n; }
-int caro_obs_cells(int kind, int n) { return kind == CARO_GAME_CONNECT4 ? 42 : n * n; }
-
-// ---- host helpers (same rules header, host instantiation)
-#define HOST_DISPATCH(var, EXPR) DISPATCH(var, EXPR)
-
-int caro_host_initial(int kind, int n, int k, uint64_t* key) {
-  const Variant var = pick_variant(kind, n);
-  const GameParams gp = make_gp(kind, n, k);
-  HOST_DISPATCH(var, { auto b = GEO::R::initial(gp); for (int i = 0; i < GEO::KW; ++i) key[i] = b.w[i]; });
-  return 0;
-}
-int caro_host_move(int kind, int n, int k, uint64_t* key, int move, int player, int* won) {
-  const Variant var = pick_variant(kind, n);
-  const GameParams gp = make_gp(kind, n, k);
-  if (player != 0 && player != 1) return fail(CARO_E_INVAL, "player must be 0 or 1");
-  if (move < 0 || move >= gp.A) return fail(CARO_E_INVAL, "move out of range");
-  HOST_DISPATCH(var, {
-    typename GEO::R::Board b;
-    for (int i = 0; i < GEO::KW; ++i) b.w[i] = key[i];
-    if (kind == CARO_GAME_CONNECT4 && !GEO::R::legal(gp, b, move)) return fail(CARO_E_INVAL, "column is full");
-    *won = GEO::R::move(gp, b, move, player) ? 1 : 0;
-    for (int i = 0; i < GEO::KW; ++i) key[i] = b.w[i];
-  });
-  return 0;
-}
-int caro_host_legal(int kind, int n, int k, const uint64_t* key, uint8_t* legal) {
-  const Variant var = pick_variant(kind, n);
-  const GameParams gp = make_gp(kind, n, k);
-  HOST_DISPATCH(var, {
-    typename GEO::R::Board b;
-    for (int i = 0; i < GEO::KW; ++i) b.w[i] = key[i];
-    for (int a = 0; a < gp.A; ++a) legal[a] = GEO::R::legal(gp, b, a) ? 1 : 0;
-  });
-  return 0;
-}
-int caro_host_encode(int kind, int n, int k, const uint64_t* key, int who, float* planes) {
-  const Variant var = pick_variant(kind, n);
-  const GameParams gp = make_gp(kind, n, k);
-  const int HW = gp.rows * gp.cols;
-  HOST_DISPATCH(var, {
-    typename GEO::R::Board b;
-    for (int i = 0; i < GEO::KW; ++i) b.w[i] = key[i];
-    for (int i = 0; i < 2 * HW; ++i) planes[i] = GEO::R::plane(gp, b, who, i / HW, i % HW);
-  });
-  return 0;
-}
-int caro_host_noise_row(uint64_t seed, uint64_t uid, uint32_t ply, uint32_t sim, int A, double alpha, double* out) {
-  if (A < 1 || A > 256) return fail(CARO_E_INVAL, "A out of range");
-  double tmp[256];
-  caro_noise_row(seed, uid, ply, sim, A, alpha, out, tmp);
-  return 0;
-}
-double caro_host_move_uniform(uint64_t seed, uint64_t uid, uint32_t ply) { return caro_move_uniform(seed, uid, ply); }
+#include "caro_host.inc"
 
 // ---- batched rules
 int caro_rules_move_batch(int kind, int n, int k, int64_t M, uint64_t* keys, const int32_t* moves,

@@ -213,11 +213,11 @@ def test_fused_path_follows_weight_updates_and_falls_back():
     assert t._hip[id(net)][1] is first
     p_before = t.probs[s].copy()
     with torch.no_grad():
-        net.policy[0].bias.add_(torch.linspace(-1, 1, 7, device="cuda:0"))
+        net.policy[0].bias[0] += 100.0  # the shipped net puts ~1.0 on the centre column of the empty board
     t.clear()
     t.search_batch(3, 8, s, 0, net, device="cuda:0")
     assert t._hip[id(net)][1] is not first
-    assert np.abs(t.probs[s] - p_before).max() > 1e-3
+    assert p_before[0] < 0.01 and t.probs[s][0] > 0.99
     t2 = MCTS(g)
     assert t2._fused_net(net.train(), "cuda:0") is None
     assert t2._fused_net(net.eval(), "cpu") is None
