@@ -271,17 +271,13 @@ class Leg:
         self._warm = None
 
     def one_step(self):
-        if self.n_streams > 1:
-            d = self.eng.move(self.S, self.B)  # host-pipelined over the parts: drains the previous move of each part
-        else:
-            self.eng.search(self.S, self.B)
-            self.eng.step()
-            d = self.eng.drain(recycle=True)
+        # host-pipelined (one engine or several parts): this move is enqueued, then the tuples of the PREVIOUS move's
+        # drain are collected while the GPU searches -- no host work sits between two moves on the GPU
+        d = self.eng.move(self.S, self.B)
         self._count(self.gatherer.push(d))
 
     def barrier(self):
-        if self.n_streams > 1:
-            self._count(self.gatherer.push(self.eng.flush()))  # the last enqueued move belongs to the timed region
+        self._count(self.gatherer.push(self.eng.flush()))  # the last enqueued move belongs to the timed region
         self._count(self.gatherer.flush())
         torch.cuda.synchronize(self.device)
         if self.world > 1:

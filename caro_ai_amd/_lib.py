@@ -78,6 +78,8 @@ _SIGNATURES = {
     "caro_policy": (C.c_int, [_P, _P, _P, _P]),
     "caro_step": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "caro_drain_tuples": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
+    "caro_drain_tuples_begin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "caro_drain_tuples_end": (C.c_int, [_P, _P, _P]),
     "caro_counters": (C.c_int, [_P, _P, _P]),
     "caro_live_games": (C.c_int, [_P, _P, _P]),
     "caro_debug_stamps": (C.c_int, [_P, C.c_int]),

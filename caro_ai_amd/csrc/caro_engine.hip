@@ -1387,6 +1387,8 @@ struct caro_engine {
   int32_t* scratch;  // device i32 [maxply]
   int32_t* live;     // device i32
   int select_pending;
+  int drain_pending;       // caro_drain_tuples_begin without its _end
+  hipEvent_t drain_ev;     // the totals of that drain have reached pinned memory
   // optional HIP-event timing of the hot kernels (bench.py's live roofline)
   int prof_on;
   int prof_gate;  // 0: skip event records for this launch (sampling inside caro_search_batch)
@@ -1606,6 +1608,7 @@ void caro_engine_destroy(caro_engine* h) {
   if (!h) return;
   for (void* p : h->allocs) (void)hipFree(p);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  if (h->drain_ev) (void)hipEventDestroy(h->drain_ev);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->pinned64) (void)hipHostFree(h->pinned64);
   delete h;
@@ -1749,20 +1752,42 @@ int caro_step(caro_engine* h, const double* uniforms, int32_t* actions, int32_t*
   return 0;
 }
 
-int caro_drain_tuples(caro_engine* h, int64_t cap, uint64_t* states, int32_t* players, double* pi, int32_t* z,
-                      int64_t* games, int recycle, int64_t* n_tuples, int64_t* n_games, void* stream) {
-  if (!h || !states || !players || !pi || !z || !n_tuples || !n_games) return fail(CARO_E_INVAL, "null argument");
+// The drain in two halves, so that a host loop never leaves the GPU idle: _begin enqueues the kernels and the copy
+// of the two totals (nothing waits), the caller enqueues the next move's search behind it, and _end -- called while
+// that search runs -- waits for the totals only.  The output buffers belong to the caller and must stay untouched
+// until _end has returned and their rows have been consumed (stream order: anything enqueued before the next _begin).
+int caro_drain_tuples_begin(caro_engine* h, int64_t cap, uint64_t* states, int32_t* players, double* pi, int32_t* z,
+                            int64_t* games, int recycle, void* stream) {
+  if (!h || !states || !players || !pi || !z) return fail(CARO_E_INVAL, "null argument");
   if (h->select_pending) return fail(CARO_E_STATE, "caro_drain_tuples with a pending caro_select");
+  if (h->drain_pending) return fail(CARO_E_STATE, "caro_drain_tuples_begin twice without caro_drain_tuples_end");
   hipStream_t st = (hipStream_t)stream;
+  if (!h->drain_ev) HIPCHK(hipEventCreateWithFlags(&h->drain_ev, hipEventDisableTiming));
   hipLaunchKernelGGL(k_drain_scan, dim3(1), dim3(1024), 0, st, h->v, (long long)cap);
   DISPATCH(h->var, hipLaunchKernelGGL(k_drain_copy<GEO>, dim3(h->v.G), dim3(256), 0, st, h->v, states, players, pi, z,
                                       games, recycle));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(h->pinned64, h->v.dr_tot, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  *n_tuples = h->pinned64[0];
-  *n_games = h->pinned64[1];
+  HIPCHK(hipMemcpyAsync(h->pinned64 + 8, h->v.dr_tot, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(h->drain_ev, st));
+  h->drain_pending = 1;
   return 0;
+}
+
+int caro_drain_tuples_end(caro_engine* h, int64_t* n_tuples, int64_t* n_games) {
+  if (!h || !n_tuples || !n_games) return fail(CARO_E_INVAL, "null argument");
+  if (!h->drain_pending) return fail(CARO_E_STATE, "caro_drain_tuples_end without caro_drain_tuples_begin");
+  HIPCHK(hipEventSynchronize(h->drain_ev));
+  h->drain_pending = 0;
+  *n_tuples = h->pinned64[8];
+  *n_games = h->pinned64[9];
+  return 0;
+}
+
+int caro_drain_tuples(caro_engine* h, int64_t cap, uint64_t* states, int32_t* players, double* pi, int32_t* z,
+                      int64_t* games, int recycle, int64_t* n_tuples, int64_t* n_games, void* stream) {
+  if (!n_tuples || !n_games) return fail(CARO_E_INVAL, "null argument");
+  const int rc = caro_drain_tuples_begin(h, cap, states, players, pi, z, games, recycle, stream);
+  return rc ? rc : caro_drain_tuples_end(h, n_tuples, n_games);
 }
 
 int caro_counters(caro_engine* h, int64_t counters[8], void* stream) {

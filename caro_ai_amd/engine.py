@@ -111,6 +111,7 @@ class SelfPlayEngine:
         self.net_rows = 0
         self.net_calls = 0
         self._prof = False
+        self._drain_open = False
 
     def close(self):
         if getattr(self, "h", None):
@@ -209,9 +210,7 @@ class SelfPlayEngine:
         _lib.check(self.L.caro_step(self.h, _ptr(u), _ptr(actions), _ptr(done), _ptr(result), self._stream()))
         return actions, done, result
 
-    def drain(self, recycle=True, cap=None):
-        """Finished games -> tuples (device tensors of their own: later drains do not touch them), in the
-        reference's append order."""
+    def _staging(self, cap):
         cap = int(cap or self.G * self.maxply)
         if not hasattr(self, "_dr") or self._dr[0].shape[0] < cap:
             dev = self.device
@@ -220,14 +219,50 @@ class SelfPlayEngine:
                         torch.empty((cap, self.A), dtype=torch.float64, device=dev),
                         torch.empty(cap, dtype=torch.int32, device=dev),
                         torch.empty((self.G, 4), dtype=torch.int64, device=dev))
+        return cap
+
+    def drain_begin(self, recycle=True, cap=None):
+        """first half of drain(): the kernels are enqueued, nothing waits (see caro_drain_tuples_begin)"""
+        cap = self._staging(cap)
+        s, p, pi, z, games = self._dr
+        _lib.check(self.L.caro_drain_tuples_begin(self.h, cap, _ptr(s), _ptr(p), _ptr(pi), _ptr(z), _ptr(games),
+                                                  1 if recycle else 0, self._stream()))
+
+    def drain_end(self):
+        """second half: waits for the totals, hands out the rows as tensors of their own (the staging buffer is
+        reused from row 0 by the next drain; the copies are ordered before it on the stream)"""
         s, p, pi, z, games = self._dr
         nt, ng = C.c_int64(0), C.c_int64(0)
-        _lib.check(self.L.caro_drain_tuples(self.h, cap, _ptr(s), _ptr(p), _ptr(pi), _ptr(z), _ptr(games),
-                                            1 if recycle else 0, C.addressof(nt), C.addressof(ng), self._stream()))
+        _lib.check(self.L.caro_drain_tuples_end(self.h, C.addressof(nt), C.addressof(ng)))
         nt, ng = nt.value, ng.value
-        # the kernel wrote into one staging buffer that the next drain reuses from row 0: hand out copies
+        if nt == 0 and ng == 0:
+            return {"states": s[:0], "players": p[:0], "pi": pi[:0], "z": z[:0], "games": games[:0]}
         return {"states": s[:nt].clone(), "players": p[:nt].clone(), "pi": pi[:nt].clone(), "z": z[:nt].clone(),
                 "games": games[:ng].clone()}
+
+    def drain(self, recycle=True, cap=None):
+        """Finished games -> tuples (device tensors of their own: later drains do not touch them), in the
+        reference's append order."""
+        self.drain_begin(recycle, cap)
+        return self.drain_end()
+
+    def move(self, searches, batch, recycle=True):
+        """One move of every game with the host loop software-pipelined: search + ply + the drain kernels of THIS
+        move are enqueued, and only then the totals of the PREVIOUS move's drain are waited for -- while the GPU is
+        busy with this move's search -- so nothing on the host sits between two moves on the GPU.  Returns the
+        tuples of the previous move (None on the first call); flush() hands out the last ones."""
+        self.search(searches, batch)
+        self.step()
+        out = self.drain_end() if self._drain_open else None
+        self.drain_begin(recycle)
+        self._drain_open = True
+        return out
+
+    def flush(self):
+        if not self._drain_open:
+            return None
+        self._drain_open = False
+        return self.drain_end()
 
     # ------------------------------------------------------------ inspection
     def counters(self):

@@ -161,6 +161,13 @@ int caro_step(caro_engine* h, const double* uniforms_dev, int32_t* actions_dev, 
 int caro_drain_tuples(caro_engine* h, int64_t cap, uint64_t* states_dev, int32_t* players_dev, double* pi_dev,
                       int32_t* z_dev, int64_t* games_dev, int recycle, int64_t* n_tuples, int64_t* n_games,
                       void* stream);
+/* The same drain in two halves for host loops that must not leave the GPU idle (the reference's loop appends to
+ * its deque right away, utils.py:101-106; here the rows of move k are handed over while move k+1 is searched):
+ * _begin enqueues the kernels and returns at once; _end waits for the two totals only.  The output buffers must
+ * not be touched between the two calls, and their rows are valid for anything enqueued before the next _begin. */
+int caro_drain_tuples_begin(caro_engine* h, int64_t cap, uint64_t* states_dev, int32_t* players_dev, double* pi_dev,
+                            int32_t* z_dev, int64_t* games_dev, int recycle, void* stream);
+int caro_drain_tuples_end(caro_engine* h, int64_t* n_tuples, int64_t* n_games);
 
 /* counters[8] (host array): sims, levels, expansions, terminals, dropped
  * duplicates, node-pool overflows, plies, finished games.  Synchronises. */

@@ -73,6 +73,51 @@ def test_drained_tuples_survive_later_drains_and_the_gatherer_keeps_them():
     assert off == n_rows
 
 
+def test_pipelined_move_hands_out_the_same_rows_one_move_later():
+    """SelfPlayEngine.move() (caro_drain_tuples_begin / _end: this move's drain is enqueued, the PREVIOUS move's
+    totals are collected while the GPU searches) against the plain search / step / drain loop: the same drains,
+    in the same order, one move later; flush() hands out the last one.  Calling _end without _begin, or _begin
+    twice, is refused."""
+    from caro_ai_amd import _lib
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.net_hip import HashNet
+    game = TicTacToe()
+    S, B, seed, moves = 6, 4, 21, 24
+
+    def make():
+        return SelfPlayEngine(game, 48, evaluators=[HashNet(game, device=DEV)], max_batch=B, steps_before_tau_0=2,
+                              seed=seed, device=DEV)
+
+    eng = make()
+    plain = []
+    for _ in range(moves):
+        eng.search(S, B)
+        eng.step()
+        plain.append(_host(eng.drain(recycle=True)))
+    c_plain = eng.counters()
+    eng.close()
+    eng = make()
+    piped = []
+    for i in range(moves):
+        out = eng.move(S, B)
+        assert (out is None) == (i == 0)
+        if out is not None:
+            piped.append(_host(out))
+    with pytest.raises(_lib.CaroError):
+        eng.drain_begin()  # the last move's drain is still open
+    piped.append(_host(eng.flush()))
+    assert eng.flush() is None
+    with pytest.raises(_lib.CaroError):
+        eng.drain_end()
+    assert eng.counters() == c_plain
+    eng.close()
+    assert len(piped) == len(plain) and sum(p["z"].shape[0] for p in plain) > 200
+    for a, b in zip(plain, piped):
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 def test_self_play_replay_rows_are_the_drained_tuples():
     from caro_ai_amd import config as cfg
     from caro_ai_amd import train
