@@ -80,6 +80,9 @@ _SIGNATURES = {
     "caro_drain_tuples": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     "caro_drain_tuples_begin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P]),
     "caro_drain_tuples_end": (C.c_int, [_P, _P, _P]),
+    "caro_stagger_enable": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "caro_search_staggered": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "caro_drain_parked_begin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "caro_counters": (C.c_int, [_P, _P, _P]),
     "caro_live_games": (C.c_int, [_P, _P, _P]),
     "caro_debug_stamps": (C.c_int, [_P, C.c_int]),

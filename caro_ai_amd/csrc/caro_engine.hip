@@ -91,6 +91,18 @@ struct View {
   unsigned long long* counters;  // [G][C_N] per-game tallies (no atomics on the hot path), summed on read
   unsigned long long* counters_sum;  // [C_N]
   unsigned long long* dbg;           // diagnostic stamps [G][8] or null (never set in product runs)
+  // staggered mode (caro_stagger_enable; k_tree_stag): every game runs its own minibatch clock
+  int stag_S;           // minibatches per move (0: lock-step engine)
+  int stag_recycle;     // finished games restart in-kernel (uid += uid_stride)
+  int32_t* lm;          // [G] index of the game's next minibatch, 0..stag_S (== stag_S: the move is due)
+  int32_t* pend;        // [G] 1: a selected minibatch awaits its expand + backup
+  int32_t* wait;        // [G] launches the game still sits out before its first search (the initial stagger)
+  // a finished game is PARKED (its record and history copied aside) so that the slot restarts at once; the parked
+  // rows wait for the next drain.  Same field meaning as the live arrays they are copied from.
+  int32_t* pk_flag;     // [G] 1 parked and not drained yet, otherwise free
+  int32_t* pk_ply; int32_t* pk_final_r; int32_t* pk_first; int32_t* pk_result; int32_t* pk_step;
+  uint64_t* pk_uid;
+  uint64_t* ph_key; int32_t* ph_player; double* ph_pi;
   // drain scratch
   int32_t* dr_off;
   int32_t* dr_gidx;
@@ -888,23 +900,17 @@ __global__ void k_policy(View v, double* __restrict__ pi_out, int32_t* __restric
   }
 }
 
+// One ply of play_game for game g (utils.py:80-99): pi from the root's visit counts, the history row, the sampled
+// move, game.move, win / draw, the tau switch.  All threads of the block take part; returns (to every thread) 1 if
+// the game has ended with this ply.  s_pi / s_n: AP entries of LDS each.
 template <class GEO>
-__global__ void k_step(View v, const double* __restrict__ uniforms, int32_t* __restrict__ actions,
-                       int32_t* __restrict__ done_out, int32_t* __restrict__ result_out) {
+__device__ __forceinline__ int step_body(const View& v, int g, const double* __restrict__ uniforms, double* s_pi,
+                                         int* s_n, int32_t* __restrict__ actions, int32_t* __restrict__ done_out,
+                                         int32_t* __restrict__ result_out) {
   using R = typename GEO::R;
   using Board = typename R::Board;
-  constexpr int AP = GEO::AP, KW = GEO::KW;
-  __shared__ double s_pi[AP];
-  __shared__ int s_n[AP];
-  const int g = blockIdx.x;
-  if (v.done[g]) {
-    if (threadIdx.x == 0) {
-      if (actions) actions[g] = -1;
-      if (done_out) done_out[g] = 1;
-      if (result_out) result_out[g] = v.result[g];
-    }
-    return;
-  }
+  constexpr int KW = GEO::KW;
+  __shared__ int s_done;
   Board root = load_board<R>(v.root + (size_t)g * KW);
   const int player = v.player[g];
   const int t = g * v.n_stores + (v.n_stores == 2 ? player : 0);
@@ -946,7 +952,28 @@ __global__ void k_step(View v, const double* __restrict__ uniforms, int32_t* __r
     if (actions) actions[g] = action;
     if (done_out) done_out[g] = done;
     if (result_out) result_out[g] = res;
+    s_done = done;
   }
+  __syncthreads();
+  return s_done;
+}
+
+template <class GEO>
+__global__ void k_step(View v, const double* __restrict__ uniforms, int32_t* __restrict__ actions,
+                       int32_t* __restrict__ done_out, int32_t* __restrict__ result_out) {
+  constexpr int AP = GEO::AP;
+  __shared__ double s_pi[AP];
+  __shared__ int s_n[AP];
+  const int g = blockIdx.x;
+  if (v.done[g]) {
+    if (threadIdx.x == 0) {
+      if (actions) actions[g] = -1;
+      if (done_out) done_out[g] = 1;
+      if (result_out) result_out[g] = v.result[g];
+    }
+    return;
+  }
+  step_body<GEO>(v, g, uniforms, s_pi, s_n, actions, done_out, result_out);
 }
 
 // ------------------------------------------------------------------ eviction
@@ -1036,6 +1063,96 @@ template <class GEO>
 __global__ void k_reset(View v, const int32_t* __restrict__ first_player) {
   const int g = blockIdx.x;
   reset_game<GEO>(v, g, v.uid_base + (uint64_t)g, first_player ? first_player[g] : -1);
+}
+
+// ------------------------------------------------------------------ staggered mode
+// Why: in lock-step all G games sit at the same minibatch index, and the first minibatches after a move carry far
+// more new leaves than the later ones (connect four, 1024 games: 2312 / 1718 / 1610 / 1536 ... 1300, mean 1434) -- the
+// net launch overflows one round of tiles (256 CUs x 6 boards) exactly there and pays a second, short round.  Games
+// are independent, so nothing forces them to move at the same time: here every game keeps its OWN minibatch clock
+// lm[g], the clocks are spread evenly over the S minibatches of a move (game g sits out g % S launches at the start),
+// and every launch then sees 1/S of the games at each index: the same ~mean leaf count every time.  A game whose S
+// minibatches are done makes its ply inside the tree kernel (step_body), and a finished game is parked and its slot
+// restarted on the spot, so the clocks never re-align.  Per game nothing changes: the same minibatches in the same
+// order on the same tree with the same noise keys (seed, uid, ply, sim) -- results equal the lock-step engine's and
+// the oracle's game by game (tests/test_gpu_stagger.py).
+
+// Moves the finished game of slot g aside (record + history rows) and restarts the slot; false if the previous
+// parked game of this slot has not been drained yet (the game then stays finished and tries again next launch).
+template <class GEO>
+__device__ __forceinline__ bool park_and_restart(const View& v, int g) {
+  constexpr int KW = GEO::KW;
+  if (v.pk_flag[g] == 1) return false;
+  const int n = v.ply[g];
+  const size_t h0 = (size_t)g * v.maxply;
+  for (int idx = threadIdx.x; idx < n * v.A; idx += blockDim.x) v.ph_pi[h0 * v.A + idx] = v.h_pi[h0 * v.A + idx];
+  for (int idx = threadIdx.x; idx < n * KW; idx += blockDim.x) v.ph_key[h0 * KW + idx] = v.h_key[h0 * KW + idx];
+  for (int j = threadIdx.x; j < n; j += blockDim.x) v.ph_player[h0 + j] = v.h_player[h0 + j];
+  const uint64_t uid = v.uid[g];
+  if (threadIdx.x == 0) {
+    v.pk_ply[g] = n;
+    v.pk_final_r[g] = v.final_r[g];
+    v.pk_first[g] = v.first[g];
+    v.pk_result[g] = v.result[g];
+    v.pk_step[g] = v.step[g];
+    v.pk_uid[g] = uid;
+    v.pk_flag[g] = 1;
+  }
+  __syncthreads();  // the live record has been read by every thread
+  if (v.stag_recycle) {
+    reset_game<GEO>(v, g, uid + v.uid_stride, -1);  // clears the slot's trees, new uid, done = 0
+    __syncthreads();
+    return true;
+  }
+  return false;  // no restart asked for: the slot stays finished (done = 1), its game is parked
+}
+
+// The fused tree kernel of the staggered mode (one 64-lane wavefront per game; launch geometry and the slot-row
+// interface to the net kernel are k_tree's): expand + backup of the game's pending minibatch, the ply if its S
+// minibatches are done (+ park / restart if the game ended), then the descents of its next minibatch.
+template <class GEO>
+__global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, const float* __restrict__ values,
+                            float* __restrict__ planes, uint64_t* __restrict__ leaf_keys,
+                            int32_t* __restrict__ rows_cur, int32_t* __restrict__ rows_next) {
+  constexpr int AP = GEO::AP;
+  __shared__ double s_pi[AP];
+  __shared__ int s_n[AP];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    rows_next[0] = 0;
+    rows_next[1] = 0;
+    rows_next[2] = B;
+    rows_cur[2] = B;
+  }
+  const int g = blockIdx.x;
+  const int w = v.wait[g];
+  if (w > 0) {  // not started yet
+    if (threadIdx.x == 0) {
+      v.wait[g] = w - 1;
+      v.g_nleaf[g] = 0;
+      v.g_class[g] = 0;
+      v.g_pack[g] = 0;
+    }
+    return;
+  }
+  int lm = v.lm[g];
+  if (v.pend[g]) {
+    expand_body<GEO>(v, B, probs, values);
+    __syncthreads();  // the block's own tree updates are visible to what follows
+  }
+  int over = v.done[g];  // 1: finished earlier and could not be parked (its slot's previous game is not drained yet)
+  if (!over && lm == v.stag_S) {
+    over = step_body<GEO>(v, g, nullptr, s_pi, s_n, nullptr, nullptr, nullptr);
+    lm = 0;
+  }
+  if (over) {
+    if (park_and_restart<GEO>(v, g)) over = 0;  // a new game sits in the slot: its first minibatch follows
+  }
+  // select_body returns at once (zero leaves) for a finished game
+  select_body<GEO>(v, B, lm, nullptr, rows_cur, planes, leaf_keys);
+  if (threadIdx.x == 0) {
+    v.lm[g] = over ? 0 : lm + 1;
+    v.pend[g] = over ? 0 : 1;
+  }
 }
 
 template <class GEO>
@@ -1388,6 +1505,7 @@ struct caro_engine {
   int32_t* live;     // device i32
   int select_pending;
   int drain_pending;       // caro_drain_tuples_begin without its _end
+  int stag_batch;          // staggered mode: the batch size of the first caro_search_staggered call
   hipEvent_t drain_ev;     // the totals of that drain have reached pinned memory
   // optional HIP-event timing of the hot kernels (bench.py's live roofline)
   int prof_on;
@@ -1729,6 +1847,97 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
     if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree launch failed"); }
   }
   h->prof_gate = 1;
+  return 0;
+}
+
+// ---- staggered mode (see k_tree_stag)
+__global__ void k_stag_init(View v) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= v.G) return;
+  v.lm[g] = 0;
+  v.pend[g] = 0;
+  v.wait[g] = g % v.stag_S;
+  v.pk_flag[g] = 0;
+}
+
+int caro_stagger_enable(caro_engine* h, int searches, int recycle, void* stream) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  if (searches < 1) return fail(CARO_E_INVAL, "searches must be >= 1");
+  if (h->v.stag_S) return fail(CARO_E_STATE, "staggered mode is already on");
+  if (h->prof_ctr || h->select_pending) return fail(CARO_E_STATE, "caro_stagger_enable needs a fresh engine");
+  if (!h->fused_ok || h->v.maxB * variant_lpd(h->var) < 64)
+    return fail(CARO_E_INVAL, "staggered mode needs the one-wavefront-per-game geometry (batch x lanes per descent = 64)");
+  if (h->v.ntab == 2) return fail(CARO_E_INVAL, "staggered mode does not combine with eviction");
+  View& v = h->v;
+  const size_t G = (size_t)v.G;
+  const int KW = variant_kw(h->var);
+  int rc = 0;
+#define DA(p, n) if ((rc = dalloc(h, &p, (n))) != 0) return rc;
+  DA(v.lm, G); DA(v.pend, G); DA(v.wait, G);
+  DA(v.pk_flag, G); DA(v.pk_ply, G); DA(v.pk_final_r, G); DA(v.pk_first, G); DA(v.pk_result, G); DA(v.pk_step, G);
+  DA(v.pk_uid, G);
+  DA(v.ph_key, G * v.maxply * KW);
+  DA(v.ph_player, G * v.maxply);
+  DA(v.ph_pi, G * v.maxply * v.A);
+#undef DA
+  v.stag_S = searches;
+  v.stag_recycle = recycle ? 1 : 0;
+  hipLaunchKernelGGL(k_stag_init, dim3((v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, v);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int launches, int batch, float* planes,
+                          uint64_t* leaf_keys, float* probs, float* values, void* stream) {
+  if (!h || !net0 || !planes || !probs || !values) return fail(CARO_E_INVAL, "null argument");
+  if (!h->v.stag_S) return fail(CARO_E_STATE, "caro_stagger_enable first");
+  if (h->v.n_nets == 2 && !net1) return fail(CARO_E_INVAL, "engine has two nets, net1 is null");
+  if (launches < 1) return fail(CARO_E_INVAL, "launches must be >= 1");
+  if (batch < 1 || batch > h->v.maxB || batch * variant_lpd(h->var) != 64)
+    return fail(CARO_E_INVAL, "staggered mode: batch x lanes per descent must be 64");
+  if (h->stag_batch && h->stag_batch != batch) return fail(CARO_E_INVAL, "staggered mode: the batch size is fixed by the first call");
+  h->stag_batch = batch;
+  hipStream_t st = (hipStream_t)stream;
+  for (int j = 0; j < launches; ++j) {
+    h->prof_gate = (h->prof_ctr++ % 12) == 0;  // sampled HIP-event timing, as caro_search_batch
+    int32_t* cur = h->rows + 4 * h->rows_par;
+    int32_t* nxt = h->rows + 4 * (h->rows_par ^ 1);
+    h->rows_par ^= 1;
+    const int p1 = prof_begin(h, PK_SELECT, st);
+    DISPATCH(h->var, hipLaunchKernelGGL(k_tree_stag<GEO>, dim3(h->v.G), dim3(64), 0, st, h->v, batch, probs, values,
+                                        planes, leaf_keys, cur, nxt));
+    prof_end(h, p1, st);
+    if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree_stag launch failed"); }
+    const int p0 = prof_begin(h, PK_NET, st);
+    const int rc = caro_net_forward_slots(net0, h->v.n_nets == 2 ? net1 : nullptr, planes, cur, h->v.g_pack, h->v.G,
+                                          batch, probs, values, stream);
+    prof_end(h, p0, st);
+    if (rc) { h->prof_gate = 1; return rc; }
+  }
+  h->prof_gate = 1;
+  return 0;
+}
+
+// drain of the PARKED games: the lock-step drain kernels on a view whose game records and history rows are the
+// parked copies (finished flag = pk_flag; a drained record becomes free again)
+int caro_drain_parked_begin(caro_engine* h, int64_t cap, uint64_t* states, int32_t* players, double* pi, int32_t* z,
+                            int64_t* games, void* stream) {
+  if (!h || !states || !players || !pi || !z) return fail(CARO_E_INVAL, "null argument");
+  if (!h->v.stag_S) return fail(CARO_E_STATE, "caro_stagger_enable first");
+  if (h->drain_pending) return fail(CARO_E_STATE, "caro_drain_parked_begin twice without caro_drain_tuples_end");
+  hipStream_t st = (hipStream_t)stream;
+  if (!h->drain_ev) HIPCHK(hipEventCreateWithFlags(&h->drain_ev, hipEventDisableTiming));
+  View pv = h->v;
+  pv.done = h->v.pk_flag; pv.ply = h->v.pk_ply; pv.final_r = h->v.pk_final_r; pv.first = h->v.pk_first;
+  pv.result = h->v.pk_result; pv.step = h->v.pk_step; pv.uid = h->v.pk_uid;
+  pv.h_key = h->v.ph_key; pv.h_player = h->v.ph_player; pv.h_pi = h->v.ph_pi;
+  hipLaunchKernelGGL(k_drain_scan, dim3(1), dim3(1024), 0, st, pv, (long long)cap);
+  DISPATCH(h->var, hipLaunchKernelGGL(k_drain_copy<GEO>, dim3(pv.G), dim3(256), 0, st, pv, states, players, pi, z,
+                                      games, 0));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h->pinned64 + 8, h->v.dr_tot, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(h->drain_ev, st));
+  h->drain_pending = 1;
   return 0;
 }
 

@@ -54,7 +54,8 @@ class SelfPlayEngine:
     def __init__(self, game, n_games, net1=None, net2=None, evaluators=None, n_stores=1, max_batch=None,
                  node_cap=None, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, first_player_mode=2,
                  c_puct=cfg.C_PUCT, alpha=cfg.ALPHA, explore=cfg.EXPLORE, seed=0, uid_base=0, uid_stride=None,
-                 device="cuda:0", searches_hint=cfg.MCTS_SEARCHES, inference="hipw", evict=False):
+                 device="cuda:0", searches_hint=cfg.MCTS_SEARCHES, inference="hipw", evict=False, stagger=False,
+                 stagger_recycle=True):
         if not torch.cuda.is_available():
             raise _lib.CaroError("SelfPlayEngine needs a GPU (torch.cuda.is_available() is False); "
                                  "there is no CPU fallback")
@@ -112,6 +113,15 @@ class SelfPlayEngine:
         self.net_calls = 0
         self._prof = False
         self._drain_open = False
+        # staggered mode (include/caro_hip.h, caro_stagger_enable): every game on its own minibatch clock, the ply
+        # inside the tree kernel, finished games parked and restarted in place; search() then runs `searches`
+        # launches, step() has nothing left to do and drain() hands out the parked games
+        self.stagger = bool(stagger)
+        if self.stagger:
+            if not self.async_net:
+                raise _lib.CaroError("stagger=True needs device-side evaluators (the fused HIP net or HashNet)")
+            self.stag_S = int(searches_hint)
+            _lib.check(self.L.caro_stagger_enable(self.h, self.stag_S, 1 if stagger_recycle else 0, self._stream()))
 
     def close(self):
         if getattr(self, "h", None):
@@ -178,6 +188,14 @@ class SelfPlayEngine:
 
     def search(self, searches, batch, noise=None):
         """search_batch (mcts.py:162-176) for all games. noise: optional [searches, G, batch, A] rows."""
+        if self.stagger:
+            assert noise is None and searches == self.stag_S, "staggered mode: generated noise, searches = searches_hint"
+            nets = [e.h for e in self.evaluators] + [None]
+            _lib.check(self.L.caro_search_staggered(self.h, nets[0], nets[1], searches, batch, _ptr(self.planes),
+                                                    _ptr(self.leaf_keys), _ptr(self._probs), _ptr(self._values),
+                                                    self._stream()))
+            self.net_calls += searches * self.n_nets
+            return
         if self.async_net:
             # whole search_batch enqueued by one C call (no Python / ctypes work per launch)
             nz = None
@@ -201,6 +219,9 @@ class SelfPlayEngine:
         return pi, counts
 
     def step(self, uniforms=None):
+        if self.stagger:  # the plies are made inside the tree kernel, each game in its own time
+            assert uniforms is None
+            return None
         u = None
         if uniforms is not None:
             u = torch.as_tensor(np.asarray(uniforms, dtype=np.float64)).to(self.device).contiguous()
@@ -225,6 +246,10 @@ class SelfPlayEngine:
         """first half of drain(): the kernels are enqueued, nothing waits (see caro_drain_tuples_begin)"""
         cap = self._staging(cap)
         s, p, pi, z, games = self._dr
+        if self.stagger:  # the parked games; their slots have restarted already (or not: stagger_recycle)
+            _lib.check(self.L.caro_drain_parked_begin(self.h, cap, _ptr(s), _ptr(p), _ptr(pi), _ptr(z), _ptr(games),
+                                                      self._stream()))
+            return
         _lib.check(self.L.caro_drain_tuples_begin(self.h, cap, _ptr(s), _ptr(p), _ptr(pi), _ptr(z), _ptr(games),
                                                   1 if recycle else 0, self._stream()))
 

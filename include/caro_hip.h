@@ -282,6 +282,27 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
                       const double* noise_dev, float* planes_dev, uint64_t* leaf_keys_dev, float* probs_dev,
                       float* values_dev, void* stream);
 
+/* ---- staggered mode: every game on its own minibatch clock (the hot path of bench.py / train.self_play) ----
+ * In lock-step all games reach a move together, and the launches right after a move carry far more new leaves
+ * than the rest, so the net launch overflows one round of tiles exactly there.  The reference plays its games one
+ * after another (train.py:41-47) -- nothing ties their moves together -- so here each game counts its own
+ * minibatches: game g sits out g % searches launches at the start, makes its ply INSIDE the tree kernel when its
+ * `searches` minibatches are done (lib/utils.py:80-99), and a finished game is parked (record + history rows copied
+ * aside) and its slot restarted at once (uid += uid_stride) when `recycle` != 0.  Every launch then carries the
+ * same mix of minibatch indices.  Game by game the results are those of caro_search_batch + caro_step: the same
+ * minibatches on the same tree with the same noise keys.  Needs the one-wavefront-per-game geometry (batch x lanes
+ * per descent = 64: connect four with batch 8), generated noise / move uniforms, no eviction; a fresh engine.
+ *   caro_stagger_enable     once, before the first search
+ *   caro_search_staggered   `launches` x (tree kernel -> net kernel); on average every game moves once per
+ *                           `searches` launches
+ *   caro_drain_parked_begin tuples of the parked games, as caro_drain_tuples_begin (no recycle flag: the slots have
+ *                           restarted already); finish with caro_drain_tuples_end */
+int caro_stagger_enable(caro_engine* h, int searches, int recycle, void* stream);
+int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int launches, int batch, float* planes_dev,
+                          uint64_t* leaf_keys_dev, float* probs_dev, float* values_dev, void* stream);
+int caro_drain_parked_begin(caro_engine* h, int64_t cap, uint64_t* states_dev, int32_t* players_dev, double* pi_dev,
+                            int32_t* z_dev, int64_t* games_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

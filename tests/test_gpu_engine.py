@@ -209,12 +209,13 @@ def _oracle_games(d, uids, seed, sbt0, S, B, n_stores, first_mode=2, salts=(0, 0
     return out
 
 
-def _check_against_oracle(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base, form="stepwise", salts=None):
+def _check_against_oracle(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base, form="stepwise", salts=None,
+                          **engine_kw):
     """salts = (s0, s1): player 0's leaves go to table net s0, player 1's to net s1 (n_nets = 2, play.py arena)"""
     game = _game_of(d)
     evs = [_synth(game, form)] if salts is None else [_synth(game, form, salts[0]), _synth(game, form, salts[1])]
     eng = _engine(game, G, evs, n_stores=n_stores, max_batch=B, steps_before_tau_0=sbt0, seed=seed,
-                  uid_base=uid_base, node_cap=S * B * game.obs_shape[1] * game.obs_shape[2] + 64)
+                  uid_base=uid_base, node_cap=S * B * game.obs_shape[1] * game.obs_shape[2] + 64, **engine_kw)
     tuples, games = eng.play_until(S, B, n_finished=n_finish)
     c = eng.counters()
     assert c["overflows"] == 0
