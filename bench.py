@@ -238,6 +238,10 @@ class Leg:
             make_evaluators = lambda: [torch_evaluator(fnet, form="net")]
         self.n_streams = args.streams if self.is_hip else 1
         common = dict(max_batch=B, steps_before_tau_0=self.sbt0, seed=0, device=str(device), searches_hint=S)
+        # staggered mode (every game on its own minibatch clock: even leaf counts per launch, include/caro_hip.h):
+        # wherever one wavefront serves a game and nothing needs the second key table
+        self.stagger = bool(args.stagger and self.is_hip and game_name == "c4" and B == 8 and not self.evict
+                            and self.n_streams == 1)
         # a small copy of the same configuration: played to completion before the clock starts, it takes the
         # first-use costs (code objects, torch's clone / cat / cast kernels, allocator growth of the drain path)
         self._warm = SelfPlayEngine(self.game, 16, evaluators=make_evaluators(), uid_base=1 << 40, uid_stride=16,
@@ -247,8 +251,8 @@ class Leg:
                                         partition_cus=bool(args.stream_mask), **common, **extra,
                                         **parallel.shard(G, rank, world))
         else:
-            self.eng = SelfPlayEngine(self.game, G, evaluators=make_evaluators(), **common, **extra,
-                                      **parallel.shard(G, rank, world))
+            self.eng = SelfPlayEngine(self.game, G, evaluators=make_evaluators(), stagger=self.stagger, **common,
+                                      **extra, **parallel.shard(G, rank, world))
         self.gatherer = parallel.TupleGatherer(every=args.gather_every)
         self.n_tuples = 0
 
@@ -344,7 +348,7 @@ class Leg:
             levels_per_launch = delta["levels"] / n_launches
             achieved = levels_per_launch * bytes_per_level / avg_s / 1e9
             fused = prof.get("compact", (0, 0))[1] == 0
-            tname = "k_tree" if fused else "k_select"
+            tname = ("k_tree_stag" if self.stagger else "k_tree") if fused else "k_select"
             others = {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in prof.items() if k not in ("select", "net")}
             roofline_tree = {"bound": "hbm", "kernel": tname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(tname),
@@ -392,6 +396,8 @@ class Leg:
                                    % (board, G, what, S, B, S * B, self.sbt0),
                        "games_per_gpu": G, "searches": S, "batch": B, "net": "lib/model.py Net, %s fp32" % netdesc,
                        "streams_per_gpu": n_streams,
+                       "schedule": "staggered: every game on its own minibatch clock, ply inside the tree kernel, "
+                                   "finished games parked and restarted in place" if self.stagger else "lock-step",
                        "parallelism": "games sharded x%d, tuples all-gathered every %d moves"
                                       % (self.world, args.gather_every)},
             "per_gpu": exp_all / dt / self.world,
@@ -459,6 +465,8 @@ def main():
                     help="split the games of a GPU over this many engines on separate HIP streams (tree kernels of "
                          "one part overlap the net kernel of another)")
     ap.add_argument("--stream-mask", type=int, default=1, help="with --streams > 1: confine each part to its own CU slice")
+    ap.add_argument("--stagger", type=int, default=1,
+                    help="1: staggered mode where the geometry allows it (connect four, batch 8); 0: lock-step")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N > 1: all-gather the finished games' tuples every this many moves (one payload message)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

@@ -1104,7 +1104,9 @@ __device__ __forceinline__ bool park_and_restart(const View& v, int g) {
     __syncthreads();
     return true;
   }
-  return false;  // no restart asked for: the slot stays finished (done = 1), its game is parked
+  if (threadIdx.x == 0) v.done[g] = 2;  // no restart asked for: parked, the slot stays finished
+  __syncthreads();
+  return false;
 }
 
 // The fused tree kernel of the staggered mode (one 64-lane wavefront per game; launch geometry and the slot-row
@@ -1134,12 +1136,21 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
     }
     return;
   }
+  const int fin = v.done[g];
+  if (fin == 2) {  // parked without restart: nothing left to do in this slot
+    if (threadIdx.x == 0) {
+      v.g_nleaf[g] = 0;
+      v.g_class[g] = 0;
+      v.g_pack[g] = 0;
+    }
+    return;
+  }
   int lm = v.lm[g];
   if (v.pend[g]) {
     expand_body<GEO>(v, B, probs, values);
     __syncthreads();  // the block's own tree updates are visible to what follows
   }
-  int over = v.done[g];  // 1: finished earlier and could not be parked (its slot's previous game is not drained yet)
+  int over = fin == 1;  // finished earlier and could not be parked (its slot's previous game is not drained yet)
   if (!over && lm == v.stag_S) {
     over = step_body<GEO>(v, g, nullptr, s_pi, s_n, nullptr, nullptr, nullptr);
     lm = 0;
