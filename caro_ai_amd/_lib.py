@@ -28,7 +28,7 @@ class CaroConfig(C.Structure):
         ("steps_before_tau_0", C.c_int32), ("first_player_mode", C.c_int32),
         ("c_puct", C.c_float), ("alpha", C.c_double), ("explore", C.c_double),
         ("seed", C.c_uint64), ("uid_base", C.c_uint64), ("uid_stride", C.c_uint64),
-        ("device_id", C.c_int32), ("evict", C.c_int32),
+        ("device_id", C.c_int32), ("evict", C.c_int32), ("stagger", C.c_int32), ("stagger_recycle", C.c_int32),
     ]
 
 
@@ -80,7 +80,6 @@ _SIGNATURES = {
     "caro_drain_tuples": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     "caro_drain_tuples_begin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int, _P]),
     "caro_drain_tuples_end": (C.c_int, [_P, _P, _P]),
-    "caro_stagger_enable": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "caro_search_staggered": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "caro_drain_parked_begin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "caro_counters": (C.c_int, [_P, _P, _P]),

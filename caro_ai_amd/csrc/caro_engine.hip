@@ -97,6 +97,7 @@ struct View {
   int32_t* lm;          // [G] index of the game's next minibatch, 0..stag_S (== stag_S: the move is due)
   int32_t* pend;        // [G] 1: a selected minibatch awaits its expand + backup
   int32_t* wait;        // [G] launches the game still sits out before its first search (the initial stagger)
+  int32_t* dirty;       // [T] 1: the tree's OTHER key table holds the keys of a finished game (cleared at the next drain)
   // a finished game is PARKED (its record and history copied aside) so that the slot restarts at once; the parked
   // rows wait for the next drain.  Same field meaning as the live arrays they are copied from.
   int32_t* pk_flag;     // [G] 1 parked and not drained yet, otherwise free
@@ -1100,7 +1101,30 @@ __device__ __forceinline__ bool park_and_restart(const View& v, int g) {
   }
   __syncthreads();  // the live record has been read by every thread
   if (v.stag_recycle) {
-    reset_game<GEO>(v, g, uid + v.uid_stride, -1);  // clears the slot's trees, new uid, done = 0
+    // restart without clearing anything on this wave's time: the slot's trees move to their OTHER key table, which
+    // is clean (both are at creation; the one left behind is cleared by k_stag_clean at the next drain, and no slot
+    // restarts twice between two drains: pk_flag above)
+    if (threadIdx.x == 0) {
+      for (int st = 0; st < v.n_stores; ++st) {
+        const int t = g * v.n_stores + st;
+        v.tbl[t] = 1 - v.tbl[t];
+        v.dirty[t] = 1;
+        v.n_nodes[t] = 0;
+        v.n_created[t] = 0;
+      }
+      const uint64_t nuid = uid + v.uid_stride;
+      const typename GEO::R::Board b0 = GEO::R::initial(v.gp);
+      store_board<typename GEO::R>(v.root + (size_t)g * KW, b0);
+      const int fp = v.first_mode == 2 ? (int)(nuid & 1ull) : v.first_mode;
+      v.player[g] = fp;
+      v.first[g] = fp;
+      v.ply[g] = 0;
+      v.step[g] = 0;
+      v.uid[g] = nuid;
+      v.done[g] = 0;
+      v.result[g] = 0;
+      v.final_r[g] = 0;
+    }
     __syncthreads();
     return true;
   }
@@ -1164,6 +1188,26 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
     v.lm[g] = over ? 0 : lm + 1;
     v.pend[g] = over ? 0 : 1;
   }
+}
+
+__global__ void k_stag_init(View v) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= v.G) return;
+  v.lm[g] = 0;
+  v.pend[g] = 0;
+  v.wait[g] = g % v.stag_S;
+  v.pk_flag[g] = 0;
+}
+
+// clears the key table a restarted slot left behind (256 threads per tree; a no-op for every other tree)
+template <class GEO>
+__global__ void k_stag_clean(View v) {
+  constexpr int KW = GEO::KW;
+  const int t = blockIdx.x;
+  if (!v.dirty[t]) return;
+  uint64_t* keys = v.node_key + (size_t)(t * 2 + (1 - v.tbl[t])) * v.hcap * KW;
+  for (int i = threadIdx.x; i < v.hcap * KW; i += blockDim.x) keys[i] = EMPTY_KEY;
+  if (threadIdx.x == 0) v.dirty[t] = 0;
 }
 
 template <class GEO>
@@ -1645,6 +1689,12 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
     return fail(CARO_E_INVAL, "max_batch out of range for this game (batch * lanes-per-descent <= 1024, batch <= 64)");
   if (cfg->game_kind == CARO_GAME_MNK && (cfg->k < 2 || cfg->k > cfg->n))
     return fail(CARO_E_INVAL, "k must satisfy 2 <= k <= n");
+  if (cfg->stagger < 0) return fail(CARO_E_INVAL, "stagger must be >= 0");
+  if (cfg->stagger > 0) {
+    if (cfg->evict) return fail(CARO_E_INVAL, "staggered mode does not combine with eviction");
+    if (cfg->max_batch * lpd != 64)
+      return fail(CARO_E_INVAL, "staggered mode needs the one-wavefront-per-game geometry (max_batch x lanes per descent = 64)");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(CARO_E_NODEV, "no HIP device: libcaro_hip needs a GPU (there is no CPU fallback)");
@@ -1679,7 +1729,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   v.maxB = cfg->max_batch;
   v.sbt0 = cfg->steps_before_tau_0;
   v.first_mode = cfg->first_player_mode;
-  v.ntab = cfg->evict ? 2 : 1;
+  v.ntab = (cfg->evict || cfg->stagger > 0) ? 2 : 1;  // second table: eviction's target / the clean table a restarted slot moves to
   v.c_puct = cfg->c_puct;
   v.alpha = cfg->alpha;
   v.explore = cfg->explore;
@@ -1718,6 +1768,16 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   DA(h->scratch, (size_t)v.maxd + 8);
   DA(h->live, 1);
   DA(h->rows, 8);
+  if (cfg->stagger > 0) {
+    DA(v.lm, G); DA(v.pend, G); DA(v.wait, G); DA(v.dirty, T);
+    DA(v.pk_flag, G); DA(v.pk_ply, G); DA(v.pk_final_r, G); DA(v.pk_first, G); DA(v.pk_result, G); DA(v.pk_step, G);
+    DA(v.pk_uid, G);
+    DA(v.ph_key, G * v.maxply * KW);
+    DA(v.ph_player, G * v.maxply);
+    DA(v.ph_pi, G * v.maxply * v.A);
+    v.stag_S = cfg->stagger;
+    v.stag_recycle = cfg->stagger_recycle ? 1 : 0;
+  }
 #undef DA
   HIPCHK(hipMemset(v.counters, 0, sizeof(unsigned long long) * C_N * G));
   HIPCHK(hipMemset(v.leaf_count, 0, sizeof(int32_t) * 4));
@@ -1729,6 +1789,10 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   *out = h;
   rc = caro_reset_games(h, nullptr, nullptr);
   if (rc) { caro_engine_destroy(h); *out = nullptr; return rc; }
+  if (v.stag_S) {
+    HIPCHK(hipMemset(v.dirty, 0, sizeof(int32_t) * T));
+    hipLaunchKernelGGL(k_stag_init, dim3((v.G + 255) / 256), dim3(256), 0, 0, v);
+  }
   HIPCHK(hipDeviceSynchronize());
   return 0;
 }
@@ -1862,46 +1926,10 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
 }
 
 // ---- staggered mode (see k_tree_stag)
-__global__ void k_stag_init(View v) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= v.G) return;
-  v.lm[g] = 0;
-  v.pend[g] = 0;
-  v.wait[g] = g % v.stag_S;
-  v.pk_flag[g] = 0;
-}
-
-int caro_stagger_enable(caro_engine* h, int searches, int recycle, void* stream) {
-  if (!h) return fail(CARO_E_INVAL, "null engine");
-  if (searches < 1) return fail(CARO_E_INVAL, "searches must be >= 1");
-  if (h->v.stag_S) return fail(CARO_E_STATE, "staggered mode is already on");
-  if (h->prof_ctr || h->select_pending) return fail(CARO_E_STATE, "caro_stagger_enable needs a fresh engine");
-  if (!h->fused_ok || h->v.maxB * variant_lpd(h->var) < 64)
-    return fail(CARO_E_INVAL, "staggered mode needs the one-wavefront-per-game geometry (batch x lanes per descent = 64)");
-  if (h->v.ntab == 2) return fail(CARO_E_INVAL, "staggered mode does not combine with eviction");
-  View& v = h->v;
-  const size_t G = (size_t)v.G;
-  const int KW = variant_kw(h->var);
-  int rc = 0;
-#define DA(p, n) if ((rc = dalloc(h, &p, (n))) != 0) return rc;
-  DA(v.lm, G); DA(v.pend, G); DA(v.wait, G);
-  DA(v.pk_flag, G); DA(v.pk_ply, G); DA(v.pk_final_r, G); DA(v.pk_first, G); DA(v.pk_result, G); DA(v.pk_step, G);
-  DA(v.pk_uid, G);
-  DA(v.ph_key, G * v.maxply * KW);
-  DA(v.ph_player, G * v.maxply);
-  DA(v.ph_pi, G * v.maxply * v.A);
-#undef DA
-  v.stag_S = searches;
-  v.stag_recycle = recycle ? 1 : 0;
-  hipLaunchKernelGGL(k_stag_init, dim3((v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, v);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
 int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int launches, int batch, float* planes,
                           uint64_t* leaf_keys, float* probs, float* values, void* stream) {
   if (!h || !net0 || !planes || !probs || !values) return fail(CARO_E_INVAL, "null argument");
-  if (!h->v.stag_S) return fail(CARO_E_STATE, "caro_stagger_enable first");
+  if (!h->v.stag_S) return fail(CARO_E_STATE, "the engine was not created in staggered mode (caro_config.stagger)");
   if (h->v.n_nets == 2 && !net1) return fail(CARO_E_INVAL, "engine has two nets, net1 is null");
   if (launches < 1) return fail(CARO_E_INVAL, "launches must be >= 1");
   if (batch < 1 || batch > h->v.maxB || batch * variant_lpd(h->var) != 64)
@@ -1934,7 +1962,7 @@ int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int la
 int caro_drain_parked_begin(caro_engine* h, int64_t cap, uint64_t* states, int32_t* players, double* pi, int32_t* z,
                             int64_t* games, void* stream) {
   if (!h || !states || !players || !pi || !z) return fail(CARO_E_INVAL, "null argument");
-  if (!h->v.stag_S) return fail(CARO_E_STATE, "caro_stagger_enable first");
+  if (!h->v.stag_S) return fail(CARO_E_STATE, "the engine was not created in staggered mode (caro_config.stagger)");
   if (h->drain_pending) return fail(CARO_E_STATE, "caro_drain_parked_begin twice without caro_drain_tuples_end");
   hipStream_t st = (hipStream_t)stream;
   if (!h->drain_ev) HIPCHK(hipEventCreateWithFlags(&h->drain_ev, hipEventDisableTiming));
@@ -1945,6 +1973,7 @@ int caro_drain_parked_begin(caro_engine* h, int64_t cap, uint64_t* states, int32
   hipLaunchKernelGGL(k_drain_scan, dim3(1), dim3(1024), 0, st, pv, (long long)cap);
   DISPATCH(h->var, hipLaunchKernelGGL(k_drain_copy<GEO>, dim3(pv.G), dim3(256), 0, st, pv, states, players, pi, z,
                                       games, 0));
+  DISPATCH(h->var, hipLaunchKernelGGL(k_stag_clean<GEO>, dim3(h->v.G * h->v.n_stores), dim3(256), 0, st, h->v));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(h->pinned64 + 8, h->v.dr_tot, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(h->drain_ev, st));
@@ -1966,7 +1995,7 @@ int caro_step(caro_engine* h, const double* uniforms, int32_t* actions, int32_t*
   DISPATCH(h->var, hipLaunchKernelGGL(k_step<GEO>, dim3(h->v.G), dim3(64), 0, (hipStream_t)stream, h->v, uniforms,
                                       actions, done, result));
   prof_end(h, p0, (hipStream_t)stream);
-  if (h->v.ntab == 2)  // drop the nodes the move made unreachable
+  if (h->cfg.evict)  // drop the nodes the move made unreachable
     DISPATCH(h->var, hipLaunchKernelGGL(k_evict<GEO>, dim3(h->v.G), dim3(256), 0, (hipStream_t)stream, h->v));
   HIPCHK(hipGetLastError());
   return 0;

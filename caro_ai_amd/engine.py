@@ -93,6 +93,15 @@ class SelfPlayEngine:
         c.uid_stride = uid_stride if uid_stride is not None else self.G
         c.device_id = self.device.index or 0
         c.evict = 1 if evict else 0
+        # staggered mode (include/caro_hip.h, caro_search_staggered): every game on its own minibatch clock, the ply
+        # inside the tree kernel, finished games parked and restarted in place; search() then runs `searches`
+        # launches, step() has nothing left to do and drain() hands out the parked games
+        self.stagger = bool(stagger)
+        self.stag_S = int(searches_hint)
+        if self.stagger and not self.async_net:
+            raise _lib.CaroError("stagger=True needs device-side evaluators (the fused HIP net or HashNet)")
+        c.stagger = self.stag_S if self.stagger else 0
+        c.stagger_recycle = 1 if stagger_recycle else 0
         self.cfg = c
         self.n_stores = n_stores
         torch.cuda.set_device(self.device)
@@ -113,15 +122,6 @@ class SelfPlayEngine:
         self.net_calls = 0
         self._prof = False
         self._drain_open = False
-        # staggered mode (include/caro_hip.h, caro_stagger_enable): every game on its own minibatch clock, the ply
-        # inside the tree kernel, finished games parked and restarted in place; search() then runs `searches`
-        # launches, step() has nothing left to do and drain() hands out the parked games
-        self.stagger = bool(stagger)
-        if self.stagger:
-            if not self.async_net:
-                raise _lib.CaroError("stagger=True needs device-side evaluators (the fused HIP net or HashNet)")
-            self.stag_S = int(searches_hint)
-            _lib.check(self.L.caro_stagger_enable(self.h, self.stag_S, 1 if stagger_recycle else 0, self._stream()))
 
     def close(self):
         if getattr(self, "h", None):

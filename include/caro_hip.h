@@ -63,6 +63,9 @@ typedef struct caro_config {
   int32_t device_id;
   int32_t evict;              /* 1: after every move drop the nodes that can no longer be reached (boards that do
                                  not contain the new root).  Result-neutral; node_cap then bounds the LIVE nodes. */
+  int32_t stagger;            /* > 0: staggered mode with this many minibatches (mcts_searches) per move -- every game
+                                 on its own minibatch clock, see caro_search_staggered; 0: lock-step */
+  int32_t stagger_recycle;    /* staggered mode: a finished game's slot restarts in-kernel (uid += uid_stride) */
 } caro_config;
 
 const char* caro_last_error(void);
@@ -292,12 +295,11 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
  * same mix of minibatch indices.  Game by game the results are those of caro_search_batch + caro_step: the same
  * minibatches on the same tree with the same noise keys.  Needs the one-wavefront-per-game geometry (batch x lanes
  * per descent = 64: connect four with batch 8), generated noise / move uniforms, no eviction; a fresh engine.
- *   caro_stagger_enable     once, before the first search
+ *   caro_config.stagger     = mcts_searches at caro_engine_create (fixed for the engine's life)
  *   caro_search_staggered   `launches` x (tree kernel -> net kernel); on average every game moves once per
  *                           `searches` launches
  *   caro_drain_parked_begin tuples of the parked games, as caro_drain_tuples_begin (no recycle flag: the slots have
  *                           restarted already); finish with caro_drain_tuples_end */
-int caro_stagger_enable(caro_engine* h, int searches, int recycle, void* stream);
 int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int launches, int batch, float* planes_dev,
                           uint64_t* leaf_keys_dev, float* probs_dev, float* values_dev, void* stream);
 int caro_drain_parked_begin(caro_engine* h, int64_t cap, uint64_t* states_dev, int32_t* players_dev, double* pi_dev,

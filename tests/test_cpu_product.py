@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_layout_matches_header():
     from caro_ai_amd import _lib
-    assert C.sizeof(_lib.CaroConfig) == 96
+    assert C.sizeof(_lib.CaroConfig) == 104
     assert _lib.CaroConfig.alpha.offset == 48 and _lib.CaroConfig.seed.offset == 64
 
 

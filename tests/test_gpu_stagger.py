@@ -119,7 +119,6 @@ def test_staggered_mode_refuses_what_it_cannot_do():
     with pytest.raises(_lib.CaroError):  # eviction uses the second key table
         _engine(game, 8, [_synth(game, "fused")], max_batch=8, stagger=True, searches_hint=5, evict=True, node_cap=256)
     eng = _engine(game, 8, [_synth(game, "fused")], max_batch=8, stagger=True, searches_hint=5)
-    assert eng.L.caro_stagger_enable(eng.h, 5, 1, None) == -71  # already on
     with pytest.raises(_lib.CaroError):  # batch x lanes per descent must be 64
         eng.L.caro_search_staggered.restype  # (binding exists)
         _lib.check(eng.L.caro_search_staggered(eng.h, eng.evaluators[0].h, None, 1, 4, eng.planes.data_ptr(), None,
@@ -127,5 +126,8 @@ def test_staggered_mode_refuses_what_it_cannot_do():
     eng.close()
     g15 = _game_of({"kind": "mnk", "n": 15, "k": 5})
     with pytest.raises(_lib.CaroError):  # 15 x 15 with batch 8 is eight wavefronts per game
-        e = _engine(g15, 4, [_synth(g15, "fused")], max_batch=8, stagger=True, searches_hint=5)
-        e.search(5, 8)
+        _engine(g15, 4, [_synth(g15, "fused")], max_batch=8, stagger=True, searches_hint=5)
+    lock = _engine(game, 8, [_synth(game, "fused")], max_batch=8, searches_hint=5)
+    assert lock.L.caro_search_staggered(lock.h, lock.evaluators[0].h, None, 1, 8, lock.planes.data_ptr(), None,
+                                        lock._probs.data_ptr(), lock._values.data_ptr(), None) == -71  # lock-step engine
+    lock.close()
