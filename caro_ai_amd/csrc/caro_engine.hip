@@ -49,7 +49,7 @@ enum Counter { C_SIMS, C_LEVELS, C_EXPANSIONS, C_TERMINALS, C_DROPPED, C_OVERFLO
 
 struct View {
   GameParams gp;
-  int G, n_stores, n_nets, cap, hcap, A, HW, maxply, maxd, maxB, sbt0, first_mode, ntab;
+  int G, n_stores, n_nets, cap, hcap, A, HW, maxply, maxd, maxB, sbt0, first_mode, ntab, etab;
   float c_puct;
   double alpha, explore;
   uint64_t seed, uid_base, uid_stride;
@@ -128,6 +128,11 @@ __device__ __forceinline__ void store_board(uint64_t* p, const typename R::Board
 // first slot of tree t's live table
 __device__ __forceinline__ size_t tbase(const View& v, int t) {
   return (size_t)(t * v.ntab + (v.ntab == 2 ? v.tbl[t] : 0)) * (size_t)v.hcap;
+}
+// first row of tree t's action rows: they follow the key table only where a second copy exists (etab == 2:
+// eviction moves the survivors' rows; a staggered restart needs a clean KEY table, the rows are rewritten anyway)
+__device__ __forceinline__ size_t ebase(const View& v, int t) {
+  return (size_t)(t * v.etab + (v.etab == 2 ? v.tbl[t] : 0)) * (size_t)v.hcap;
 }
 
 constexpr uint64_t EMPTY_KEY = ~0ULL;  // no board has bit 63 set (C4) / overlapping planes (m,n,k)
@@ -439,7 +444,7 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
   int32_t* pa = v.path_act + ((size_t)g * v.maxB + b) * v.maxd;
   const size_t tb = tbase(v, t);
   const uint64_t* tkeys = v.node_key + tb * KW;
-  const uint32_t* tedges = v.edges + tb * 4 * AP;
+  const uint32_t* tedges = v.edges + ebase(v, t) * 4 * AP;
 
   // the root's row is requested first; the descent's Dirichlet row (only used if the root is in the tree) is
   // generated while it is on its way
@@ -617,7 +622,7 @@ __device__ __forceinline__ void backup_path(const View& v, int t, float value, b
                                             const int32_t* pa, int len) {
   float cur = -value;
   for (int i = len - 1; i >= 0; --i) {
-    uint32_t* row = v.edges + (tbase(v, t) + pn[i]) * 4 * AP;
+    uint32_t* row = v.edges + (ebase(v, t) + pn[i]) * 4 * AP;
     const int a = pa[i];
     const uint32_t nraw = row[a];
     const int n = (int)(nraw & NMASK) + 1;
@@ -671,6 +676,7 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
   const bool overflow = base + nleaf > v.cap;
   const int A = v.A;
   const size_t tb = tbase(v, t);
+  const size_t eb = ebase(v, t);
   // ---- round 1: everything select left behind for descent `lane`
   int my_st = ST_DROPPED, my_len = 0, my_local = 0;
   float my_val = 0.f;
@@ -777,7 +783,7 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
       const int b = idx / AP, a = idx - b * AP;
       const int node = s_node[b];
       if (node < 0) continue;  // not a leaf (a failed insert cannot happen while n_nodes <= cap < hcap)
-      uint32_t* row = v.edges + (tb + node) * 4 * AP;
+      uint32_t* row = v.edges + (eb + node) * 4 * AP;
       row[a] = 0u;
       row[AP + a] = 0u;
       row[2 * AP + a] = 0u;
@@ -799,7 +805,7 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
     bool owner = true;
     for (int k = 0; k < j; ++k) owner = owner && !(e_node[k] == node && e_act[k] == a);
     if (!owner) continue;
-    uint32_t* row = v.edges + (tb + node) * 4 * AP;
+    uint32_t* row = v.edges + (eb + node) * 4 * AP;
     const uint32_t nraw = row[a];
     int cnt = (int)(nraw & NMASK);
     uint32_t strong = nraw & NSTRONG;
@@ -861,7 +867,7 @@ __device__ __forceinline__ void root_policy(const View& v, int g, int t, const t
   constexpr int AP = GEO::AP;
   const int node = probe<R>(v, t, root);
   for (int a = threadIdx.x; a < AP; a += blockDim.x)
-    s_n[a] = (node >= 0 && a < v.A) ? (int)(v.edges[(tbase(v, t) + node) * 4 * AP + a] & NMASK) : 0;
+    s_n[a] = (node >= 0 && a < v.A) ? (int)(v.edges[(ebase(v, t) + node) * 4 * AP + a] & NMASK) : 0;
   __syncthreads();
   __shared__ int s_best;
   __shared__ double s_total;
@@ -1344,7 +1350,7 @@ __global__ void k_lookup(View v, long long M, const int32_t* __restrict__ game, 
   const int node = probe<R>(v, t, b);
   if (threadIdx.x == 0) found[m] = node >= 0;
   if (node < 0) return;
-  const uint32_t* row = v.edges + (tbase(v, t) + node) * 4 * AP;
+  const uint32_t* row = v.edges + (ebase(v, t) + node) * 4 * AP;
   for (int a = threadIdx.x; a < v.A; a += blockDim.x) {
     const size_t o = (size_t)m * v.A + a;
     N[o] = (int)(row[a] & NMASK);
@@ -1380,7 +1386,7 @@ __global__ void k_poke(View v, long long M, const int32_t* __restrict__ game, co
     __syncthreads();
     const int node = s_node;
     if (node >= 0) {
-      uint32_t* row = v.edges + (tbase(v, t) + node) * 4 * AP;
+      uint32_t* row = v.edges + (ebase(v, t) + node) * 4 * AP;
       for (int a = threadIdx.x; a < AP; a += blockDim.x) {
         const size_t o = (size_t)m * v.A + a;
         const bool in = a < v.A;
@@ -1421,7 +1427,7 @@ __global__ void k_dump(View v, int game, int store, long long cap, uint64_t* key
   __syncthreads();
   const long long node = s_out;
   if (node >= cap) return;
-  const uint32_t* row = v.edges + (tbase(v, t) + slot) * 4 * AP;
+  const uint32_t* row = v.edges + (ebase(v, t) + slot) * 4 * AP;
   for (int a = threadIdx.x; a < v.A; a += blockDim.x) {
     const size_t o = (size_t)node * v.A + a;
     N[o] = (int)(row[a] & NMASK);
@@ -1729,7 +1735,8 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   v.maxB = cfg->max_batch;
   v.sbt0 = cfg->steps_before_tau_0;
   v.first_mode = cfg->first_player_mode;
-  v.ntab = (cfg->evict || cfg->stagger > 0) ? 2 : 1;  // second table: eviction's target / the clean table a restarted slot moves to
+  v.ntab = (cfg->evict || cfg->stagger > 0) ? 2 : 1;  // second key table: eviction's target / the clean table a restarted slot moves to
+  v.etab = cfg->evict ? 2 : 1;                          // second copy of the action rows: eviction only
   v.c_puct = cfg->c_puct;
   v.alpha = cfg->alpha;
   v.explore = cfg->explore;
@@ -1746,7 +1753,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
 #define DA(p, n) if ((rc = dalloc(h, &p, (n))) != 0) { caro_engine_destroy(h); return rc; }
   DA(v.tbl, T);
   DA(v.node_key, T * v.ntab * v.hcap * KW);
-  DA(v.edges, T * v.ntab * v.hcap * 4 * AP);
+  DA(v.edges, T * v.etab * v.hcap * 4 * AP);
   DA(v.n_nodes, T);
   DA(v.n_created, T);
   DA(v.root, G * KW);
