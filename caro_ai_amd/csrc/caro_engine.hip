@@ -142,6 +142,43 @@ __device__ __forceinline__ uint32_t home_slot(const View& v, const typename R::B
   return (uint32_t)R::hash(b) & ((uint32_t)v.hcap - 1u);
 }
 
+// Everything the per-game kernels need to know about game g that depends on g alone, loaded in ONE round of
+// independent loads at the top of a kernel (a block is a chain of dependent memory latencies: done -> root / player
+// -> table selector -> first row were four of them).  The fused kernels carry it in registers from the backup
+// through the ply to the descents; whoever changes the game (step_body, park_and_restart) updates both copies.
+template <class GEO>
+struct GameRegs {
+  typename GEO::R::Board root;
+  int done, player, ply, step;
+  int tbl[2], nn[2];  // per store: live key table (0 unless a second one exists), nodes held
+  uint64_t uid;
+};
+template <class GEO>
+__device__ __forceinline__ GameRegs<GEO> load_game(const View& v, int g) {
+  using R = typename GEO::R;
+  GameRegs<GEO> r;
+  r.done = v.done[g];
+  r.player = v.player[g];
+  r.ply = v.ply[g];
+  r.step = v.step[g];
+  r.uid = v.uid[g];
+  r.root = load_board<R>(v.root + (size_t)g * GEO::KW);
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int t = g * v.n_stores + (st < v.n_stores ? st : 0);
+    r.tbl[st] = v.ntab == 2 ? v.tbl[t] : 0;
+    r.nn[st] = v.n_nodes[t];
+  }
+  return r;
+}
+// tbase / ebase with the table selector in hand
+__device__ __forceinline__ size_t tbase_sel(const View& v, int t, int sel) {
+  return (size_t)(t * v.ntab + sel) * (size_t)v.hcap;
+}
+__device__ __forceinline__ size_t ebase_sel(const View& v, int t, int sel) {
+  return (size_t)(t * v.etab + (v.etab == 2 ? sel : 0)) * (size_t)v.hcap;
+}
+
 // `state in self.probs` (lib/mcts.py:160): probe of tree t, returns the node's slot or -1
 template <class R>
 __device__ __forceinline__ int probe_from(const View& v, int t, const typename R::Board& b, uint32_t i) {
@@ -402,9 +439,9 @@ __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, in
 // slot rows in game order by itself (caro_net.hip tile_rows), which keeps the whole path free of any dependence
 // on block arrival order.  (k_encode produces DENSE rows for the step-wise form instead.)
 template <class GEO>
-__device__ __forceinline__ void select_body(const View& v, int B, int mb_index, const double* __restrict__ noise,
-                                            int32_t* __restrict__ rows, float* __restrict__ planes,
-                                            uint64_t* __restrict__ leaf_keys) {
+__device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& gr, int B, int mb_index,
+                                            const double* __restrict__ noise, int32_t* __restrict__ rows,
+                                            float* __restrict__ planes, uint64_t* __restrict__ leaf_keys) {
   using R = typename GEO::R;
   using Board = typename R::Board;
   constexpr int LPD = GEO::LPD, APL = GEO::APL, AP = GEO::AP, KW = GEO::KW;
@@ -420,7 +457,7 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
   __shared__ int s_player[MAXB];
   __shared__ float s_value[MAXB];
 
-  if (v.done[g]) {
+  if (gr.done) {
     if (tid == 0) {
       v.g_nleaf[g] = 0;
       v.g_class[g] = 0;
@@ -431,20 +468,22 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
   unsigned long long st0 = 0, st_noise = 0, st_root = 0, st_loop = 0;
   if (v.dbg) st0 = __builtin_amdgcn_s_memtime();
   Descent<GEO> d;
-  d.cur = load_board<R>(v.root + (size_t)g * KW);
+  d.cur = gr.root;
   d.aux = R::aux_of(v.gp, d.cur);
-  const int player0 = v.player[g];
+  const int player0 = gr.player;
   d.player = player0;
   d.depth = 0;
   d.status = ST_LEAF;
   d.value = 0.0f;
-  const int t = g * v.n_stores + (v.n_stores == 2 ? player0 : 0);
+  const int st_sel = v.n_stores == 2 ? player0 : 0;
+  const int t = g * v.n_stores + st_sel;
   const int A = v.A;
   int32_t* pn = v.path_node + ((size_t)g * v.maxB + b) * v.maxd;
   int32_t* pa = v.path_act + ((size_t)g * v.maxB + b) * v.maxd;
-  const size_t tb = tbase(v, t);
+  const int tsel = st_sel ? gr.tbl[1] : gr.tbl[0];
+  const size_t tb = tbase_sel(v, t, tsel);
   const uint64_t* tkeys = v.node_key + tb * KW;
-  const uint32_t* tedges = v.edges + ebase(v, t) * 4 * AP;
+  const uint32_t* tedges = v.edges + ebase_sel(v, t, tsel) * 4 * AP;
 
   // the root's row is requested first; the descent's Dirichlet row (only used if the root is in the tree) is
   // generated while it is on its way
@@ -458,7 +497,7 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
       nz[j] = a < A ? noise[((size_t)g * B + b) * A + a] : 0.0;
     }
   } else {
-    const uint64_t key = caro_noise_key(v.seed, v.uid[g], (uint32_t)v.ply[g], (uint32_t)(mb_index * B + b));
+    const uint64_t key = caro_noise_key(v.seed, gr.uid, (uint32_t)gr.ply, (uint32_t)(mb_index * B + b));
     noise_group<LPD, APL>(key, l, A, v.alpha, nz);
   }
   if (v.dbg) st_noise = __builtin_amdgcn_s_memtime();
@@ -565,7 +604,8 @@ __device__ __forceinline__ void select_body(const View& v, int B, int mb_index, 
 
 template <class GEO>
 __global__ void k_select(View v, int B, int mb_index, const double* __restrict__ noise) {
-  select_body<GEO>(v, B, mb_index, noise, nullptr, nullptr, nullptr);
+  const GameRegs<GEO> gr = load_game<GEO>(v, blockIdx.x);
+  select_body<GEO>(v, gr, B, mb_index, noise, nullptr, nullptr, nullptr);
 }
 
 // NN planes of the unique leaves, written as dense rows (rows of net 0 first, then net 1).  Every block
@@ -647,7 +687,7 @@ __device__ __forceinline__ void backup_path(const View& v, int t, float value, b
 //   2  per leaf: the key in its home slot, its net value;  3  the path entries (and the priors, off the chain)
 //   4  the edges the owners update.
 template <class GEO>
-__device__ __forceinline__ void expand_body(const View& v, int B, const float* __restrict__ probs,
+__device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, int B, const float* __restrict__ probs,
                                             const float* __restrict__ values) {
   using R = typename GEO::R;
   using Board = typename R::Board;
@@ -667,16 +707,19 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
   __shared__ unsigned char q_strong[MAXB];
   __shared__ int s_nq;
   const int g = blockIdx.x;
-  if (v.done[g]) return;
+  if (gr.done) return;
   const int lane = threadIdx.x;
-  const int t = v.g_tree[g];
+  // the tree the pending minibatch was selected on: the mover's (the ply comes after the backup)
+  const int st_sel = v.n_stores == 2 ? gr.player : 0;
+  const int t = g * v.n_stores + st_sel;
   const int nleaf = v.g_nleaf[g];
   const int off = v.g_off[g];
-  const int base = v.n_nodes[t];
+  const int base = st_sel ? gr.nn[1] : gr.nn[0];
   const bool overflow = base + nleaf > v.cap;
   const int A = v.A;
-  const size_t tb = tbase(v, t);
-  const size_t eb = ebase(v, t);
+  const int tsel = st_sel ? gr.tbl[1] : gr.tbl[0];
+  const size_t tb = tbase_sel(v, t, tsel);
+  const size_t eb = ebase_sel(v, t, tsel);
   // ---- round 1: everything select left behind for descent `lane`
   int my_st = ST_DROPPED, my_len = 0, my_local = 0;
   float my_val = 0.f;
@@ -734,6 +777,8 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
       v.n_created[t] += nleaf;
       atomicAdd(ctr + C_EXPANSIONS, (unsigned long long)nleaf);
     }
+    if (st_sel) gr.nn[1] = base + nleaf;
+    else gr.nn[0] = base + nleaf;
   } else if (lane == 0) {
     atomicAdd(v.counters + (size_t)g * C_N + C_OVERFLOW, 1ull);
   }
@@ -825,7 +870,8 @@ __device__ __forceinline__ void expand_body(const View& v, int B, const float* _
 
 template <class GEO>
 __global__ void k_expand_backup(View v, const float* __restrict__ probs, const float* __restrict__ values) {
-  expand_body<GEO>(v, v.leaf_count[2], probs, values);
+  GameRegs<GEO> gr = load_game<GEO>(v, blockIdx.x);
+  expand_body<GEO>(v, gr, v.leaf_count[2], probs, values);
 }
 
 // Fused form used by caro_search_batch (one 64-lane wavefront per game): expand + backup of the previous
@@ -846,13 +892,14 @@ __global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ n
   }
   unsigned long long t0 = 0;
   if (v.dbg) t0 = __builtin_amdgcn_s_memtime();
+  GameRegs<GEO> gr = load_game<GEO>(v, blockIdx.x);
   if (do_expand) {
-    expand_body<GEO>(v, B, probs, values);
+    expand_body<GEO>(v, gr, B, probs, values);
     __syncthreads();  // the block's own tree updates are visible to its descents
   }
   const unsigned long long t1 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
   if (v.dbg && threadIdx.x == 0 && !do_select) v.dbg[(size_t)blockIdx.x * 8 + 5] = t1 - t0;  // the closing launch: expand + backup alone
-  if (do_select) select_body<GEO>(v, B, mb_index, noise, rows_cur, planes, leaf_keys);
+  if (do_select) select_body<GEO>(v, gr, B, mb_index, noise, rows_cur, planes, leaf_keys);
   if (v.dbg && threadIdx.x == 0 && do_select) {  // a launch in the middle of a move: expand + backup | whole block
     v.dbg[(size_t)blockIdx.x * 8 + 6] = t1 - t0;
     v.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - t0;
@@ -908,49 +955,111 @@ __global__ void k_policy(View v, double* __restrict__ pi_out, int32_t* __restric
 }
 
 // One ply of play_game for game g (utils.py:80-99): pi from the root's visit counts, the history row, the sampled
-// move, game.move, win / draw, the tau switch.  All threads of the block take part; returns (to every thread) 1 if
-// the game has ended with this ply.  s_pi / s_n: AP entries of LDS each.
+// move, game.move, win / draw, the tau switch.  All threads of the block take part; `gr` (the game's scalars, in
+// registers) is read instead of memory and comes back updated; returns (to every thread) 1 if the game has ended
+// with this ply.  s_pi / s_n: AP entries of LDS each.
 template <class GEO>
-__device__ __forceinline__ int step_body(const View& v, int g, const double* __restrict__ uniforms, double* s_pi,
-                                         int* s_n, int32_t* __restrict__ actions, int32_t* __restrict__ done_out,
-                                         int32_t* __restrict__ result_out) {
+__device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr, const double* __restrict__ uniforms,
+                                         double* s_pi, int* s_n, int32_t* __restrict__ actions,
+                                         int32_t* __restrict__ done_out, int32_t* __restrict__ result_out) {
   using R = typename GEO::R;
   using Board = typename R::Board;
-  constexpr int KW = GEO::KW;
-  __shared__ int s_done;
-  Board root = load_board<R>(v.root + (size_t)g * KW);
-  const int player = v.player[g];
-  const int t = g * v.n_stores + (v.n_stores == 2 ? player : 0);
-  root_policy<GEO>(v, g, t, root, s_pi, s_n);
-  const int ply = v.ply[g];
+  constexpr int AP = GEO::AP, KW = GEO::KW;
+  __shared__ int s_action;
+  __shared__ int s_best;
+  __shared__ double s_total;
+  Board root = gr.root;
+  const int player = gr.player;
+  const int st_sel = v.n_stores == 2 ? player : 0;
+  const int t = g * v.n_stores + st_sel;
+  const int tsel = st_sel ? gr.tbl[1] : gr.tbl[0];
+  // get_policy_value (mcts.py:289-313): the root's visit counts -- its key and its N row are requested together from
+  // the home slot (one latency); a collision falls back to the probe sequence
+  {
+    const uint32_t hs = home_slot<R>(v, root);
+    const uint64_t* kp = v.node_key + (tbase_sel(v, t, tsel) + hs) * KW;
+    const uint32_t* erow = v.edges + ebase_sel(v, t, tsel) * 4 * AP;
+    uint32_t nraw[(AP + 63) / 64];
+#pragma unroll
+    for (int j = 0; j < (AP + 63) / 64; ++j) {
+      const int a = threadIdx.x + j * 64;
+      nraw[j] = a < AP && threadIdx.x < 64 ? erow[(size_t)hs * 4 * AP + a] : 0u;
+    }
+    bool eq = true;
+#pragma unroll
+    for (int w = 0; w < KW; ++w) eq = eq && (kp[w] == root.w[w]);
+    int node = (int)hs;
+    if (!eq) {
+      node = kp[0] == EMPTY_KEY ? -1 : probe_from<R>(v, t, root, (hs + 1u) & ((uint32_t)v.hcap - 1u));
+#pragma unroll
+      for (int j = 0; j < (AP + 63) / 64; ++j) {
+        const int a = threadIdx.x + j * 64;
+        nraw[j] = node >= 0 && a < AP && threadIdx.x < 64 ? erow[(size_t)node * 4 * AP + a] : 0u;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < (AP + 63) / 64; ++j) {
+      const int a = threadIdx.x + j * 64;
+      if (a < AP && threadIdx.x < 64) s_n[a] = (node >= 0 && a < v.A) ? (int)(nraw[j] & NMASK) : 0;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tau = (v.sbt0 > 0 && gr.step < v.sbt0) ? 1 : 0;  // utils.py:70,97-99
+    int best = 0;
+    long long tot = 0;
+    for (int a = 0; a < v.A; ++a) {
+      if (s_n[a] > s_n[best]) best = a;
+      tot += s_n[a];
+    }
+    s_best = tau == 0 ? best : -1;
+    s_total = (double)tot;
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < AP; a += blockDim.x) {
+    double p = 0.0;
+    if (a < v.A) p = s_best >= 0 ? (a == s_best ? 1.0 : 0.0) : (double)s_n[a] / s_total;  // mcts.py:305-311
+    s_pi[a] = p;
+  }
+  __syncthreads();
+  const int ply = gr.ply;
   // game_history.append((state, cur_player, probs)), utils.py:82
   const size_t hi = (size_t)g * v.maxply + ply;
   for (int a = threadIdx.x; a < v.A; a += blockDim.x) v.h_pi[hi * v.A + a] = s_pi[a];
   if (threadIdx.x == 0) {
     store_board<R>(v.h_key + hi * KW, root);
     v.h_player[hi] = player;
-    const double u = uniforms ? uniforms[g] : caro_move_uniform(v.seed, v.uid[g], (uint32_t)ply);
-    const int action = caro_sample_index(s_pi, v.A, u);  // np.random.choice(A, p=probs), utils.py:83
-    const bool won = R::move(v.gp, root, action, player);  // utils.py:86
-    store_board<R>(v.root + (size_t)g * KW, root);
-    v.ply[g] = ply + 1;
-    int done = 0, res = 0;
-    if (won) {  // utils.py:87-90
+    const double u = uniforms ? uniforms[g] : caro_move_uniform(v.seed, gr.uid, (uint32_t)ply);
+    s_action = caro_sample_index(s_pi, v.A, u);  // np.random.choice(A, p=probs), utils.py:83
+  }
+  __syncthreads();
+  // every thread replays the move on its own copy of the game (the same integers everywhere)
+  const int action = s_action;
+  const bool won = R::move(v.gp, root, action, player);  // utils.py:86
+  gr.root = root;
+  gr.ply = ply + 1;
+  int done = 0, res = 0, final_r = 0;
+  if (won) {  // utils.py:87-90
+    done = 1;
+    final_r = 1;
+    res = player == 0 ? 1 : -1;
+  } else {
+    gr.player = 1 - player;
+    if (R::full(v.gp, root)) {  // utils.py:93-96
       done = 1;
-      v.final_r[g] = 1;
-      res = player == 0 ? 1 : -1;
     } else {
-      v.player[g] = 1 - player;
-      if (R::full(v.gp, root)) {  // utils.py:93-96
-        done = 1;
-        v.final_r[g] = 0;
-        res = 0;
-      } else {
-        v.step[g] = v.step[g] + 1;  // utils.py:97
-      }
+      gr.step = gr.step + 1;  // utils.py:97
     }
+  }
+  gr.done = done;
+  if (threadIdx.x == 0) {
+    store_board<R>(v.root + (size_t)g * KW, root);
+    v.ply[g] = gr.ply;
+    v.player[g] = gr.player;
+    v.step[g] = gr.step;
     unsigned long long* ctr = v.counters + (size_t)g * C_N;
     if (done) {
+      v.final_r[g] = final_r;
       v.done[g] = 1;
       v.result[g] = res;
       ctr[C_FINISHED] += 1ull;
@@ -959,10 +1068,8 @@ __device__ __forceinline__ int step_body(const View& v, int g, const double* __r
     if (actions) actions[g] = action;
     if (done_out) done_out[g] = done;
     if (result_out) result_out[g] = res;
-    s_done = done;
   }
-  __syncthreads();
-  return s_done;
+  return done;
 }
 
 template <class GEO>
@@ -980,7 +1087,8 @@ __global__ void k_step(View v, const double* __restrict__ uniforms, int32_t* __r
     }
     return;
   }
-  step_body<GEO>(v, g, uniforms, s_pi, s_n, actions, done_out, result_out);
+  GameRegs<GEO> gr = load_game<GEO>(v, g);
+  step_body<GEO>(v, g, gr, uniforms, s_pi, s_n, actions, done_out, result_out);
 }
 
 // ------------------------------------------------------------------ eviction
@@ -1087,56 +1195,69 @@ __global__ void k_reset(View v, const int32_t* __restrict__ first_player) {
 // Moves the finished game of slot g aside (record + history rows) and restarts the slot; false if the previous
 // parked game of this slot has not been drained yet (the game then stays finished and tries again next launch).
 template <class GEO>
-__device__ __forceinline__ bool park_and_restart(const View& v, int g) {
+__device__ __forceinline__ bool park_and_restart(const View& v, int g, GameRegs<GEO>& gr) {
+  using R = typename GEO::R;
   constexpr int KW = GEO::KW;
   if (v.pk_flag[g] == 1) return false;
-  const int n = v.ply[g];
+  const int n = gr.ply;
   const size_t h0 = (size_t)g * v.maxply;
   for (int idx = threadIdx.x; idx < n * v.A; idx += blockDim.x) v.ph_pi[h0 * v.A + idx] = v.h_pi[h0 * v.A + idx];
   for (int idx = threadIdx.x; idx < n * KW; idx += blockDim.x) v.ph_key[h0 * KW + idx] = v.h_key[h0 * KW + idx];
   for (int j = threadIdx.x; j < n; j += blockDim.x) v.ph_player[h0 + j] = v.h_player[h0 + j];
-  const uint64_t uid = v.uid[g];
+  const uint64_t uid = gr.uid;
   if (threadIdx.x == 0) {
     v.pk_ply[g] = n;
     v.pk_final_r[g] = v.final_r[g];
     v.pk_first[g] = v.first[g];
     v.pk_result[g] = v.result[g];
-    v.pk_step[g] = v.step[g];
+    v.pk_step[g] = gr.step;
     v.pk_uid[g] = uid;
     v.pk_flag[g] = 1;
   }
   __syncthreads();  // the live record has been read by every thread
-  if (v.stag_recycle) {
-    // restart without clearing anything on this wave's time: the slot's trees move to their OTHER key table, which
-    // is clean (both are at creation; the one left behind is cleared by k_stag_clean at the next drain, and no slot
-    // restarts twice between two drains: pk_flag above)
-    if (threadIdx.x == 0) {
-      for (int st = 0; st < v.n_stores; ++st) {
+  if (!v.stag_recycle) {
+    if (threadIdx.x == 0) v.done[g] = 2;  // no restart asked for: parked, the slot stays finished
+    gr.done = 2;
+    return false;
+  }
+  // restart without clearing anything on this wave's time: the slot's trees move to their OTHER key table, which is
+  // clean (both are at creation; the one left behind is cleared by k_stag_clean at the next drain, and no slot
+  // restarts twice between two drains: pk_flag above)
+  const uint64_t nuid = uid + v.uid_stride;
+  const int fp = v.first_mode == 2 ? (int)(nuid & 1ull) : v.first_mode;
+  gr.root = R::initial(v.gp);
+  gr.player = fp;
+  gr.ply = 0;
+  gr.step = 0;
+  gr.uid = nuid;
+  gr.done = 0;
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    gr.tbl[st] = 1 - gr.tbl[st];
+    gr.nn[st] = 0;
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {  // unrolled: gr.tbl must stay in registers
+      if (st < v.n_stores) {
         const int t = g * v.n_stores + st;
-        v.tbl[t] = 1 - v.tbl[t];
+        v.tbl[t] = gr.tbl[st];
         v.dirty[t] = 1;
         v.n_nodes[t] = 0;
         v.n_created[t] = 0;
       }
-      const uint64_t nuid = uid + v.uid_stride;
-      const typename GEO::R::Board b0 = GEO::R::initial(v.gp);
-      store_board<typename GEO::R>(v.root + (size_t)g * KW, b0);
-      const int fp = v.first_mode == 2 ? (int)(nuid & 1ull) : v.first_mode;
-      v.player[g] = fp;
-      v.first[g] = fp;
-      v.ply[g] = 0;
-      v.step[g] = 0;
-      v.uid[g] = nuid;
-      v.done[g] = 0;
-      v.result[g] = 0;
-      v.final_r[g] = 0;
     }
-    __syncthreads();
-    return true;
+    store_board<R>(v.root + (size_t)g * KW, gr.root);
+    v.player[g] = fp;
+    v.first[g] = fp;
+    v.ply[g] = 0;
+    v.step[g] = 0;
+    v.uid[g] = nuid;
+    v.done[g] = 0;
+    v.result[g] = 0;
+    v.final_r[g] = 0;
   }
-  if (threadIdx.x == 0) v.done[g] = 2;  // no restart asked for: parked, the slot stays finished
-  __syncthreads();
-  return false;
+  return true;
 }
 
 // The fused tree kernel of the staggered mode (one 64-lane wavefront per game; launch geometry and the slot-row
@@ -1156,7 +1277,12 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
     rows_cur[2] = B;
   }
   const int g = blockIdx.x;
+  const unsigned long long t0 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  // one round of loads for everything that depends on g alone
   const int w = v.wait[g];
+  int lm = v.lm[g];
+  const int pend = v.pend[g];
+  GameRegs<GEO> gr = load_game<GEO>(v, g);
   if (w > 0) {  // not started yet
     if (threadIdx.x == 0) {
       v.wait[g] = w - 1;
@@ -1166,8 +1292,7 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
     }
     return;
   }
-  const int fin = v.done[g];
-  if (fin == 2) {  // parked without restart: nothing left to do in this slot
+  if (gr.done == 2) {  // parked without restart: nothing left to do in this slot
     if (threadIdx.x == 0) {
       v.g_nleaf[g] = 0;
       v.g_class[g] = 0;
@@ -1175,24 +1300,30 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
     }
     return;
   }
-  int lm = v.lm[g];
-  if (v.pend[g]) {
-    expand_body<GEO>(v, B, probs, values);
+  if (pend) {
+    expand_body<GEO>(v, gr, B, probs, values);
     __syncthreads();  // the block's own tree updates are visible to what follows
   }
-  int over = fin == 1;  // finished earlier and could not be parked (its slot's previous game is not drained yet)
+  const unsigned long long t1 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  int over = gr.done == 1;  // finished earlier and could not be parked (its slot's previous game is not drained yet)
   if (!over && lm == v.stag_S) {
-    over = step_body<GEO>(v, g, nullptr, s_pi, s_n, nullptr, nullptr, nullptr);
+    over = step_body<GEO>(v, g, gr, nullptr, s_pi, s_n, nullptr, nullptr, nullptr);
     lm = 0;
   }
   if (over) {
-    if (park_and_restart<GEO>(v, g)) over = 0;  // a new game sits in the slot: its first minibatch follows
+    if (park_and_restart<GEO>(v, g, gr)) over = 0;  // a new game sits in the slot: its first minibatch follows
   }
+  const unsigned long long t2 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
   // select_body returns at once (zero leaves) for a finished game
-  select_body<GEO>(v, B, lm, nullptr, rows_cur, planes, leaf_keys);
+  select_body<GEO>(v, gr, B, lm, nullptr, rows_cur, planes, leaf_keys);
   if (threadIdx.x == 0) {
     v.lm[g] = over ? 0 : lm + 1;
     v.pend[g] = over ? 0 : 1;
+    if (v.dbg) {  // diagnostic stamps (tools/probe_stag.py): ply + park | expand + backup | whole block
+      v.dbg[(size_t)g * 8 + 5] = t2 - t1;
+      v.dbg[(size_t)g * 8 + 6] = t1 - t0;
+      v.dbg[(size_t)g * 8 + 7] = __builtin_amdgcn_s_memtime() - t0;
+    }
   }
 }
 
