@@ -2,6 +2,7 @@
 """Summarise the rocprofv3 runs of tools/profile_r02.sh (gpurun_out/prof_r02/) into profiles/.
 
     python tools/prof_summary.py gpurun_out/prof_r02 r02_a
+    python tools/prof_summary.py gpurun_out/prof_r03 r03_a pmc_r03.json     (tools/profile_r03.sh: + configs 5 and 4)
 
 bench.py plays a 16-game copy of its configuration before the clock starts (first-use costs); its small launches
 are in the traces too.  Only the launches of the full-size engine are summarised: per kernel, the dispatches with
@@ -17,7 +18,7 @@ import os
 import sys
 from collections import defaultdict
 
-SHORT = ["k_tree", "k_net_forward_w", "k_net_forward_3x", "k_net_forward", "k_select", "k_expand_backup", "k_encode",
+SHORT = ["k_tree_stag", "k_tree", "k_net_forward_w", "k_net_forward_3x", "k_net_forward", "k_select", "k_expand_backup", "k_encode",
          "k_step", "k_drain_copy", "k_drain_scan", "k_evict", "k_net_hash"]
 
 
@@ -68,6 +69,8 @@ def main():
                                                           max(v) / 1e3, sum(v) / total))
     print(open(out).read())
     # ---- counters
+    pmc_name = sys.argv[3] if len(sys.argv) > 3 else "pmc_r02.json"
+
     def counters(sub, names):
         acc = []
         for r in rows(os.path.join(src, sub), "*counter_collection.csv"):
@@ -77,43 +80,50 @@ def main():
                             "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
         return full_size(acc, "g")
 
-    fe, wr = counters("pmc_fetch", {"FETCH_SIZE"}), counters("pmc_write", {"WRITE_SIZE"})
-    kernels = {}
-    for k in sorted({r["k"] for r in fe} | {r["k"] for r in wr}):
-        f = [r["v"] for r in fe if r["k"] == k]
-        w = [r["v"] for r in wr if r["k"] == k]
-        fa, wa = sum(f) / max(1, len(f)), sum(w) / max(1, len(w))
-        kernels[k] = {"launches_fetch_pass": len(f), "launches_write_pass": len(w), "FETCH_SIZE_KiB_per_launch": fa,
-                      "WRITE_SIZE_KiB_per_launch": wa, "hbm_bytes_per_launch_raw": (fa + wa) * 1024.0,
-                      "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
-    mf = counters("pmc_mfma", {"SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"})
-    mfma = {}
-    for k in sorted({r["k"] for r in mf}):
-        get = lambda c: [r["v"] for r in mf if r["k"] == k and r["c"] == c]
-        busy, gui = get("SQ_VALU_MFMA_BUSY_CYCLES"), get("GRBM_GUI_ACTIVE")
-        dur = [r["ns"] for r in mf if r["k"] == k and r["c"] == "GRBM_GUI_ACTIVE"]
-        if not busy or not gui:
-            continue
-        b, g = sum(busy) / len(busy), sum(gui) / len(gui)
-        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: kernel cycles = g / 8; 1024 SIMDs each with one MFMA pipe
-        mfma[k] = {"launches": len(busy), "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": b,
-                   "GRBM_GUI_ACTIVE_per_launch_sum_of_8_XCDs": g,
-                   "avg_duration_us_under_the_profiler": sum(dur) / len(dur) / 1e3,
-                   "mfma_busy_fraction": b / (g / 8.0 * 1024.0)}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES "
-                         "GRBM_GUI_ACTIVE (separate passes, each with --kernel-trace only) -- python3 bench.py --steps 3 "
-                         "--warmup 2 --no-cpu-baseline --no-extra-configs --no-profile; launches of the full-size engine",
-               "correction": "read side x2 (gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads); KiB units",
-               "kernels": kernels, "mfma_utilisation": mfma,
-               "mfma_note": "busy cycles of the MFMA pipe summed over the 1024 SIMDs / (kernel cycles x 1024)"},
-              open(os.path.join(root, "profiles", "pmc_r02.json"), "w"), indent=1)
-    for k, v in kernels.items():
-        print("%-18s fetch %10.1f KiB  write %10.1f KiB  -> %12.0f B/launch  (%d launches)" %
-              (k, v["FETCH_SIZE_KiB_per_launch"], v["WRITE_SIZE_KiB_per_launch"], v["hbm_bytes_per_launch"],
-               v["launches_fetch_pass"]))
-    for k, v in mfma.items():
-        print("%-18s MFMA busy %.3f (%.1f us under the profiler)" % (k, v["mfma_busy_fraction"],
-                                                                     v["avg_duration_us_under_the_profiler"]))
+    def section(prefix):
+        fe, wr = counters(prefix + "fetch", {"FETCH_SIZE"}), counters(prefix + "write", {"WRITE_SIZE"})
+        kernels = {}
+        for k in sorted({r["k"] for r in fe} | {r["k"] for r in wr}):
+            f = [r["v"] for r in fe if r["k"] == k]
+            w = [r["v"] for r in wr if r["k"] == k]
+            fa, wa = sum(f) / max(1, len(f)), sum(w) / max(1, len(w))
+            kernels[k] = {"launches_fetch_pass": len(f), "launches_write_pass": len(w), "FETCH_SIZE_KiB_per_launch": fa,
+                          "WRITE_SIZE_KiB_per_launch": wa, "hbm_bytes_per_launch_raw": (fa + wa) * 1024.0,
+                          "hbm_bytes_per_launch": (2.0 * fa + wa) * 1024.0}
+        mf = counters(prefix + "mfma", {"SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"})
+        mfma = {}
+        for k in sorted({r["k"] for r in mf}):
+            get = lambda c: [r["v"] for r in mf if r["k"] == k and r["c"] == c]
+            busy, gui = get("SQ_VALU_MFMA_BUSY_CYCLES"), get("GRBM_GUI_ACTIVE")
+            dur = [r["ns"] for r in mf if r["k"] == k and r["c"] == "GRBM_GUI_ACTIVE"]
+            if not busy or not gui:
+                continue
+            b, g = sum(busy) / len(busy), sum(gui) / len(gui)
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs: kernel cycles = g / 8; 1024 SIMDs each with one MFMA pipe
+            mfma[k] = {"launches": len(busy), "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": b,
+                       "GRBM_GUI_ACTIVE_per_launch_sum_of_8_XCDs": g,
+                       "avg_duration_us_under_the_profiler": sum(dur) / len(dur) / 1e3,
+                       "mfma_busy_fraction": b / (g / 8.0 * 1024.0)}
+        for k, v in kernels.items():
+            print("%s%-18s fetch %10.1f KiB  write %10.1f KiB  -> %12.0f B/launch  (%d launches)" %
+                  (prefix, k, v["FETCH_SIZE_KiB_per_launch"], v["WRITE_SIZE_KiB_per_launch"], v["hbm_bytes_per_launch"],
+                   v["launches_fetch_pass"]))
+        for k, v in mfma.items():
+            print("%s%-18s MFMA busy %.3f (%.1f us under the profiler)" % (prefix, k, v["mfma_busy_fraction"],
+                                                                           v["avg_duration_us_under_the_profiler"]))
+        return {"kernels": kernels, "mfma_utilisation": mfma}
+
+    out_json = {"source": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES "
+                          "GRBM_GUI_ACTIVE (separate passes, each with --kernel-trace only) -- python3 bench.py "
+                          "--no-cpu-baseline --no-extra-configs --no-profile (steps / warm-up: see the script that "
+                          "made the directory, tools/profile_rNN.sh); launches of the full-size engine",
+                "correction": "read side x2 (gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads); KiB units",
+                "mfma_note": "busy cycles of the MFMA pipe summed over the 1024 SIMDs / (kernel cycles x 1024)"}
+    out_json.update(section("pmc_"))
+    for extra in ("config5", "config4"):  # profile_r03.sh: the same three passes on BASELINE configs 5 and 4
+        if os.path.isdir(os.path.join(src, extra + "_fetch")):
+            out_json[extra] = section(extra + "_")
+    json.dump(out_json, open(os.path.join(root, "profiles", pmc_name), "w"), indent=1)
 
 
 if __name__ == "__main__":
