@@ -80,6 +80,7 @@ struct View {
   int32_t* d_status;
   float* d_value;
   int32_t* d_local;
+  int32_t* d_home;      // leaf descents: home slot of the leaf board | bit 31 if that slot was empty when the descent ended
   uint64_t* d_key;
   int32_t* d_player;
   int32_t* g_nleaf;
@@ -178,6 +179,24 @@ __device__ __forceinline__ size_t tbase_sel(const View& v, int t, int sel) {
 __device__ __forceinline__ size_t ebase_sel(const View& v, int t, int sel) {
   return (size_t)(t * v.etab + (v.etab == 2 ? sel : 0)) * (size_t)v.hcap;
 }
+
+// Synchronisation inside a per-game block.  ONE = the block's tree work is done by ONE wavefront (the fused kernels):
+// its lanes run in lock-step, so all that is needed is that earlier memory operations have completed -- no
+// s_barrier, which would also wait for the block's noise wave (k_tree / k_tree_stag) to finish.
+// Nor a wait: the wave's memory instructions are issued in program order and the hardware keeps accesses of one
+// wavefront to the same address in order (LDS: one in-order queue; global: the same path for every lane), which is
+// all a block-local hand-over between lanes of the SAME wave needs -- so nothing stalls until data is really used.
+template <bool ONE>
+__device__ __forceinline__ void block_sync() {
+  if constexpr (ONE) {
+    asm volatile("" ::: "memory");  // the compiler keeps the order of the memory operations around this point
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
+template <bool ONE>
+__device__ __forceinline__ int block_threads() { return ONE ? 64 : (int)blockDim.x; }
 
 // `state in self.probs` (lib/mcts.py:160): probe of tree t, returns the node's slot or -1
 template <class R>
@@ -286,6 +305,7 @@ struct Descent {
   typename GEO::R::Aux aux;
   int player, depth, status;
   float value;
+  uint32_t home;  // where the descent ended outside the tree: home slot of that board | bit 31 if the slot is empty
 };
 
 // One level of find_leaf (lib/mcts.py:123-147) for the descents of a wave.  ROOT: the level at the game's root
@@ -344,7 +364,12 @@ __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, in
       if (node >= 0) load_row<GEO, ROOT>(r, tkeys, tedges, (uint32_t)node, l);
     }
   }
-  if (node < 0) return false;  // not in the tree: this is the leaf (mcts.py:123)
+  if (node < 0) {  // not in the tree: this is the leaf (mcts.py:123)
+    // r.slot is still the board's home slot: expand_body takes it (and whether it is empty) from here instead of
+    // looking again -- nothing touches the tree between a minibatch's descents and its expansion
+    d.home = r.slot | (r.k[0] == EMPTY_KEY ? 0x80000000u : 0u);
+    return false;
+  }
   int nsum = 0;
 #pragma unroll
   for (int j = 0; j < APL; ++j) nsum += (int)(nraw[j] & NMASK);
@@ -438,10 +463,13 @@ __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, in
 // total per net (a sum: the order of the adds does not matter); the net kernel maps its dense tiles onto the
 // slot rows in game order by itself (caro_net.hip tile_rows), which keeps the whole path free of any dependence
 // on block arrival order.  (k_encode produces DENSE rows for the step-wise form instead.)
-template <class GEO>
+// `helper_nz` (fused kernels): the block's noise wave writes this minibatch's Dirichlet rows to LDS ([B][AP] doubles
+// at helper_nz, then the flag behind them); the tree wave picks them up here instead of generating them.
+template <class GEO, bool ONE = false>
 __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& gr, int B, int mb_index,
                                             const double* __restrict__ noise, int32_t* __restrict__ rows,
-                                            float* __restrict__ planes, uint64_t* __restrict__ leaf_keys) {
+                                            float* __restrict__ planes, uint64_t* __restrict__ leaf_keys,
+                                            const double* helper_nz = nullptr, volatile int* helper_flag = nullptr) {
   using R = typename GEO::R;
   using Board = typename R::Board;
   constexpr int LPD = GEO::LPD, APL = GEO::APL, AP = GEO::AP, KW = GEO::KW;
@@ -456,6 +484,7 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
   __shared__ int s_depth[MAXB];
   __shared__ int s_player[MAXB];
   __shared__ float s_value[MAXB];
+  __shared__ uint32_t s_dhome[MAXB];
 
   if (gr.done) {
     if (tid == 0) {
@@ -475,6 +504,7 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
   d.depth = 0;
   d.status = ST_LEAF;
   d.value = 0.0f;
+  d.home = 0u;
   const int st_sel = v.n_stores == 2 ? player0 : 0;
   const int t = g * v.n_stores + st_sel;
   const int A = v.A;
@@ -496,6 +526,10 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
       const int a = l * APL + j;
       nz[j] = a < A ? noise[((size_t)g * B + b) * A + a] : 0.0;
     }
+  } else if (helper_nz) {
+    while (*helper_flag == 0) __builtin_amdgcn_s_sleep(2);  // the noise wave started when this one did: rarely waits
+#pragma unroll
+    for (int j = 0; j < APL; ++j) nz[j] = helper_nz[b * AP + l * APL + j];
   } else {
     const uint64_t key = caro_noise_key(v.seed, gr.uid, (uint32_t)gr.ply, (uint32_t)(mb_index * B + b));
     noise_group<LPD, APL>(key, l, A, v.alpha, nz);
@@ -516,8 +550,9 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
     s_depth[b] = d.depth;
     s_player[b] = d.player;
     s_value[b] = d.value;
+    s_dhome[b] = d.home;
   }
-  __syncthreads();
+  block_sync<ONE>();
   // From here on thread bb < B (all in the first wavefront) speaks for descent bb: planned-set de-duplication
   // (mcts.py:272-278: the first occurrence of a new leaf is kept), ranks and tallies by ballot.
   if (tid < 64) {
@@ -540,7 +575,7 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
     const unsigned long long m_term = __ballot(st == ST_TERMINAL);
     const unsigned long long m_drop = __ballot(st == ST_LEAF && dup);
     int levels, maxdep = 0;
-    if (blockDim.x >= 64) {  // a whole wavefront: cross-lane reduction
+    if (ONE || blockDim.x >= 64) {  // a whole wavefront: cross-lane reduction
       levels = group_sum_i32<64>(dep);
       if (v.dbg) maxdep = group_allreduce_i32<64>(dep, [](int x, int y) { return x > y ? x : y; });
     } else {                 // a partial wavefront (batch x lanes < 64): lanes that do not exist cannot be read
@@ -557,6 +592,7 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
       v.d_local[di] = __popcll(m_first & ((1ull << bb) - 1ull));
       v.d_player[di] = s_player[bb];
       v.path_len[di] = dep;
+      v.d_home[di] = (int32_t)s_dhome[bb];
       store_board<R>(v.d_key + di * KW, key);
       s_first[bb] = first_seen;
     }
@@ -584,7 +620,7 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
       }
     }
   }
-  if (rows) __syncthreads();  // s_first for the plane writers
+  if (rows) block_sync<ONE>();  // s_first for the plane writers
   if (rows) {
     const int HW = v.HW;
     int local = 0;
@@ -596,7 +632,7 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
       for (int w = 0; w < KW; ++w) brd.w[w] = s_key[bb][w];
       const int who = s_player[bb];
       float* dst = planes + (size_t)rowi * 2 * HW;
-      for (int i = tid; i < 2 * HW; i += blockDim.x) dst[i] = R::plane(v.gp, brd, who, i / HW, i % HW);
+      for (int i = tid; i < 2 * HW; i += block_threads<ONE>()) dst[i] = R::plane(v.gp, brd, who, i / HW, i % HW);
       if (leaf_keys && tid < KW) leaf_keys[(size_t)rowi * KW + tid] = s_key[bb][tid];
     }
   }
@@ -686,7 +722,7 @@ __device__ __forceinline__ void backup_path(const View& v, int t, float value, b
 //   1  per descent: status, path length, leaf rank, terminal value, leaf board
 //   2  per leaf: the key in its home slot, its net value;  3  the path entries (and the priors, off the chain)
 //   4  the edges the owners update.
-template <class GEO>
+template <class GEO, bool ONE = false>
 __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, int B, const float* __restrict__ probs,
                                             const float* __restrict__ values) {
   using R = typename GEO::R;
@@ -713,44 +749,63 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
   const int st_sel = v.n_stores == 2 ? gr.player : 0;
   const int t = g * v.n_stores + st_sel;
   const int nleaf = v.g_nleaf[g];
-  const int off = v.g_off[g];
+  const int off = ONE ? g * B : v.g_off[g];  // the fused kernels use slot rows: no load in front of the value loads
   const int base = st_sel ? gr.nn[1] : gr.nn[0];
   const bool overflow = base + nleaf > v.cap;
   const int A = v.A;
   const int tsel = st_sel ? gr.tbl[1] : gr.tbl[0];
   const size_t tb = tbase_sel(v, t, tsel);
   const size_t eb = ebase_sel(v, t, tsel);
-  // ---- round 1: everything select left behind for descent `lane`
+  // ---- round 1: everything select left behind, in ONE round of independent loads (they depend on g and the lane
+  // only): the record of descent `lane` -- with the home slot of its leaf and whether that slot was empty, as the
+  // descent saw it --, the net value of every leaf row of the game, and the first 8 levels of every path
+  // (lane = descent * 8 + level; deeper levels are fetched later, by the few entries that need them)
   int my_st = ST_DROPPED, my_len = 0, my_local = 0;
-  float my_val = 0.f;
+  uint32_t my_home = 0u;
+  float my_val = 0.f, row_val = 0.f;
   Board brd;
 #pragma unroll
   for (int w = 0; w < KW; ++w) brd.w[w] = 0;
+  const bool pre_paths = B <= 8 && block_threads<ONE>() >= 64;
+  __shared__ int s_pn[64], s_pa[64];
+  int pre_n = 0, pre_a = 0;
+  if (pre_paths && lane < 64 && (lane >> 3) < B && (lane & 7) < v.maxd) {
+    const size_t di = (size_t)g * v.maxB + (lane >> 3);
+    pre_n = v.path_node[di * v.maxd + (lane & 7)];
+    pre_a = v.path_act[di * v.maxd + (lane & 7)];
+  }
   if (lane < B) {
     const size_t di = (size_t)g * v.maxB + lane;
     my_st = v.d_status[di];
     my_len = v.path_len[di];
     my_local = v.d_local[di];
     my_val = v.d_value[di];   // meaningful for terminals
+    my_home = (uint32_t)v.d_home[di];
     brd = load_board<R>(v.d_key + di * KW);
+    if ((long long)off + lane < (long long)v.G * v.maxB) row_val = values[off + lane];  // leaf rows off .. off + nleaf - 1
+  }
+  if (pre_paths && lane < 64) {
+    s_pn[lane] = pre_n;
+    s_pa[lane] = pre_a;
   }
   const bool is_leaf = lane < B && my_st == ST_LEAF && !overflow;
-  // ---- round 2: home slot of the leaf, its value
+  // the value of this descent's leaf: row off + my_local, held by lane my_local
+  __shared__ float s_rowval[MAXB];
+  if (lane < B) s_rowval[lane] = row_val;
+  block_sync<ONE>();
   if (lane < B) {
     s_node[lane] = -2;  // not a leaf
     if (is_leaf) {
-      const uint32_t hs = home_slot<R>(v, brd);
-      const uint64_t k0 = v.node_key[(tb + hs) * KW];
-      my_val = values[off + my_local];
-      s_home[lane] = hs;
-      s_free[lane] = k0 == EMPTY_KEY;
+      my_val = s_rowval[my_local];
+      s_home[lane] = my_home & 0x7fffffffu;
+      s_free[lane] = (my_home >> 31) != 0u;
       s_row[lane] = off + my_local;
       s_node[lane] = -1;
 #pragma unroll
       for (int w = 0; w < KW; ++w) s_brd[lane][w] = brd.w[w];
     }
   }
-  __syncthreads();
+  block_sync<ONE>();
   if (!overflow) {
     // _create_node.  The reference inserts the leaves one after another (first-seen order); lane 0 places them in
     // that same order: a leaf whose home slot is free and not taken by an earlier leaf of this minibatch needs no
@@ -798,7 +853,7 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
     q_strong[qpos] = my_st == ST_LEAF;
   }
   if (lane == 0) s_nq = n_term + __popcll(m_leaf);
-  __syncthreads();  // also publishes s_node of the new leaves
+  block_sync<ONE>();  // also publishes s_node of the new leaves
   const int nq = s_nq;
   if (lane == 0) {  // exclusive scan over at most B queue items
     int acc = 0;
@@ -808,23 +863,28 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
     }
     s_total = acc;
   }
-  __syncthreads();
+  block_sync<ONE>();
   const int total = s_total;
   // ---- round 3: the path entries; next to them (off the dependent chain) the rows of the new nodes
   if (total <= MAXE)
-    for (int j = lane; j < total; j += blockDim.x) {
+    for (int j = lane; j < total; j += block_threads<ONE>()) {
       int k = 0;
       while (k + 1 < nq && q_off[k + 1] <= j) ++k;  // queue item of entry j
       const int r = j - q_off[k];                    // r-th entry of that backup, counted from the leaf
       const int i = q_len[k] - 1 - r;
       const size_t di = (size_t)g * v.maxB + q_b[k];
-      e_node[j] = v.path_node[di * v.maxd + i];
-      e_act[j] = (short)v.path_act[di * v.maxd + i];
+      if (pre_paths && i < 8) {  // preloaded in round 1
+        e_node[j] = s_pn[q_b[k] * 8 + i];
+        e_act[j] = (short)s_pa[q_b[k] * 8 + i];
+      } else {
+        e_node[j] = v.path_node[di * v.maxd + i];
+        e_act[j] = (short)v.path_act[di * v.maxd + i];
+      }
       e_val[j] = (r & 1) ? q_val[k] : -q_val[k];     // cur = -value at the leaf's parent, sign flips each ply (mcts.py:238,246)
       e_strong[j] = q_strong[k];
     }
   if (!overflow)
-    for (int idx = lane; idx < B * AP; idx += blockDim.x) {  // lanes over (leaf, action)
+    for (int idx = lane; idx < B * AP; idx += block_threads<ONE>()) {  // lanes over (leaf, action)
       const int b = idx / AP, a = idx - b * AP;
       const int node = s_node[b];
       if (node < 0) continue;  // not a leaf (a failed insert cannot happen while n_nodes <= cap < hcap)
@@ -842,10 +902,10 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
       }
     return;
   }
-  __syncthreads();
+  block_sync<ONE>();
   // ---- round 4: the owners' read-modify-writes
   const int n = total;
-  for (int j = lane; j < n; j += blockDim.x) {
+  for (int j = lane; j < n; j += block_threads<ONE>()) {
     const int node = e_node[j], a = e_act[j];
     bool owner = true;
     for (int k = 0; k < j; ++k) owner = owner && !(e_node[k] == node && e_act[k] == a);
@@ -874,6 +934,29 @@ __global__ void k_expand_backup(View v, const float* __restrict__ probs, const f
   expand_body<GEO>(v, gr, v.leaf_count[2], probs, values);
 }
 
+// The block's NOISE WAVE (fused kernels: 128 threads, wave 1): the Dirichlet rows of this minibatch's descents --
+// pure float64 arithmetic, ~9 k cycles, a quarter of a median block -- are generated here while the tree wave
+// (wave 0) sits in the memory latencies of the backup, and handed over through LDS.  Same lanes, same functions,
+// same bits as the in-line form (select_body without a helper).  `go` = 0: nothing to generate (the flag is set all
+// the same: the tree wave may wait for it).
+template <class GEO>
+__device__ __forceinline__ void noise_wave(const View& v, int B, int go, uint64_t uid, uint32_t ply, int mb,
+                                           double* s_nz, volatile int* s_flag) {
+  constexpr int LPD = GEO::LPD, APL = GEO::APL, AP = GEO::AP;
+  const int lane = threadIdx.x & 63;
+  const int b = lane / LPD, l = lane % LPD;
+  if (go) {
+    double nz[APL];
+    const uint64_t key = caro_noise_key(v.seed, uid, ply, (uint32_t)(mb * B + b));
+    noise_group<LPD, APL>(key, l, v.A, v.alpha, nz);
+#pragma unroll
+    for (int j = 0; j < APL; ++j) s_nz[b * AP + l * APL + j] = nz[j];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) *s_flag = 1;
+}
+
 // Fused form used by caro_search_batch (one 64-lane wavefront per game): expand + backup of the previous
 // minibatch, then the descents of the next one on the updated tree, then row reservation + NN planes -- all
 // per-game work, so one block does it back to back and a minibatch costs two launches (this + the net) instead
@@ -884,6 +967,16 @@ __global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ n
                        const float* __restrict__ values, float* __restrict__ planes, uint64_t* __restrict__ leaf_keys,
                        int32_t* __restrict__ rows_cur, int32_t* __restrict__ rows_next, int do_expand,
                        int do_select) {
+  __shared__ double s_nz[MAXB * 0 + 64 * GEO::APL];  // [B][AP] with B x LPD = 64
+  __shared__ int s_flag;
+  if (threadIdx.x == 0) s_flag = 0;
+  __syncthreads();  // the only s_barrier of the block: the flag is clear before the noise wave can set it
+  if (threadIdx.x >= 64) {  // the noise wave
+    const int g = blockIdx.x;
+    const int go = do_select && !noise && !v.done[g];
+    noise_wave<GEO>(v, B, go, go ? v.uid[g] : 0ull, go ? (uint32_t)v.ply[g] : 0u, mb_index, s_nz, &s_flag);
+    return;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     rows_next[0] = 0;
     rows_next[1] = 0;
@@ -894,12 +987,12 @@ __global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ n
   if (v.dbg) t0 = __builtin_amdgcn_s_memtime();
   GameRegs<GEO> gr = load_game<GEO>(v, blockIdx.x);
   if (do_expand) {
-    expand_body<GEO>(v, gr, B, probs, values);
-    __syncthreads();  // the block's own tree updates are visible to its descents
+    expand_body<GEO, true>(v, gr, B, probs, values);
+    block_sync<true>();  // the block's own tree updates are visible to its descents
   }
   const unsigned long long t1 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
   if (v.dbg && threadIdx.x == 0 && !do_select) v.dbg[(size_t)blockIdx.x * 8 + 5] = t1 - t0;  // the closing launch: expand + backup alone
-  if (do_select) select_body<GEO>(v, gr, B, mb_index, noise, rows_cur, planes, leaf_keys);
+  if (do_select) select_body<GEO, true>(v, gr, B, mb_index, noise, rows_cur, planes, leaf_keys, s_nz, &s_flag);
   if (v.dbg && threadIdx.x == 0 && do_select) {  // a launch in the middle of a move: expand + backup | whole block
     v.dbg[(size_t)blockIdx.x * 8 + 6] = t1 - t0;
     v.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - t0;
@@ -958,7 +1051,7 @@ __global__ void k_policy(View v, double* __restrict__ pi_out, int32_t* __restric
 // move, game.move, win / draw, the tau switch.  All threads of the block take part; `gr` (the game's scalars, in
 // registers) is read instead of memory and comes back updated; returns (to every thread) 1 if the game has ended
 // with this ply.  s_pi / s_n: AP entries of LDS each.
-template <class GEO>
+template <class GEO, bool ONE = false>
 __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr, const double* __restrict__ uniforms,
                                          double* s_pi, int* s_n, int32_t* __restrict__ actions,
                                          int32_t* __restrict__ done_out, int32_t* __restrict__ result_out) {
@@ -1003,7 +1096,7 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
       if (a < AP && threadIdx.x < 64) s_n[a] = (node >= 0 && a < v.A) ? (int)(nraw[j] & NMASK) : 0;
     }
   }
-  __syncthreads();
+  block_sync<ONE>();
   if (threadIdx.x == 0) {
     const int tau = (v.sbt0 > 0 && gr.step < v.sbt0) ? 1 : 0;  // utils.py:70,97-99
     int best = 0;
@@ -1015,24 +1108,24 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
     s_best = tau == 0 ? best : -1;
     s_total = (double)tot;
   }
-  __syncthreads();
-  for (int a = threadIdx.x; a < AP; a += blockDim.x) {
+  block_sync<ONE>();
+  for (int a = threadIdx.x; a < AP; a += block_threads<ONE>()) {
     double p = 0.0;
     if (a < v.A) p = s_best >= 0 ? (a == s_best ? 1.0 : 0.0) : (double)s_n[a] / s_total;  // mcts.py:305-311
     s_pi[a] = p;
   }
-  __syncthreads();
+  block_sync<ONE>();
   const int ply = gr.ply;
   // game_history.append((state, cur_player, probs)), utils.py:82
   const size_t hi = (size_t)g * v.maxply + ply;
-  for (int a = threadIdx.x; a < v.A; a += blockDim.x) v.h_pi[hi * v.A + a] = s_pi[a];
+  for (int a = threadIdx.x; a < v.A; a += block_threads<ONE>()) v.h_pi[hi * v.A + a] = s_pi[a];
   if (threadIdx.x == 0) {
     store_board<R>(v.h_key + hi * KW, root);
     v.h_player[hi] = player;
     const double u = uniforms ? uniforms[g] : caro_move_uniform(v.seed, gr.uid, (uint32_t)ply);
     s_action = caro_sample_index(s_pi, v.A, u);  // np.random.choice(A, p=probs), utils.py:83
   }
-  __syncthreads();
+  block_sync<ONE>();
   // every thread replays the move on its own copy of the game (the same integers everywhere)
   const int action = s_action;
   const bool won = R::move(v.gp, root, action, player);  // utils.py:86
@@ -1201,9 +1294,9 @@ __device__ __forceinline__ bool park_and_restart(const View& v, int g, GameRegs<
   if (v.pk_flag[g] == 1) return false;
   const int n = gr.ply;
   const size_t h0 = (size_t)g * v.maxply;
-  for (int idx = threadIdx.x; idx < n * v.A; idx += blockDim.x) v.ph_pi[h0 * v.A + idx] = v.h_pi[h0 * v.A + idx];
-  for (int idx = threadIdx.x; idx < n * KW; idx += blockDim.x) v.ph_key[h0 * KW + idx] = v.h_key[h0 * KW + idx];
-  for (int j = threadIdx.x; j < n; j += blockDim.x) v.ph_player[h0 + j] = v.h_player[h0 + j];
+  for (int idx = threadIdx.x; idx < n * v.A; idx += 64) v.ph_pi[h0 * v.A + idx] = v.h_pi[h0 * v.A + idx];
+  for (int idx = threadIdx.x; idx < n * KW; idx += 64) v.ph_key[h0 * KW + idx] = v.h_key[h0 * KW + idx];
+  for (int j = threadIdx.x; j < n; j += 64) v.ph_player[h0 + j] = v.h_player[h0 + j];
   const uint64_t uid = gr.uid;
   if (threadIdx.x == 0) {
     v.pk_ply[g] = n;
@@ -1214,7 +1307,7 @@ __device__ __forceinline__ bool park_and_restart(const View& v, int g, GameRegs<
     v.pk_uid[g] = uid;
     v.pk_flag[g] = 1;
   }
-  __syncthreads();  // the live record has been read by every thread
+  block_sync<true>();  // the live record has been read by every thread
   if (!v.stag_recycle) {
     if (threadIdx.x == 0) v.done[g] = 2;  // no restart asked for: parked, the slot stays finished
     gr.done = 2;
@@ -1270,13 +1363,31 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
   constexpr int AP = GEO::AP;
   __shared__ double s_pi[AP];
   __shared__ int s_n[AP];
+  __shared__ double s_nz[64 * GEO::APL];  // [B][AP] with B x LPD = 64
+  __shared__ int s_flag;
+  const int g = blockIdx.x;
+  if (threadIdx.x == 0) s_flag = 0;
+  __syncthreads();  // the only s_barrier of the block: the flag is clear before the noise wave can set it
+  if (threadIdx.x >= 64) {
+    // the noise wave: rows of the minibatch the tree wave is about to select.  A game whose ply is due moves first:
+    // its rows are those of the NEXT ply's minibatch 0 (if the ply ends the game the slot restarts on an empty tree,
+    // or stays finished: no descent gets as far as using a row).
+    const int go = v.wait[g] == 0 && v.done[g] == 0;
+    int lm_h = go ? v.lm[g] : 0;
+    uint32_t ply_h = go ? (uint32_t)v.ply[g] : 0u;
+    if (lm_h == v.stag_S) {
+      lm_h = 0;
+      ply_h += 1u;
+    }
+    noise_wave<GEO>(v, B, go, go ? v.uid[g] : 0ull, ply_h, lm_h, s_nz, &s_flag);
+    return;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     rows_next[0] = 0;
     rows_next[1] = 0;
     rows_next[2] = B;
     rows_cur[2] = B;
   }
-  const int g = blockIdx.x;
   const unsigned long long t0 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
   // one round of loads for everything that depends on g alone
   const int w = v.wait[g];
@@ -1301,13 +1412,13 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
     return;
   }
   if (pend) {
-    expand_body<GEO>(v, gr, B, probs, values);
-    __syncthreads();  // the block's own tree updates are visible to what follows
+    expand_body<GEO, true>(v, gr, B, probs, values);
+    block_sync<true>();  // the block's own tree updates are visible to what follows
   }
   const unsigned long long t1 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
   int over = gr.done == 1;  // finished earlier and could not be parked (its slot's previous game is not drained yet)
   if (!over && lm == v.stag_S) {
-    over = step_body<GEO>(v, g, gr, nullptr, s_pi, s_n, nullptr, nullptr, nullptr);
+    over = step_body<GEO, true>(v, g, gr, nullptr, s_pi, s_n, nullptr, nullptr, nullptr);
     lm = 0;
   }
   if (over) {
@@ -1315,7 +1426,7 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
   }
   const unsigned long long t2 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
   // select_body returns at once (zero leaves) for a finished game
-  select_body<GEO>(v, gr, B, lm, nullptr, rows_cur, planes, leaf_keys);
+  select_body<GEO, true>(v, gr, B, lm, nullptr, rows_cur, planes, leaf_keys, s_nz, &s_flag);
   if (threadIdx.x == 0) {
     v.lm[g] = over ? 0 : lm + 1;
     v.pend[g] = over ? 0 : 1;
@@ -1896,7 +2007,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   DA(v.path_node, G * v.maxB * v.maxd);
   DA(v.path_act, G * v.maxB * v.maxd);
   DA(v.path_len, G * v.maxB);
-  DA(v.d_status, G * v.maxB); DA(v.d_value, G * v.maxB); DA(v.d_local, G * v.maxB); DA(v.d_player, G * v.maxB);
+  DA(v.d_status, G * v.maxB); DA(v.d_value, G * v.maxB); DA(v.d_local, G * v.maxB); DA(v.d_home, G * v.maxB); DA(v.d_player, G * v.maxB);
   DA(v.d_key, G * v.maxB * KW);
   DA(v.g_nleaf, G); DA(v.g_off, G); DA(v.g_tree, G); DA(v.g_class, G); DA(v.g_pack, G);
   DA(v.leaf_count, 4);
@@ -2029,7 +2140,7 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
       h->rows_par ^= 1;
       counts = cur;
       const int p1 = prof_begin(h, PK_SELECT, st);
-      DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(64), 0, st, h->v, batch, mb,
+      DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, mb,
                                           noise ? noise + (size_t)mb * noise_stride : nullptr, probs, values, planes,
                                           leaf_keys, cur, nxt, mb > 0 ? 1 : 0, 1));
       prof_end(h, p1, st);
@@ -2054,7 +2165,7 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
     int32_t* nxt = h->rows + 4 * (h->rows_par ^ 1);
     h->rows_par ^= 1;
     const int p1 = prof_begin(h, PK_EXPAND, st);
-    DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(64), 0, st, h->v, batch, searches,
+    DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, searches,
                                         (const double*)nullptr, probs, values, planes, leaf_keys, cur, nxt, 1, 0));
     prof_end(h, p1, st);
     if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree launch failed"); }
@@ -2081,7 +2192,7 @@ int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int la
     int32_t* nxt = h->rows + 4 * (h->rows_par ^ 1);
     h->rows_par ^= 1;
     const int p1 = prof_begin(h, PK_SELECT, st);
-    DISPATCH(h->var, hipLaunchKernelGGL(k_tree_stag<GEO>, dim3(h->v.G), dim3(64), 0, st, h->v, batch, probs, values,
+    DISPATCH(h->var, hipLaunchKernelGGL(k_tree_stag<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, probs, values,
                                         planes, leaf_keys, cur, nxt));
     prof_end(h, p1, st);
     if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree_stag launch failed"); }

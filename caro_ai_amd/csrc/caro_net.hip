@@ -36,6 +36,7 @@
 
 #include "../../include/caro_hip.h"
 #include "../../include/caro_noise.h"
+#include "caro_net_exp.h"  // experiment switches: every macro is the product behaviour unless -DCARO_EXP=N
 
 namespace cnet {
 
@@ -164,12 +165,7 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
   const float* w_p = STAGED ? b_v2 + 1 : p.w_head + nsmall;
   const float* b_p = w_p + (size_t)A * 2 * HW;
   float* feat = scratch;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
-#if defined(CARO_EXP) && CARO_EXP == 20  // timing experiment: phase stamps of the heads behind the staged block
-  unsigned long long* hst = reinterpret_cast<unsigned long long*>(scratch + HEAD_STAGE_AT + HEAD_STAGE_MAX + 8);
-#define CARO_HST(n) if (tid == 0) hst[n] = __builtin_amdgcn_s_memtime();
-#else
-#define CARO_HST(n)
-#endif
+  CARO_HST_BEGIN(scratch, tid)  // nothing in the product build (caro_net_exp.h)
   CARO_HST(0)
   float* hid = feat + 768;              // [TB][20]
   float* logit = feat + 768 + 20 * 32;  // [TB * A] (TB * A <= 1024, see caro_net_create)
@@ -556,20 +552,9 @@ __device__ __forceinline__ void fetch_heads(const float* hp, int hspan, unsigned
   if (hspan > NT * 4) dma_b128(src + NT, dst + NT * 16);
 }
 
-// timing experiments (tools/build_exp.sh N; the results are wrong, only the clock is read): 21 no chunk barriers,
-// 22 no weight fetches, 23 neither.  Measured at 1434 leaves: trunk 296 k cycles, 293 k / 289 k / 281 k without.  The
-// fetches cost what their 960 KiB per workgroup take of the LDS write port (128 B per cycle: 7.5 k cycles); issuing them
-// in the shadow of the MFMAs instead of in front of a chunk's first burst changed nothing.
-#if defined(CARO_EXP) && (CARO_EXP == 21 || CARO_EXP == 23)
-#define CARO_CHUNK_BARRIER
-#else
-#define CARO_CHUNK_BARRIER __syncthreads();
-#endif
-#if defined(CARO_EXP) && (CARO_EXP == 22 || CARO_EXP == 23)
-#define CARO_FETCH_ON 0
-#else
-#define CARO_FETCH_ON 1
-#endif
+// CARO_CHUNK_BARRIER / CARO_FETCH_ON: the chunk barrier and the weight fetch of the product build; the removal builds
+// of the timing experiments redefine them in caro_net_exp.h (measured at 1434 leaves: trunk 296 k cycles, 293 k / 289 k /
+// 281 k without barriers / fetches / both: the fetches cost what their 960 KiB per workgroup take of the LDS write port).
 template <int KS>
 __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* wbuf, int nb, int tid, int hspan) {
   const float slope = p.slope;
@@ -700,12 +685,6 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
       accM2[e] = 0.f;
       accM3[e] = 0.f;
     }
-    // the per-set addresses (ra ^ granule) are re-formed in every layer: hoisted out of the layer loop they would take
-    // a hundred registers
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int d = 0; d < 3; ++d) asm volatile("" : "+v"(ra[r][d]));
     // the per-set addresses (ra ^ granule) are re-formed in every layer: hoisted out of the layer loop -- as the compiler
     // would -- they take a hundred registers and the kernel spills (4 MB of scratch writes per launch); neither keeping
     // part of them, nor packed adds for the transforms, nor a table of weight addresses changed the trunk's time
@@ -886,6 +865,11 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   // rows of boards this tile does not have, the spare rows and the zero row stay zero for ever; the others are written
   // by conv_in
   for (int k = tid + (R * NF) / 4; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // the wait below leaves exactly this thread's 2 chunks x (WCH / 4 / NT) transfers in flight (conv_in's weights are
+  // the oldest transfer): the immediate is tied to the constants here.  conv_in reads w_in from LDS and b_in from
+  // global memory, so only w_in has to be covered by the 320-lane transfer (what comes along behind it is not used).
+  static_assert(2 * (WCH / 4 / NT) == 8, "s_waitcnt vmcnt(8) below counts 2 chunks x WCH / 4 / NT transfers per thread");
+  static_assert(320 * 4 >= 9 * 2 * NF, "the 320-lane transfer must cover w_in [9][2][64]");
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 2 x 4 chunk transfers of this thread may still be on their way
   int* smap = reinterpret_cast<int*>(win + 1536);  // [TB] plane / output row of every board of this tile
   tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
@@ -910,10 +894,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
     stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
     stamps[4 * blockIdx.x + 2] = t_trunk0 - t_c0;
     stamps[4 * blockIdx.x + 3] = t_trunk1 - t_c0;
-#if defined(CARO_EXP) && CARO_EXP == 20
-    const unsigned long long* hst = reinterpret_cast<const unsigned long long*>(wbuf + HEAD_STAGE_AT + HEAD_STAGE_MAX + 8);
-    stamps[4 * blockIdx.x + 1] = (hst[1] - hst[0]) | (hst[2] - hst[1]) << 20 | (hst[3] - hst[2]) << 40;
-#endif
+    CARO_HST_PUBLISH(stamps, wbuf)  // nothing in the product build
   }
 }
 

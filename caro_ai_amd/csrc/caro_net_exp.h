@@ -1,0 +1,38 @@
+// caro_net_exp.h -- the switches of the net kernel's TIMING EXPERIMENTS, kept out of the product source.
+// The product build (CARO_EXP undefined) gets the plain definitions at the bottom and nothing else.  tools/build_exp.sh N
+// compiles caro_net.hip with -DCARO_EXP=N into caro_ai_amd/libcaro_exp<N>.so (never loaded by the package; the results of
+// the removal builds are WRONG, only the clock is read):
+//   20  phase stamps of the heads (1x1 convolutions | FC stage | softmax), packed into stamp word 1
+//   21  no chunk barriers in the trunk      22  no weight fetches      23  neither
+#ifndef CARO_NET_EXP_H
+#define CARO_NET_EXP_H
+
+#if defined(CARO_EXP) && CARO_EXP == 20
+#define CARO_HST_BEGIN(scratch, tid)                                                                              \
+  unsigned long long* hst = reinterpret_cast<unsigned long long*>((scratch) + HEAD_STAGE_AT + HEAD_STAGE_MAX + 8); \
+  const int hst_tid = (tid);
+#define CARO_HST(n) if (hst_tid == 0) hst[n] = __builtin_amdgcn_s_memtime();
+#define CARO_HST_PUBLISH(stamps, wbuf)                                                                                       \
+  {                                                                                                                          \
+    const unsigned long long* hst = reinterpret_cast<const unsigned long long*>((wbuf) + HEAD_STAGE_AT + HEAD_STAGE_MAX + 8); \
+    (stamps)[4 * blockIdx.x + 1] = (hst[1] - hst[0]) | (hst[2] - hst[1]) << 20 | (hst[3] - hst[2]) << 40;                    \
+  }
+#else
+#define CARO_HST_BEGIN(scratch, tid)
+#define CARO_HST(n)
+#define CARO_HST_PUBLISH(stamps, wbuf)
+#endif
+
+#if defined(CARO_EXP) && (CARO_EXP == 21 || CARO_EXP == 23)
+#define CARO_CHUNK_BARRIER
+#else
+#define CARO_CHUNK_BARRIER __syncthreads();
+#endif
+
+#if defined(CARO_EXP) && (CARO_EXP == 22 || CARO_EXP == 23)
+#define CARO_FETCH_ON 0
+#else
+#define CARO_FETCH_ON 1
+#endif
+
+#endif

@@ -83,26 +83,27 @@ def play_game(game, mcts_stores, replay_buffer: Union[collections.deque, None], 
 
 def play_games(game, n_games, replay_buffer, net1, net2=None, steps_before_tau_0=10, mcts_searches=10,
                mcts_batch_size=8, n_stores=None, concurrent=None, seed=0, uid_base=0, device="cuda:0",
-               first_player_mode=2, engine=None, return_stats=False):
+               first_player_mode=2, return_stats=False):
     """Play the `n_games` games with uids uid_base .. uid_base + n_games - 1 on the HIP engine, `concurrent` at a time.
 
     net2 given -> arena: player 0 is net1, player 1 is net2, one tree per player (play.py:47 semantics,
     n_stores=2); otherwise self-play with one shared tree per game (train.py:43-47).
     Returns the list of net1 results ordered by uid (which games are played, and how each one goes, depends on
     the uids and the seed only -- not on `concurrent`); with return_stats=True also a dict with steps, counters
-    and timing."""
+    and timing.  When n_games is not a multiple of `concurrent`, slots that run ahead may start up to
+    concurrent - 1 games beyond the wanted range: they are played while the last wanted games finish, their results
+    and tuples are dropped, but stats['counters'] / 'speed_nodes' include their work."""
     from caro_ai_amd.engine import SelfPlayEngine
     arena = net2 is not None and net2 is not net1
     if n_stores is None:
         n_stores = 2 if arena else 1
     G = int(concurrent or min(n_games, 1024))
     G = max(1, min(G, n_games))
-    own = engine is None
-    if own:
-        engine = SelfPlayEngine(game, G, net1=net1, net2=net2 if arena else None, n_stores=n_stores,
-                                max_batch=mcts_batch_size, steps_before_tau_0=steps_before_tau_0, seed=seed,
-                                uid_base=uid_base, first_player_mode=first_player_mode, device=device,
-                                searches_hint=mcts_searches)
+    # the bookkeeping below (slot g plays uids uid_base + g, + G, ...) is that of an engine made here, fresh
+    engine = SelfPlayEngine(game, G, net1=net1, net2=net2 if arena else None, n_stores=n_stores,
+                            max_batch=mcts_batch_size, steps_before_tau_0=steps_before_tau_0, seed=seed,
+                            uid_base=uid_base, first_player_mode=first_player_mode, device=device,
+                            searches_hint=mcts_searches)
     t0 = time.time()
     c0 = engine.counters()
     last_uid = uid_base + n_games - 1
@@ -143,13 +144,11 @@ def play_games(game, n_games, replay_buffer, net1, net2=None, steps_before_tau_0
     results = [outcome[u][0] for u in sorted(outcome)]
     steps = [outcome[u][1] for u in sorted(outcome)]
     if not return_stats:
-        if own:
-            engine.close()
+        engine.close()
         return results
     c1 = engine.counters()
     dt = time.time() - t0
     stats = {"steps": steps, "seconds": dt, "counters": {k: c1[k] - c0[k] for k in c1},
              "speed_nodes": (c1["expansions"] - c0["expansions"]) / dt, "speed_steps": sum(steps) / dt}
-    if own:
-        engine.close()
+    engine.close()
     return results, stats

@@ -51,6 +51,17 @@ def init(backend=None):
     return rank, local_rank, world
 
 
+def local_device(local_rank=None):
+    """the GPU of this rank: cuda:<local_rank>, wrapped onto the GPUs that exist when several ranks share one
+    (gloo rehearsal of the N > 1 path on a 1-GPU box, CARO_DIST_BACKEND=gloo / CARO_SHARE_GPU=1)"""
+    if local_rank is None:
+        local_rank = env_rank()[1]
+    n = torch.cuda.device_count()
+    if os.environ.get("CARO_SHARE_GPU"):
+        return "cuda:0"
+    return "cuda:%d" % (local_rank % n if n > 0 else local_rank)
+
+
 def shard(n_games_per_rank, rank, world):
     """uid layout: game slot g of rank r starts as uid r*G + g and is recycled with
     stride world*G, so every uid is played exactly once whatever the world size."""

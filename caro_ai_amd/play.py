@@ -79,7 +79,7 @@ def meet(game, first, second, rounds, seed, uid_base, device):
 def main(argv=None):
     args = parse_args(argv)
     rank, local_rank, world = parallel.init()
-    device = "cuda:%d" % (local_rank if world > 1 else 0)  # the engine is GPU only; --cuda is accepted as is
+    device = parallel.local_device(local_rank) if world > 1 else "cuda:0"  # the engine is GPU only; --cuda is accepted as is
     game = game_provider.get_game(args)
     agents = [(path, load_checkpoint(game, path, device)) for path in args.models]
 

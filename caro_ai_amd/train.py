@@ -159,7 +159,13 @@ def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="c
     player; returns challenger_win / (wins + losses + draws)  (train.py:120-149).
     With several ranks each plays a contiguous share of the rounds (round = game uid, so the set of games is the
     single-rank one) and the three counters are all-reduced: every rank gets the same ratio and takes the same
-    promote / keep decision."""
+    promote / keep decision.
+    DEVIATIONS from the reference's evaluate (declared): (1) the reference builds ONE pair of
+    stores before its loop and reuses it for all rounds (train.py:134-141), so later rounds search on statistics
+    left by earlier ones; here every round is an independent game with fresh trees (play.py:47 semantics, SURVEY
+    Q3) -- that is what lets the rounds run concurrently and shard across ranks; (2) the reference draws the
+    opening side with np.random.choice(2) per round, here it alternates with the round's uid (uid & 1), so a run
+    is reproducible.  The promote / keep decision can therefore differ from the reference's for the same nets."""
     from caro_ai_amd.lib.utils import play_games
     rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
     lo, n = parallel.shard_rounds(rounds, rank, world)
@@ -201,7 +207,7 @@ def parse_args(argv=None):
 def main(argv=None):
     args = parse_args(argv)
     rank, local_rank, world = parallel.init()
-    device = "cuda:%d" % local_rank
+    device = parallel.local_device(local_rank)
     saves_path = os.path.join(args.saves, args.name)
     if rank == 0:
         os.makedirs(saves_path, exist_ok=True)

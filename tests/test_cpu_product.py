@@ -160,3 +160,32 @@ def test_batched_dirichlet_consumes_numpy_stream_like_single_calls():
         many = np.random.dirichlet([0.3] * A, size=40)
         after_many = np.random.random()
         assert np.array_equal(one.view(np.uint64), many.view(np.uint64)) and after_one == after_many
+
+
+def test_net_kernel_touches_m0_only_in_front_of_its_lds_dma():
+    """caro_net.hip sets M0 by hand in front of every `global_load_lds_dwordx4` (inline asm, M0 not on the clobber
+    list: ADVICE r2).  That is safe as long as the COMPILER never keeps a value of its own in M0 -- checked on the
+    built gfx950 code object: every instruction that names m0 is an `s_mov_b32 m0, ...` whose next memory instruction
+    is the LDS DMA it belongs to."""
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "caro_ai_amd", "csrc", "caro_net.hip.o")
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
+        pytest.skip("needs the built object and the ROCm llvm tools")
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "net.fatbin"), os.path.join(tmp, "net.co")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj,
+                               os.path.join(tmp, "copy.o")])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        dis = subprocess.check_output([os.path.join(llvm, "llvm-objdump"), "-d", co], text=True)
+    ins = [ln.split("//")[0].split() for ln in dis.splitlines() if ln.startswith("\t") or ln.startswith("  ")]
+    ins = [i for i in ins if i]
+    uses = [k for k, i in enumerate(ins) if any(tok.strip(",") == "m0" for tok in i[1:])]
+    assert len(uses) > 20, "no M0 traffic found: did the kernel change its DMA form?"
+    for k in uses:
+        assert ins[k][0] == "s_mov_b32" and ins[k][1].strip(",") == "m0", " ".join(ins[k])
+        nxt = next(i[0] for i in ins[k + 1:k + 6] if i[0] != "s_nop")
+        assert nxt == "global_load_lds_dwordx4", (" ".join(ins[k]), nxt)

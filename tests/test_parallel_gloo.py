@@ -287,3 +287,47 @@ def test_sharded_evaluate_equals_single_rank():
     single = train.evaluate(game, nets[0], nets[1], rounds=10, device="cuda:0", seed=4)
     assert res[0] == res[1] == single
     assert round(single * 10) == single * 10
+
+
+def _play_cli_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), CARO_DIST_BACKEND="gloo")
+    from caro_ai_amd import play
+    from tests.conftest import GOLDEN
+    a = os.path.join(GOLDEN, "weights", "best_026_12000.dat")
+    b = os.path.join(GOLDEN, "weights", "best_025_10600.dat")
+    agents, pairs = play.main(["-g", "0", "--cuda", a, b, "-r", "6"])
+    q.put((rank, {os.path.basename(k): v for k, v in agents.items()},
+           {(os.path.basename(i), os.path.basename(j)): v for (i, j), v in pairs.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_play_cli_two_ranks_on_one_gpu_equals_single_rank():
+    """play.py's main() launched as two gloo ranks on a ONE-GPU box (LOCAL_RANK 1 has no cuda:1: the device pick
+    wraps onto the GPUs that exist, parallel.local_device): the rounds are split over the ranks, the W/L/D counters
+    all-reduced, and both ranks print the single-rank table (the CLI path of the sharded arena)."""
+    from caro_ai_amd import play
+    from tests.conftest import GOLDEN
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_play_cli_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, agents, pairs = q.get(timeout=300)
+        res[rank] = (agents, pairs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]
+    a = os.path.join(GOLDEN, "weights", "best_026_12000.dat")
+    b = os.path.join(GOLDEN, "weights", "best_025_10600.dat")
+    agents, pairs = play.main(["-g", "0", "--cuda", a, b, "-r", "6"])
+    assert res[0][0] == {os.path.basename(k): v for k, v in agents.items()}
+    assert res[0][1] == {(os.path.basename(i), os.path.basename(j)): v for (i, j), v in pairs.items()}
+    assert sum(res[0][1][("best_026_12000.dat", "best_025_10600.dat")]) == 6
