@@ -745,6 +745,10 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
   const int g = blockIdx.x;
   if (gr.done) return;
   const int lane = threadIdx.x;
+  // diagnostic stamps (tools/probe_stag.py --expand): cycles at the phase boundaries of this function, game g
+  unsigned long long* xs = v.dbg ? v.dbg + ((size_t)v.G + g) * 8 : nullptr;
+#define CARO_XS(n) if (xs && lane == 0) xs[n] = __builtin_amdgcn_s_memtime();
+  CARO_XS(0)
   // the tree the pending minibatch was selected on: the mover's (the ply comes after the backup)
   const int st_sel = v.n_stores == 2 ? gr.player : 0;
   const int t = g * v.n_stores + st_sel;
@@ -806,11 +810,31 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
     }
   }
   block_sync<ONE>();
+  CARO_XS(1)  // round 1 has arrived, leaves published
+  const bool single_wave = ONE || blockDim.x == 64;
   if (!overflow) {
-    // _create_node.  The reference inserts the leaves one after another (first-seen order); lane 0 places them in
-    // that same order: a leaf whose home slot is free and not taken by an earlier leaf of this minibatch needs no
-    // memory access at all, only collisions walk the probe sequence.  Slot choice = sequential insertion.
-    if (lane == 0) {
+    // _create_node.  The reference inserts the leaves one after another (first-seen order): a leaf whose home slot is
+    // free and not taken by an earlier leaf of this minibatch lands in its home slot, anything else walks the probe
+    // sequence.  Slot choice = sequential insertion.  The common case -- every leaf meets a free home slot of its own
+    // -- needs no sequence at all: each leaf's lane writes its key.  Otherwise lane 0 places them one by one.
+    bool all_fast = false;
+    if (single_wave) {
+      bool clash = false;
+      for (int bb = 0; bb < B; ++bb) {
+        const int ob = __shfl((int)is_leaf, bb);
+        const uint32_t oh = (uint32_t)__shfl((int)(my_home & 0x7fffffffu), bb);
+        clash = clash || (bb < lane && ob && oh == (my_home & 0x7fffffffu));
+      }
+      all_fast = __ballot(is_leaf && ((my_home >> 31) == 0u || clash)) == 0ull;
+    }
+    if (all_fast) {
+      if (is_leaf) {
+        uint64_t* k = v.node_key + (tb + (my_home & 0x7fffffffu)) * KW;
+#pragma unroll
+        for (int w = KW - 1; w >= 0; --w) k[w] = brd.w[w];
+        s_node[lane] = (int)(my_home & 0x7fffffffu);
+      }
+    } else if (lane == 0) {
       for (int b = 0; b < B; ++b) {
         if (s_node[b] == -2) continue;
         bool fast = s_free[b] != 0;
@@ -827,9 +851,11 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
           s_node[b] = insert_key<R>(v, t, lb);
         }
       }
+    }
+    if (lane == 0) {
       unsigned long long* ctr = v.counters + (size_t)g * C_N;
       v.n_nodes[t] = base + nleaf;
-      v.n_created[t] += nleaf;
+      atomicAdd(v.n_created + t, nleaf);  // no return value: nothing waits for it
       atomicAdd(ctr + C_EXPANSIONS, (unsigned long long)nleaf);
     }
     if (st_sel) gr.nn[1] = base + nleaf;
@@ -837,6 +863,7 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
   } else if (lane == 0) {
     atomicAdd(v.counters + (size_t)g * C_N + C_OVERFLOW, 1ull);
   }
+  CARO_XS(2)  // leaves inserted
   // Flatten the backup queue, lane-parallel.  Queue order (reference): terminals by sim index, then new
   // leaves by first-seen index; inside one backup from the leaf upwards.
   const unsigned long long m_term = __ballot(lane < B && my_st == ST_TERMINAL);
@@ -864,6 +891,7 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
     s_total = acc;
   }
   block_sync<ONE>();
+  CARO_XS(3)  // queue flattened
   const int total = s_total;
   // ---- round 3: the path entries; next to them (off the dependent chain) the rows of the new nodes
   if (total <= MAXE)
@@ -883,6 +911,7 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
       e_val[j] = (r & 1) ? q_val[k] : -q_val[k];     // cur = -value at the leaf's parent, sign flips each ply (mcts.py:238,246)
       e_strong[j] = q_strong[k];
     }
+  CARO_XS(4)  // path entries listed
   if (!overflow)
     for (int idx = lane; idx < B * AP; idx += block_threads<ONE>()) {  // lanes over (leaf, action)
       const int b = idx / AP, a = idx - b * AP;
@@ -903,8 +932,76 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
     return;
   }
   block_sync<ONE>();
+  CARO_XS(5)  // rows of the new nodes written
   // ---- round 4: the owners' read-modify-writes
   const int n = total;
+  if (single_wave && n <= 128) {
+    // One wavefront, at most two entries per lane (j0 = lane, j1 = lane + 64).  The entries of one edge are found by
+    // matching: the first entry not grouped yet is broadcast, a ballot marks its equals (bit = entry index), the lane
+    // holding that first entry becomes the owner and keeps the two masks.  One round per DISTINCT edge, a few scalar
+    // instructions each -- the quadratic search of the general form below cost the slowest blocks 20 k cycles.
+    const int j0 = lane, j1 = lane + 64;
+    const bool v0 = j0 < n, v1 = j1 < n;
+    const int key0 = v0 ? (e_node[j0] << 8) | (int)(unsigned short)e_act[j0] : -1;
+    const int key1 = v1 ? (e_node[j1] << 8) | (int)(unsigned short)e_act[j1] : -1;
+    unsigned long long todo0 = __ballot(v0), todo1 = __ballot(v1);
+    bool own0 = false, own1 = false;
+    unsigned long long g0m0 = 0ull, g0m1 = 0ull, g1m1 = 0ull;
+    while (todo0 | todo1) {
+      const bool lo = todo0 != 0ull;
+      const int lead = lo ? __ffsll((unsigned long long)todo0) - 1 : __ffsll((unsigned long long)todo1) - 1;
+      const int k = lo ? __builtin_amdgcn_readlane(key0, lead) : __builtin_amdgcn_readlane(key1, lead);
+      const unsigned long long m0 = __ballot(v0 && key0 == k);
+      const unsigned long long m1 = __ballot(v1 && key1 == k);
+      if (lane == lead) {
+        if (lo) { own0 = true; g0m0 = m0; g0m1 = m1; }
+        else { own1 = true; g1m1 = m1; }
+      }
+      todo0 &= ~m0;
+      todo1 &= ~m1;
+    }
+    // the owners' rows are requested together, then each owner adds its entries in queue order (ascending index)
+    uint32_t* row0 = own0 ? v.edges + (eb + (key0 >> 8)) * 4 * AP : nullptr;
+    uint32_t* row1 = own1 ? v.edges + (eb + (key1 >> 8)) * 4 * AP : nullptr;
+    const int a0 = key0 & 0xff, a1 = key1 & 0xff;
+    uint32_t n0 = 0u, n1 = 0u, w0 = 0u, w1 = 0u;
+    if (own0) { n0 = row0[a0]; w0 = row0[AP + a0]; }
+    if (own1) { n1 = row1[a1]; w1 = row1[AP + a1]; }
+    if (own0) {
+      int cnt = (int)(n0 & NMASK);
+      uint32_t strong = n0 & NSTRONG;
+      float w = __uint_as_float(w0);
+      for (unsigned long long m = g0m0; m; m &= m - 1ull) {
+        const int e = __ffsll(m) - 1;
+        cnt += 1;
+        w = w + e_val[e];
+        if (e_strong[e]) strong = NSTRONG;
+      }
+      for (unsigned long long m = g0m1; m; m &= m - 1ull) {
+        const int e = 64 + __ffsll(m) - 1;
+        cnt += 1;
+        w = w + e_val[e];
+        if (e_strong[e]) strong = NSTRONG;
+      }
+      row0[a0] = (uint32_t)cnt | strong;
+      row0[AP + a0] = __float_as_uint(w);
+      row0[2 * AP + a0] = __float_as_uint(w / (float)cnt);
+    }
+    if (own1) {
+      int cnt = (int)(n1 & NMASK);
+      uint32_t strong = n1 & NSTRONG;
+      float w = __uint_as_float(w1);
+      for (unsigned long long m = g1m1; m; m &= m - 1ull) {
+        const int e = 64 + __ffsll(m) - 1;
+        cnt += 1;
+        w = w + e_val[e];
+        if (e_strong[e]) strong = NSTRONG;
+      }
+      row1[a1] = (uint32_t)cnt | strong;
+      row1[AP + a1] = __float_as_uint(w);
+      row1[2 * AP + a1] = __float_as_uint(w / (float)cnt);
+    }
+  } else
   for (int j = lane; j < n; j += block_threads<ONE>()) {
     const int node = e_node[j], a = e_act[j];
     bool owner = true;
@@ -926,6 +1023,9 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
     row[AP + a] = __float_as_uint(w);
     row[2 * AP + a] = __float_as_uint(w / (float)cnt);  // value_avg = value / visit_count
   }
+  CARO_XS(6)  // backups applied
+  if (xs && lane == 0) xs[7] = (unsigned long long)total;
+#undef CARO_XS
 }
 
 template <class GEO>
@@ -2331,8 +2431,8 @@ int caro_debug_stamps(caro_engine* h, int on) {
   if (!h) return fail(CARO_E_INVAL, "null engine");
   if (on && !h->v.dbg) {
     void* q = nullptr;
-    HIPCHK(hipMalloc(&q, (size_t)h->v.G * 8 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(q, 0, (size_t)h->v.G * 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&q, (size_t)h->v.G * 16 * sizeof(unsigned long long)));  // [G][8] block stamps, then [G][8] of expand_body
+    HIPCHK(hipMemset(q, 0, (size_t)h->v.G * 16 * sizeof(unsigned long long)));
     h->allocs.push_back(q);
     h->v.dbg = (unsigned long long*)q;
   } else if (!on) {
@@ -2342,7 +2442,7 @@ int caro_debug_stamps(caro_engine* h, int on) {
 }
 int caro_debug_read(caro_engine* h, uint64_t* out_host, int64_t n_u64, void* stream) {
   if (!h || !out_host || !h->v.dbg) return fail(CARO_E_INVAL, "no stamp buffer");
-  if (n_u64 > (int64_t)h->v.G * 8) n_u64 = (int64_t)h->v.G * 8;
+  if (n_u64 > (int64_t)h->v.G * 16) n_u64 = (int64_t)h->v.G * 16;
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   HIPCHK(hipMemcpy(out_host, h->v.dbg, n_u64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return 0;

@@ -21,9 +21,14 @@ for rep in range(3):
     _lib.check(L.caro_search_staggered(eng.h, nets[0], nets[1], 1, B, C.c_void_p(eng.planes.data_ptr()),
                                        C.c_void_p(eng.leaf_keys.data_ptr()), C.c_void_p(eng._probs.data_ptr()),
                                        C.c_void_p(eng._values.data_ptr()), eng._stream()))
-    out = np.zeros(G * 8, np.uint64)
+    out = np.zeros(G * 16, np.uint64)
     _lib.check(L.caro_debug_read(eng.h, out.ctypes.data, out.size, None))
-    d = out.reshape(G, 8).astype(np.float64)
+    d = out[:G * 8].reshape(G, 8).astype(np.float64)
+    x = out[G * 8:].reshape(G, 8).astype(np.float64)  # expand_body: stamps at its phase boundaries, entry count
+    ok = x[:, 6] > x[:, 0]
+    ph = np.diff(x[ok, :7], axis=1)
+    print("   expand_body phases (median / p90 / max): round-1 loads %s | insert %s | flatten %s | entries %s | rows %s | owners + edges %s | queue entries %s"
+          % tuple([np.percentile(ph[:, i], [50, 90, 100]).round(0) for i in range(6)] + [np.percentile(x[ok, 7], [50, 90, 100])]))
     noise, loop, end, maxd = d[:, 0], d[:, 2], d[:, 3], d[:, 4]
     step, exp, whole = d[:, 5], d[:, 6], d[:, 7]
     st = step > 500
