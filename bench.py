@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
 MFMA_BF16_PEAK_TFS = 2500.0 # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
-PMC_FILE = os.path.join("profiles", "pmc_r02.json")
+PMC_FILE = os.path.join("profiles", "pmc_r03.json")
 CPU_RATIO_FILE = os.path.join("profiles", "cpu_ratio_r03.json")
 NET_KERNEL = {"hip": "k_net_forward", "hipw": "k_net_forward_w", "hip3x": "k_net_forward_3x"}
 
@@ -60,10 +60,17 @@ def host_cores():
     return n
 
 
-def load_pmc():
-    """HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of this command), by kernel"""
+def load_pmc(section=None):
+    """HBM bytes per launch and MFMA-busy fraction from the committed PMC passes (separate rocprofv3 --pmc runs of
+    this command, tools/profile_r03.sh), by kernel; section = None (headline) | "config5" | "config4" """
     try:
-        return {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(os.path.join(ROOT, PMC_FILE)))["kernels"].items()}
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
+        d = d[section] if section else d
+        out = {k: {"hbm": v["hbm_bytes_per_launch"]} for k, v in d["kernels"].items()}
+        for k, v in d.get("mfma_utilisation", {}).items():
+            out.setdefault(k, {})["mfma_busy"] = v["mfma_busy_fraction"]
+            out[k]["us_under_profiler"] = v["avg_duration_us_under_the_profiler"]
+        return out
     except Exception:
         return {}
 
@@ -331,14 +338,18 @@ class Leg:
         args, game, G, S, B = self.args, self.game, self.G, self.S, self.B
         exp_all, sims_all, levels_all, plies_all, fin_all = tot
         n_streams = self.n_streams
-        pmc = load_pmc() if self.game_name == "c4" and G == 1024 and not self.arena else {}
+        section = None if (self.game_name == "c4" and G == 1024 and not self.arena and S == 25) else \
+            "config5" if (self.arena and G == 512 and S == 100) else \
+            "config4" if (self.game_name == "gomoku15" and G == 1024 and S == 50) else "none"
+        pmc = load_pmc(section) if section != "none" else {}
         A, KW, HW = game.action_space, game.key_words, game.obs_shape[1] * game.obs_shape[2]
         bytes_per_level = 12 * A + 8 * KW + 28            # N,Q,P rows + key probe + backup RMW
         bytes_per_exp = 16 * HW + 20 * A + 8 * KW + 12
         # FLOPs of one leaf through lib/model.py Net (2 x MAC): conv_in, 5 residual 3x3 convs, 1x1 heads, FC heads
         flops_per_leaf = 2.0 * (HW * 64 * 18 + 5 * HW * 64 * 576 + HW * 3 * 64 + 20 * HW + 20 + 2 * HW * A)
-        traffic_note = ("HBM bytes per launch from %s (separate rocprofv3 --pmc passes of this command, corrected as "
-                        "MI355X_MICROARCH.md prescribes); not measured in this run" % PMC_FILE)
+        traffic_note = ("HBM bytes per launch from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                        "configuration, tools/profile_r03.sh, corrected as MI355X_MICROARCH.md prescribes: read side "
+                        "x2); not measured in this run" % PMC_FILE)
         kernel_us = 0.0
         roofline = roofline_tree = None
         if prof is not None and prof["select"][1] > 0:
@@ -351,8 +362,9 @@ class Leg:
             tname = ("k_tree_stag" if self.stagger else "k_tree") if fused else "k_select"
             others = {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in prof.items() if k not in ("select", "net")}
             roofline_tree = {"bound": "hbm", "kernel": tname, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(tname),
+                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(tname, {}).get("hbm"),
                              "traffic_source": traffic_note if pmc.get(tname) else None,
+                             "algorithmic_bytes_per_launch": levels_per_launch * bytes_per_level,
                              "avg_launch_us": avg_s * 1e6, "launches": n_launches, "launches_timed": n,
                              "levels_per_launch": levels_per_launch, "bytes_per_level": bytes_per_level,
                              "other_kernels_us": others}
@@ -366,8 +378,17 @@ class Leg:
             peak = MFMA_F32_PEAK_TFS if args.net != "hip3x" else MFMA_BF16_PEAK_TFS / 6.0
             kname = NET_KERNEL[args.net]
             roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": pmc.get(kname),
-                        "traffic_source": traffic_note if pmc.get(kname) else None,
+                        "frac": achieved / peak, "traffic": pmc.get(kname, {}).get("hbm"),
+                        "traffic_source": (traffic_note + "; the net's algorithmic bytes per launch are planes + "
+                                           "priors + the weights once (%.2f MB): the measured figure is higher because "
+                                           "every XCD's L2 reads the weight taps itself -- harmless for a kernel bound "
+                                           "by the matrix pipe"
+                                           % ((leaves_per_launch * (8 * HW + 4 * A + 4) + 4.0e6 * (HW > 100) + 1.0e6) / 1e6))
+                        if pmc.get(kname) else None,
+                        "mfma_busy_pmc": pmc.get(kname, {}).get("mfma_busy"),
+                        "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), rocprofv3 --pmc pass of "
+                                          "this configuration (%s): the primary utilisation figure" % PMC_FILE
+                        if pmc.get(kname, {}).get("mfma_busy") else None,
                         "avg_launch_us": avg_s * 1e6, "launches_timed": n, "leaves_per_launch": leaves_per_launch,
                         "flops_per_leaf": flops_per_leaf}
             if args.net == "hipw":
