@@ -383,7 +383,9 @@ class Leg:
                                            "priors + the weights once (%.2f MB): the measured figure is higher because "
                                            "every XCD's L2 reads the weight taps itself -- harmless for a kernel bound "
                                            "by the matrix pipe"
-                                           % ((leaves_per_launch * (8 * HW + 4 * A + 4) + 4.0e6 * (HW > 100) + 1.0e6) / 1e6))
+                                           % ((leaves_per_launch * (8 * HW + 4 * A + 4)
+                                               + 4.0 * (60 * 4096 + 18 * 64 + 64 + 5 * 64 + 3 * 64 + 3 + 20 * HW + 41
+                                                        + A * 2 * HW + A)) / 1e6))
                         if pmc.get(kname) else None,
                         "mfma_busy_pmc": pmc.get(kname, {}).get("mfma_busy"),
                         "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), rocprofv3 --pmc pass of "
