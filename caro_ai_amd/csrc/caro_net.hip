@@ -677,6 +677,7 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
 
   for (int layer = 0; layer < NRES; ++layer) {
     const int c0 = layer * 6;  // first chunk of the layer; 6 % WNBUF == 0, so chunk c0 + k sits in buffer k % WNBUF
+    CARO_LST(layer, 0)
     f32x16 accM0, accM1, accM2, accM3;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -700,6 +701,7 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     if constexpr (NSET > 6) { CARO_PAIR(6) CARO_PAIR(8) CARO_PAIR(10) }
     if constexpr (NSET > 12) { CARO_PAIR(12) CARO_PAIR(14) CARO_PAIR(16) CARO_PAIR(18) CARO_PAIR(20) CARO_PAIR(22) }
 #undef CARO_PAIR
+    CARO_LST(layer, 1)
     // output transform: Y0 += {1,1,1,0}[p] * M_p,  Y1 += {0,1,-1,-1}[p] * M_p, p = 0..3 in this order
     f32x16 accY0, accY1;
 #pragma unroll
@@ -711,7 +713,29 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
       accY0[e] = y0;
       accY1[e] = y1;
     }
-    __syncthreads();  // every wave has read this layer's input activations: they may be overwritten
+    // what the in-place update needs besides the sums -- the bias (global memory: an L2 latency) and this lane's OLD
+    // activations (its own cells: nobody else writes them) -- is requested in front of the barrier and arrives while
+    // the waves wait for one another (requested behind it, as before, it cost every layer 2 k idle cycles)
+    const float* bias = p.b_res + layer * NF + ct * 32 + 4 * h;
+    const int g0 = ct * 8 + h;  // granule of group q is g0 + 2q
+    float* row0p = act + orow0 * NF;
+    float* row1p = row0p + p.W * NF;
+    const int k0 = orow0 & 15, k1 = (orow0 + p.W) & 15;
+    float4 bq[4], old0[4], old1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + 8 * q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      old0[q] = ovalid0 ? *reinterpret_cast<const float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      old1[q] = ovalid1 ? *reinterpret_cast<const float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    CARO_LST(layer, 2)
+    // every wave has read this layer's input activations (its LDS reads were waited for in the last step): they may be
+    // overwritten.  A bare s_barrier: __syncthreads() would first wait for the loads just requested
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    CARO_LST(layer, 3)
     if (KS > 1) {
       // partial sums of the waves kq > 0 -> ring buffer 2 (it held the layer's last chunk; the next fetch into it is
       // issued at the barrier of the next layer's second chunk) -> added by the wave kq == 0 of the same tile, in the
@@ -744,38 +768,29 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
         if (KS == 4 && round == 0) __syncthreads();  // the partials of kq = 1, 2 have been read
       }
     }
+    CARO_LST(layer, 4)
     const bool writer = kq == 0;
     // in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89); only real cells are written, the rest stay 0
-    const float* bias = p.b_res + layer * NF + ct * 32 + 4 * h;
-    const int g0 = ct * 8 + h;  // granule of group q is g0 + 2q
-    float* row0p = act + orow0 * NF;
-    float* row1p = row0p + p.W * NF;
-    const int k0 = orow0 & 15, k1 = (orow0 + p.W) & 15;
-    float4 old0[4], old1[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      old0[q] = ovalid0 ? *reinterpret_cast<const float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
-      old1[q] = ovalid1 ? *reinterpret_cast<const float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 bq = *reinterpret_cast<const float4*>(bias + 8 * q);
       float4 n0, n1;
-      n0.x = old0[q].x + leaky(accY0[4 * q] + bq.x, slope);
-      n0.y = old0[q].y + leaky(accY0[4 * q + 1] + bq.y, slope);
-      n0.z = old0[q].z + leaky(accY0[4 * q + 2] + bq.z, slope);
-      n0.w = old0[q].w + leaky(accY0[4 * q + 3] + bq.w, slope);
-      n1.x = old1[q].x + leaky(accY1[4 * q] + bq.x, slope);
-      n1.y = old1[q].y + leaky(accY1[4 * q + 1] + bq.y, slope);
-      n1.z = old1[q].z + leaky(accY1[4 * q + 2] + bq.z, slope);
-      n1.w = old1[q].w + leaky(accY1[4 * q + 3] + bq.w, slope);
+      n0.x = old0[q].x + leaky(accY0[4 * q] + bq[q].x, slope);
+      n0.y = old0[q].y + leaky(accY0[4 * q + 1] + bq[q].y, slope);
+      n0.z = old0[q].z + leaky(accY0[4 * q + 2] + bq[q].z, slope);
+      n0.w = old0[q].w + leaky(accY0[4 * q + 3] + bq[q].w, slope);
+      n1.x = old1[q].x + leaky(accY1[4 * q] + bq[q].x, slope);
+      n1.y = old1[q].y + leaky(accY1[4 * q + 1] + bq[q].y, slope);
+      n1.z = old1[q].z + leaky(accY1[4 * q + 2] + bq[q].z, slope);
+      n1.w = old1[q].w + leaky(accY1[4 * q + 3] + bq[q].w, slope);
       if (ovalid0 && writer) *reinterpret_cast<float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) = n0;
       if (ovalid1 && writer) *reinterpret_cast<float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) = n1;
     }
+    CARO_LST(layer, 5)
     // new activations visible to every wave; it is also the chunk barrier of the next layer's first chunk (this
     // wave's share of its second chunk has arrived, nobody reads this layer's last chunks any more)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    CARO_LST(layer, 6)
   }
 #undef CARO_STEP
 #undef CARO_AWAIT

@@ -35,4 +35,17 @@
 #define CARO_FETCH_ON 1
 #endif
 
+// 24: per-layer stamps of the row-Winograd trunk (workgroups 0..63, thread 0): layer start | main loop done | output
+//     transform done | partial sums exchanged | activations written | the layer's closing barrier passed
+#if defined(CARO_EXP) && CARO_EXP == 24
+__device__ unsigned long long g_caro_lst[64 * 5 * 8];
+#define CARO_LST(layer, n)                                                                                     \
+  if (tid == 0 && blockIdx.x < 64) g_caro_lst[(blockIdx.x * 5 + (layer)) * 8 + (n)] = __builtin_amdgcn_s_memtime();
+extern "C" int caro_exp_read_lst(unsigned long long* out_host) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_caro_lst), sizeof(unsigned long long) * 64 * 5 * 8);
+}
+#else
+#define CARO_LST(layer, n)
+#endif
+
 #endif
