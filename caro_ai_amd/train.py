@@ -119,17 +119,51 @@ def train_neural_net(game, replay_buffer, net, optimizer, device="cuda:0", train
     return {"loss_total": sums[0], "loss_value": sums[1], "loss_policy": sums[2]}
 
 
+def staggered_ok(game, batch):
+    """the geometry staggered mode needs: one wavefront per game (batch x lanes per descent = 64)"""
+    A = game.action_space
+    lpd = 8 if A == 7 else 16 if A <= 16 else 32 if A <= 32 else 64
+    return batch * lpd == 64
+
+
 def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0, searches=cfg.MCTS_SEARCHES,
-              batch=cfg.MCTS_BATCH_SIZE, concurrent=None):
+              batch=cfg.MCTS_BATCH_SIZE, concurrent=None, stagger=False):
     """Play n_games with the (best) net against itself, tuples appended on the device.
-    Returns speed_steps, speed_nodes, steps, nodes (train.py:49-58)."""
+    Returns speed_steps, speed_nodes, steps, nodes (train.py:49-58).
+    stagger=True (the CLI's choice where the geometry allows): the engine's staggered mode -- every game on its own
+    minibatch clock, finished games restarted in place -- played until at least n_games have finished; the games a
+    slot started beyond that are dropped unfinished.  Each finished game is the one the lock-step form plays for the
+    same uid; only the ORDER in which games reach the replay buffer differs."""
     from caro_ai_amd.engine import SelfPlayEngine
     rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
     G = int(concurrent or n_games)
+    stagger = bool(stagger) and staggered_ok(game, batch)
     eng = SelfPlayEngine(game, G, net1=net, max_batch=batch, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, seed=seed,
-                         device=device, searches_hint=searches, uid_base=uid_base + rank * G, uid_stride=world * G)
+                         device=device, searches_hint=searches, uid_base=uid_base + rank * G, uid_stride=world * G,
+                         stagger=stagger)
     t0 = time.time()
     finished = steps = 0
+    if stagger:
+        gatherer = parallel.TupleGatherer(every=1 << 30, pi_dtype=torch.float32)
+        while finished < n_games:
+            d = eng.move(searches, batch)  # host-pipelined: hands out the rows parked during the previous pass
+            if d is not None and int(d["games"].shape[0]):
+                finished += int(d["games"].shape[0])
+                steps += int(d["games"][:, 3].sum().item())
+                gatherer.push(d)
+        d = eng.flush()
+        if d is not None and int(d["games"].shape[0]):
+            finished += int(d["games"].shape[0])
+            steps += int(d["games"][:, 3].sum().item())
+            gatherer.push(d)
+        out = gatherer.flush()
+        if out is not None:
+            replay_buffer.extend(out)
+        c = eng.counters()
+        dt = time.time() - t0
+        eng.close()
+        return {"speed_steps": steps / dt, "speed_nodes": c["expansions"] / dt, "steps": steps,
+                "nodes": c["expansions"], "games": finished}
     # multi-GPU: every rank plays the same number of moves (the loop below is driven by rank-local counts, so the
     # exchange is batched and flushed once at the end, when every rank has left the loop)
     gatherer = parallel.TupleGatherer(every=1 << 30, pi_dtype=torch.float32)
@@ -221,7 +255,7 @@ def main(argv=None):
     step_idx = best_idx = 0
     while args.iterations == 0 or step_idx < args.iterations:
         sp = self_play(game, replay_buffer, best_net.target_model, args.games, device=device, seed=step_idx,
-                       uid_base=step_idx * args.games * world)
+                       uid_base=step_idx * args.games * world, stagger=True)
         step_idx += 1
         writer.add_scalar("speed_steps", sp["speed_steps"], step_idx)
         writer.add_scalar("speed_nodes", sp["speed_nodes"], step_idx)

@@ -131,3 +131,30 @@ def test_staggered_mode_refuses_what_it_cannot_do():
     assert lock.L.caro_search_staggered(lock.h, lock.evaluators[0].h, None, 1, 8, lock.planes.data_ptr(), None,
                                         lock._probs.data_ptr(), lock._values.data_ptr(), None) == -71  # lock-step engine
     lock.close()
+
+
+def test_train_self_play_staggered_fills_the_replay_buffer():
+    """train.self_play(stagger=True) -- the CLI's throughput form (train.py:25-59's loop, all games at once): at least
+    n_games finished games reach the device replay buffer with well-formed rows, and -- connect four, batch 8 -- the
+    staggered engine is really what ran.  The same call on a geometry without one wavefront per game falls back to
+    lock-step."""
+    from caro_ai_amd import train
+    from caro_ai_amd.lib.model import Net
+    game = _game_of({"kind": "c4"})
+    assert train.staggered_ok(game, 8) and not train.staggered_ok(_game_of({"kind": "mnk", "n": 3, "k": 3}), 8)
+    torch.manual_seed(1)
+    net = Net(game.obs_shape, game.action_space).to(DEV).eval()
+    rb = train.DeviceReplayBuffer(game, 20000, DEV)
+    sp = train.self_play(game, rb, net, 96, device=DEV, seed=3, searches=6, batch=8, concurrent=64, stagger=True)
+    assert sp["games"] >= 96 and sp["steps"] >= 7 * 96 and sp["speed_nodes"] > 0
+    n = len(rb)
+    assert n == sp["steps"] + sp["games"]  # a game of s steps contributes s + 1 rows
+    pi = rb.pi[:n].cpu().numpy()
+    z = rb.z[:n].cpu().numpy()
+    assert np.allclose(pi.sum(1), 1.0, atol=1e-5) and set(np.unique(z).tolist()) <= {-1.0, 0.0, 1.0}
+    ttt = _game_of({"kind": "mnk", "n": 3, "k": 3})
+    torch.manual_seed(2)
+    net3 = Net(ttt.obs_shape, ttt.action_space).to(DEV).eval()
+    rb3 = train.DeviceReplayBuffer(ttt, 4096, DEV)
+    sp3 = train.self_play(ttt, rb3, net3, 32, device=DEV, seed=3, searches=4, batch=8, concurrent=16, stagger=True)
+    assert sp3["games"] >= 32 and len(rb3) == sp3["steps"] + sp3["games"]
