@@ -543,6 +543,94 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
   }
   if (v.dbg) st_loop = __builtin_amdgcn_s_memtime();
 
+  if constexpr (ONE) {
+    // One wavefront, descent b in lanes [b * LPD, (b + 1) * LPD), every lane of a group holding the same copy of its
+    // descent: the planned-set de-duplication (mcts.py:272-278: the first occurrence of a new leaf is kept), the
+    // ranks, the tallies and the records are done from registers -- the leaf of descent o is read from the first lane
+    // of its group (a uniform lane index: v_readlane), nothing goes through LDS.
+    const bool head = l == 0;  // one speaker per descent
+    const int st = d.status;
+    bool dup = false;
+    for (int o = 0; o < B; ++o) {
+      const int src = o * LPD;
+      bool eq = o < b && __builtin_amdgcn_readlane(st, src) == ST_LEAF;
+#pragma unroll
+      for (int w = 0; w < KW; ++w) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d.cur.w[w], src);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(d.cur.w[w] >> 32), src);
+        eq = eq && ((((uint64_t)hi << 32) | lo) == d.cur.w[w]);
+      }
+      dup = dup || eq;
+    }
+    const bool first_seen = st == ST_LEAF && !dup;
+    const unsigned long long m_first = __ballot(head && first_seen);
+    const unsigned long long m_term = __ballot(head && st == ST_TERMINAL);
+    const unsigned long long m_drop = __ballot(head && st == ST_LEAF && dup);
+    const int my_rank = __popcll(m_first & ((1ull << tid) - 1ull));  // leaves of earlier descents (heads only carry bits)
+    const int levels = group_sum_i32<64>(head ? d.depth : 0);
+    int maxdep = 0;
+    if (v.dbg) maxdep = group_allreduce_i32<64>(d.depth, [](int x, int y) { return x > y ? x : y; });
+    if (head) {
+      const size_t di = (size_t)g * v.maxB + b;
+      v.d_status[di] = (st == ST_LEAF && dup) ? ST_DROPPED : st;
+      v.d_value[di] = d.value;
+      v.d_local[di] = my_rank;
+      v.d_player[di] = d.player;
+      v.path_len[di] = d.depth;
+      v.d_home[di] = (int32_t)d.home;
+      store_board<R>(v.d_key + di * KW, d.cur);
+    }
+    const int nleaf = __popcll(m_first);
+    if (tid == 0) {
+      v.g_nleaf[g] = nleaf;
+      v.g_tree[g] = t;
+      v.g_class[g] = v.n_nets == 2 ? player0 : 0;
+      if (v.dbg) {  // cycles since kernel start: noise generated | root level done | descents done | end; max depth
+        unsigned long long* dd = v.dbg + (size_t)g * 8;
+        dd[0] = st_noise - st0; dd[1] = st_root - st0; dd[2] = st_loop - st0;
+        dd[3] = __builtin_amdgcn_s_memtime() - st0; dd[4] = (unsigned long long)maxdep;
+      }
+      // this block is the only writer of game g's tallies; adds without a return value do not wait for memory
+      unsigned long long* ctr = v.counters + (size_t)g * C_N;
+      atomicAdd(ctr + C_SIMS, (unsigned long long)B);
+      atomicAdd(ctr + C_LEVELS, (unsigned long long)levels);
+      atomicAdd(ctr + C_TERMINALS, (unsigned long long)__popcll(m_term));
+      atomicAdd(ctr + C_DROPPED, (unsigned long long)__popcll(m_drop));
+      if (rows) {
+        const int cls = v.n_nets == 2 ? player0 : 0;
+        if (nleaf) atomicAdd(rows + cls, nleaf);
+        v.g_off[g] = g * B;
+        v.g_pack[g] = nleaf | (cls << 8);
+      }
+    }
+    if (rows) {
+      // NN planes of the unique leaves into the game's slot rows, leaf by leaf in first-seen order: the board and the
+      // player to move come from the first lane of the leaf's group
+      const int HW = v.HW;
+      int local = 0;
+      for (unsigned long long m = m_first; m; m &= m - 1ull) {
+        const int src = __ffsll(m) - 1;
+        Board brd;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) {
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d.cur.w[w], src);
+          const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(d.cur.w[w] >> 32), src);
+          brd.w[w] = ((uint64_t)hi << 32) | lo;
+        }
+        const int who = __builtin_amdgcn_readlane(d.player, src);
+        const int rowi = g * B + local++;
+        float* dst = planes + (size_t)rowi * 2 * HW;
+        for (int i = tid; i < 2 * HW; i += 64) dst[i] = R::plane(v.gp, brd, who, i / HW, i % HW);
+        if (leaf_keys && tid < KW) {
+          uint64_t kw = brd.w[0];
+#pragma unroll
+          for (int w = 1; w < KW; ++w) kw = tid == w ? brd.w[w] : kw;  // no run-time index into the registers
+          leaf_keys[(size_t)rowi * KW + tid] = kw;
+        }
+      }
+    }
+    return;
+  }
   if (l == 0) {
 #pragma unroll
     for (int w = 0; w < KW; ++w) s_key[b][w] = d.cur.w[w];
@@ -820,9 +908,9 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
     bool all_fast = false;
     if (single_wave) {
       bool clash = false;
-      for (int bb = 0; bb < B; ++bb) {
-        const int ob = __shfl((int)is_leaf, bb);
-        const uint32_t oh = (uint32_t)__shfl((int)(my_home & 0x7fffffffu), bb);
+      for (int bb = 0; bb < B; ++bb) {  // bb is uniform: readlane, not a trip through the LDS crossbar
+        const int ob = __builtin_amdgcn_readlane((int)is_leaf, bb);
+        const uint32_t oh = (uint32_t)__builtin_amdgcn_readlane((int)(my_home & 0x7fffffffu), bb);
         clash = clash || (bb < lane && ob && oh == (my_home & 0x7fffffffu));
       }
       all_fast = __ballot(is_leaf && ((my_home >> 31) == 0u || clash)) == 0ull;
