@@ -158,3 +158,57 @@ def test_train_self_play_staggered_fills_the_replay_buffer():
     rb3 = train.DeviceReplayBuffer(ttt, 4096, DEV)
     sp3 = train.self_play(ttt, rb3, net3, 32, device=DEV, seed=3, searches=4, batch=8, concurrent=16, stagger=True)
     assert sp3["games"] >= 32 and len(rb3) == sp3["steps"] + sp3["games"]
+
+
+def test_staggered_real_weights_vs_reference_recorded_games():
+    """The staggered path with the real net on the GPU (what bench.py runs) against the 32 self-play games RECORDED
+    FROM THE REFERENCE at config 2's per-game settings (tests/golden/real_c4_x32.json.gz: shipped best_026_12000.dat,
+    25 x 8 sims/move, tau = 1 for 10 plies).  A staggered engine cannot be stopped after every ply to read root N, but
+    its replay rows carry pi of every ply -- N / sum N for the first ten plies, the one-hot of the first maximum
+    afterwards: each game is compared ply by ply for as long as it follows the recorded boards.  Stated tolerance as
+    for the lock-step comparison: >= 99 % of the compared plies carry the reference's pi exactly, and a
+    game that matched at every ply ends with the recorded result and step count."""
+    import os
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.model import Net
+    from tests.conftest import GOLDEN, load_golden
+    d = load_golden("real_c4_x32.json.gz")
+    game = _game_of(d)
+    games = d["games"]
+    g0 = games[0]
+    assert [gm["uid"] for gm in games] == list(range(g0["uid"], g0["uid"] + 32))
+    net = Net(game.obs_shape, game.action_space)
+    net.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", d["weights"]), map_location="cpu"))
+    net = net.to(DEV).eval()
+    eng = SelfPlayEngine(game, 32, net1=net, max_batch=g0["batch"], seed=g0["seed"], uid_base=g0["uid"], device=DEV,
+                         steps_before_tau_0=g0["steps_before_tau_0"], searches_hint=g0["searches"], stagger=True,
+                         stagger_recycle=False)
+    tuples, recs = eng.play_until(g0["searches"], g0["batch"], recycle=False)
+    assert eng.live_games() == 0 and eng.counters()["overflows"] == 0
+    eng.close()
+    ST = np.concatenate([t["states"] for t in tuples])
+    PI = np.concatenate([t["pi"] for t in tuples])
+    by_uid, off = {}, 0
+    for uid, first, result, steps in recs.tolist():
+        n = steps + 1
+        by_uid[uid] = (first, result, steps, game.from_keys(ST[off:off + n].view(np.uint64))[::-1], PI[off:off + n][::-1])
+        off += n
+    total = same = whole = 0
+    for gm in games:
+        first, result, steps, states, pis = by_uid[gm["uid"]]
+        assert first == gm["first_player"]
+        ok = True
+        for ply in range(min(len(states), gm["plies"])):
+            if str(states[ply]) != gm["states"][ply]:
+                break  # another move was played: later plies are another game
+            total += 1
+            if pis[ply].tolist() == gm["pi"][ply]:
+                same += 1
+            else:
+                ok = False
+        else:
+            if ok and len(states) == gm["plies"]:
+                assert (result, steps) == (gm["result"], gm["steps"]), gm["uid"]
+                whole += 1
+    print("staggered vs reference-recorded games: identical pi on %d / %d plies, %d / 32 whole games" % (same, total, whole))
+    assert total >= 400 and same / total >= 0.99 and whole >= 24
