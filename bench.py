@@ -247,15 +247,14 @@ class Leg:
         common = dict(max_batch=B, steps_before_tau_0=self.sbt0, seed=0, device=str(device), searches_hint=S)
         # staggered mode (every game on its own minibatch clock: even leaf counts per launch, include/caro_hip.h):
         # wherever one wavefront serves a game and nothing needs the second key table
-        self.stagger = bool(args.stagger and self.is_hip and game_name == "c4" and B == 8 and not self.evict
-                            and self.n_streams == 1)
+        self.stagger = bool(args.stagger and self.is_hip and game_name == "c4" and B == 8 and not self.evict)
         # a small copy of the same configuration: played to completion before the clock starts, it takes the
         # first-use costs (code objects, torch's clone / cat / cast kernels, allocator growth of the drain path)
         self._warm = SelfPlayEngine(self.game, 16, evaluators=make_evaluators(), uid_base=1 << 40, uid_stride=16,
                                     **{**common, **extra, "searches_hint": 2})
         if self.n_streams > 1:
             self.eng = StreamedSelfPlay(self.game, G, make_evaluators, n_streams=self.n_streams,
-                                        partition_cus=bool(args.stream_mask), **common, **extra,
+                                        partition_cus=bool(args.stream_mask), stagger=self.stagger, **common, **extra,
                                         **parallel.shard(G, rank, world))
         else:
             self.eng = SelfPlayEngine(self.game, G, evaluators=make_evaluators(), stagger=self.stagger, **common,
