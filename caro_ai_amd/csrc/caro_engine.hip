@@ -12,6 +12,12 @@
 //   k_step           get_policy_value + one ply of play_game
 //                    [lib/mcts.py:289-313, lib/utils.py:80-99].
 //   k_drain_*        replay emission [lib/utils.py:101-106] + slot recycling.
+//   k_tree           the three per-game bodies fused (expand + backup of minibatch i-1, select of minibatch i, NN
+//                    planes into the game's slot rows): one launch per minibatch beside the net kernel, lock-step.
+//   k_tree_stag      the same with every game on its OWN minibatch clock (staggered mode): the ply (step_body) and
+//                    the restart of a finished game's slot happen inside the kernel, so every launch carries the same
+//                    mix of minibatch indices and the net launch the same leaf count.  Both fused kernels run a
+//                    second wavefront per game that generates the Dirichlet rows while the tree wave waits for memory.
 //
 // Data layout in HBM (T = G * n_stores trees, AP = padded action count).  The transposition table IS
 // the node store: open addressing with linear probing over hcap = 2^k >= 2*cap slots, node id = slot,
