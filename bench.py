@@ -4,21 +4,24 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N          # WORLD_SIZE unset: starts its N ranks itself (one child process per GPU)
 
-A "step" is one move of every one of the G concurrent games on a rank: 25
-search minibatches (fused tree kernel -> net forward), the ply itself, and the
-drain / recycling of finished games (plus, for N > 1, the all-gather of the
-drained (s, pi, z) tuples).  value = node-expansions (reference: `_create_node`
-calls, lib/mcts.py:178-190 = train.py's "leaves") summed over ranks /
-max-over-ranks wall time of the K timed steps.
+A "step" is one move of every one of the G concurrent games on a rank: 25 launch pairs (fused tree kernel -> net
+forward), the plies, and the drain of finished games (plus, for N > 1, the all-gather of the drained (s, pi, z)
+tuples every few moves).  Default schedule = STAGGERED (include/caro_hip.h, caro_search_staggered): every game runs
+its own minibatch clock, so a step is 25 launches in which every game makes one move on average, each at its own
+launch, and finished games restart in place; `--stagger 0` = lock-step (all games move together).  Game by game the
+two schedules play the same games.  value = node-expansions (reference: `_create_node` calls, lib/mcts.py:178-190 =
+train.py's "leaves") summed over ranks / max-over-ranks wall time of the K timed steps.
 
-One JSON line on stdout (rank 0).  `roofline` is the dominant kernel (the fused
-net forward; HIP events on its launch stream, inside the timed region),
-`roofline_tree` the tree kernel; `cpu_baseline` is the oracle (CPU port of the
-reference algorithm) driving the same net on the host cores for a bounded
-sample, rank 0, N = 1 only.  At N = 1 the line also carries `config4` and
-`config5`: short legs of BASELINE.json's 15x15 and arena configurations, run in
-the same process after the headline loop (each with its own value / roofline).
+One JSON line on stdout (rank 0).  `roofline` is the dominant kernel (the fused net forward; HIP events on its
+launch stream, inside the timed region; `mfma_busy_pmc` / `traffic` from the committed PMC passes of the same
+configuration), `roofline_tree` the tree kernel; `sustained` = 200 further moves of the same engine on their own
+clock; `dist` = what the collective layer is (backend, world size, each rank's device and own value);
+`cpu_baseline` is the oracle (CPU port of the reference algorithm) driving the same net on the host cores for a
+bounded sample, rank 0, N = 1 only.  At N = 1 the line also carries `config5` (512-match arena) and `config4`
+(15 x 15, measured in mid-game after --config4-warmup moves at full size), run in the same process after the
+headline loop; `extras_rc` != 0 says one of them failed.
 """
 import argparse
 import json
