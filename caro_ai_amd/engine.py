@@ -102,6 +102,7 @@ class SelfPlayEngine:
             raise _lib.CaroError("stagger=True needs device-side evaluators (the fused HIP net or HashNet)")
         c.stagger = self.stag_S if self.stagger else 0
         c.stagger_recycle = 1 if stagger_recycle else 0
+        self.stagger_recycle = bool(stagger_recycle)
         self.cfg = c
         self.n_stores = n_stores
         torch.cuda.set_device(self.device)
@@ -247,6 +248,8 @@ class SelfPlayEngine:
         cap = self._staging(cap)
         s, p, pi, z, games = self._dr
         if self.stagger:  # the parked games; their slots have restarted already (or not: stagger_recycle)
+            assert bool(recycle) == self.stagger_recycle, \
+                "staggered mode restarts slots in-kernel: recycle is fixed by stagger_recycle at construction"
             _lib.check(self.L.caro_drain_parked_begin(self.h, cap, _ptr(s), _ptr(p), _ptr(pi), _ptr(z), _ptr(games),
                                                       self._stream()))
             return

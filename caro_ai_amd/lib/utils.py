@@ -99,11 +99,17 @@ def play_games(game, n_games, replay_buffer, net1, net2=None, steps_before_tau_0
         n_stores = 2 if arena else 1
     G = int(concurrent or min(n_games, 1024))
     G = max(1, min(G, n_games))
+    # One generation of games on a geometry with one wavefront per game (connect four, batch 8: play.py's arena):
+    # the engine's staggered mode without restarts -- every game on its own minibatch clock, the same games, evener
+    # launches.  Several generations keep the lock-step engine, whose drain decides slot by slot whether to restart.
+    A = game.action_space
+    lpd = 8 if A == 7 else 16 if A <= 16 else 32 if A <= 32 else 64
+    stagger = G == n_games and mcts_batch_size * lpd == 64
     # the bookkeeping below (slot g plays uids uid_base + g, + G, ...) is that of an engine made here, fresh
     engine = SelfPlayEngine(game, G, net1=net1, net2=net2 if arena else None, n_stores=n_stores,
                             max_batch=mcts_batch_size, steps_before_tau_0=steps_before_tau_0, seed=seed,
                             uid_base=uid_base, first_player_mode=first_player_mode, device=device,
-                            searches_hint=mcts_searches)
+                            searches_hint=mcts_searches, stagger=stagger, stagger_recycle=False)
     t0 = time.time()
     c0 = engine.counters()
     last_uid = uid_base + n_games - 1
@@ -128,7 +134,7 @@ def play_games(game, n_games, replay_buffer, net1, net2=None, steps_before_tau_0
         engine.step()
         # keep recycling while some wanted game has not been handed to its slot yet; slots that run ahead of the
         # others may then start a few games beyond the wanted range: they are played but not reported
-        recycle = any(slot_uid[(u - uid_base) % G] < u for u in waiting)
+        recycle = not stagger and any(slot_uid[(u - uid_base) % G] < u for u in waiting)
         d = engine.drain(recycle=recycle)
         if int(d["games"].shape[0]):
             for uid, _first, result, steps in d["games"].cpu().numpy().tolist():
