@@ -23,8 +23,8 @@
 //   Weights stream from L2 through the other 96 KiB of LDS (k_net_forward: two buffers of three taps, staged through
 //   registers; k_net_forward_w: a ring of three 32 KiB chunks filled by global_load_lds, one workgroup barrier per
 //   chunk plus two per layer around the in-place epilogue).
-//   conv_in (K = 18), the 1x1 heads, the two FC heads, tanh and the softmax
-//   run on the VALU in the same kernel.
+//   conv_in (K = 18: k_net_forward_w runs it on the matrix pipe too, one MFMA per tap; the other two kernels on the
+//   VALU), the 1x1 heads, the two FC heads, tanh and the softmax run in the same kernel.
 // float32 throughout: MFMA f32 is an exact fma chain in k order.
 #include <hip/hip_runtime.h>
 
@@ -122,6 +122,60 @@ __device__ __forceinline__ void conv_in_f32(const NetParams& p, const float* __r
   }
 }
 
+// conv_in on the matrix pipe (k_net_forward_w): the same K = 18 dot products as conv_in_f32 -- bias, then for every tap
+// the product of plane 0, then of plane 1, which is the k order of one v_mfma_f32_32x32x2_f32 per tap (k = plane) with
+// the weights as first operand, i.e. the same fma chain -- as 9 MFMAs per (32 rows x 32 channels) instead of 576 fma
+// per thread whose 144 weight reads per thread kept the LDS return path busy for 9 k cycles.  Wave = column tile
+// (wave & 1) x row tiles (wave >> 1) and (wave >> 1) + 4; lane (i, h) feeds row 32 rt + i with plane h: 9 loads per row
+// tile instead of 18.  Output layout = the trunk's (a lane holds 4 groups of 4 consecutive channels of its row).
+__device__ __forceinline__ void conv_in_mfma(const NetParams& p, const float* __restrict__ planes, const int* smap,
+                                             float* act, const float* win, int R, int tid) {
+  const int HW = p.HW;
+  const float slope = p.slope;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 31, h = lane >> 5;
+  const int ct = wave & 1;
+  float wa[9];  // A operands: w[co = ct*32 + i][k = (tap, plane h)], win = [tap][plane][64]
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wa[t] = win[(2 * t + h) * NF + ct * 32 + i];
+  float4 bias[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bias[q] = *reinterpret_cast<const float4*>(p.b_in + ct * 32 + 8 * q + 4 * h);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int rt = (wave >> 1) + 4 * half;
+    if (rt * 32 >= R) continue;  // uniform per wave: no real row in this tile
+    const int r = rt * 32 + i;
+    const bool rv = r < R;
+    const int bi = rv ? r / HW : 0, cell = rv ? r - bi * HW : 0;
+    const int y = cell / p.W, x = cell - y * p.W;
+    const float* pl = planes + (size_t)smap[bi] * 2 * HW + h * HW;
+    float in[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ny = y + t / 3 - 1, nx = x + t % 3 - 1;
+      const bool ok = rv && ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
+      in[t] = ok ? pl[ny * p.W + nx] : 0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[4 * q] = bias[q].x; acc[4 * q + 1] = bias[q].y; acc[4 * q + 2] = bias[q].z; acc[4 * q + 3] = bias[q].w;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], in[t], acc, 0, 0, 0);
+    if (rv) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c4 = ct * 8 + 2 * q + h;
+        const float4 out = make_float4(leaky(acc[4 * q], slope), leaky(acc[4 * q + 1], slope),
+                                       leaky(acc[4 * q + 2], slope), leaky(acc[4 * q + 3], slope));
+        *reinterpret_cast<float4*>(act + r * NF + ((c4 ^ (r & 15)) << 2)) = out;
+      }
+    }
+  }
+}
+
 // 1x1 heads, the two FC heads, tanh and the softmax (lib/model.py:44-67, lib/mcts.py:216) from the trunk
 // output in `act`; `scratch` = the (now free) weight stage.  probs / values are the launch's output rows;
 // `slot_v` = output row of board `tid` (threads tid < nb), re-published through the scratch for the prob rows.
@@ -188,6 +242,7 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
   }
   __syncthreads();
   CARO_HST(1)
+  CARO_PST(9)
   // value head: Linear(HW,20) + LeakyReLU -- threads from 0 up
   for (int k = tid; k < nb * 20; k += NT) {
     const int bi = k / 20, u = k - bi * 20;
@@ -222,6 +277,7 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
   }
   __syncthreads();
   CARO_HST(2)
+  CARO_PST(10)
   // Linear(20,1) + tanh on the last wave; beside it the softmax terms exp(logit - max), one thread per action
   {
     const int vt = tid - (NT - 64);
@@ -257,6 +313,7 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
   }
   __syncthreads();
   CARO_HST(3)
+  CARO_PST(11)
   for (int k = tid; k < nb * A; k += NT) {
     const int bi = k / A;
     probs[(size_t)omap[bi] * A + (k - bi * A)] = ebuf[k] / stat[2 * bi + 1];
@@ -807,6 +864,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   float* act = lds;
   float* wbuf = lds + ACT;
 
+  CARO_PST(0)
   int L, row0, board0, nb, nb_cap = p0.TB;
   int ks = 1;  // K-split of this workgroup's tiles (1: a full tile of TB boards)
   bool second = false;
@@ -857,6 +915,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
     board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * nb_cap;
   }
   if (board0 >= L) return;
+  CARO_PST(1)
   const NetParams p = second ? p1 : p0;
   unsigned long long t_c0 = 0, t_r0 = 0;  // diagnostic only, as in k_net_forward
   if (stamps) {
@@ -885,15 +944,20 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   // global memory, so only w_in has to be covered by the 320-lane transfer (what comes along behind it is not used).
   static_assert(2 * (WCH / 4 / NT) == 8, "s_waitcnt vmcnt(8) below counts 2 chunks x WCH / 4 / NT transfers per thread");
   static_assert(320 * 4 >= 9 * 2 * NF, "the 320-lane transfer must cover w_in [9][2][64]");
+  CARO_PST(2)
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 2 x 4 chunk transfers of this thread may still be on their way
+  CARO_PST(3)
   int* smap = reinterpret_cast<int*>(win + 1536);  // [TB] plane / output row of every board of this tile
   tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
-  conv_in_f32(p, planes, smap, act, win, R, tid);
+  CARO_PST(4)
+  conv_in_mfma(p, planes, smap, act, win, R, tid);
+  CARO_PST(5)
   const int slot_v = tid < nb ? smap[tid] : 0;
   unsigned long long t_trunk0 = 0;
   if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // conv_in's output and the two chunks are visible to every wave
+  CARO_PST(6)
 
   // head parameters staged in LDS during the trunk's last chunks when they fit (heads_f32)
   const int hspan = head_span(HW, p.A) <= HEAD_STAGE_MAX ? head_span(HW, p.A) : 0;
@@ -902,8 +966,10 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   else trunk_w<4>(p, act, wbuf, nb, tid, hspan);
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
+  CARO_PST(8)
   if (hspan) heads_f32<true>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
   else heads_f32<false>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
+  CARO_PST(12)
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
     stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;

@@ -44,8 +44,17 @@ __device__ unsigned long long g_caro_lst[64 * 5 * 8];
 extern "C" int caro_exp_read_lst(unsigned long long* out_host) {
   return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_caro_lst), sizeof(unsigned long long) * 64 * 5 * 8);
 }
+// ... and of the prologue / the heads: kernel start | leaf count known | LDS zeroed, fetches issued | conv_in weights
+//     arrived | slot rows mapped | conv_in done | trunk may start || heads start | 1x1 convolutions | FC stage | end
+__device__ unsigned long long g_caro_pst[64 * 16];
+#define CARO_PST(n) \
+  if (threadIdx.x == 0 && blockIdx.x < 64) g_caro_pst[blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memtime();
+extern "C" int caro_exp_read_pst(unsigned long long* out_host) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_caro_pst), sizeof(unsigned long long) * 64 * 16);
+}
 #else
 #define CARO_LST(layer, n)
+#define CARO_PST(n)
 #endif
 
 #endif
