@@ -1290,6 +1290,42 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
       if (a < AP && threadIdx.x < 64) s_n[a] = (node >= 0 && a < v.A) ? (int)(nraw[j] & NMASK) : 0;
     }
   }
+  const int ply = gr.ply;
+  const size_t hi = (size_t)g * v.maxply + ply;  // game_history.append((state, cur_player, probs)), utils.py:82
+  int action;
+  if constexpr (ONE && AP <= 64) {
+    // One wavefront, one action per lane: the policy and the sampled move from registers.  Integer total and first
+    // maximum by cross-lane reduction / ballot (exact); pi[a] = N[a] / total is the same float64 division in every
+    // form; np.random.choice's cumulative sums are SEQUENTIAL float64 additions in action order: every lane runs the
+    // same chain over the broadcast pi values (v_readlane: uniform index) and keeps the prefix of its own action, so
+    // the comparisons acc / total <= u are the serial loop's, one per lane.
+    block_sync<ONE>();
+    const int lane = threadIdx.x;
+    const int n = lane < AP ? s_n[lane] : 0;
+    const int tau = (v.sbt0 > 0 && gr.step < v.sbt0) ? 1 : 0;  // utils.py:70,97-99
+    const int tot = group_sum_i32<64>(n);
+    const int nmax = group_allreduce_i32<64>(n, [](int x, int y) { return x > y ? x : y; });
+    const int best = __ffsll((unsigned long long)__ballot(lane < v.A && n == nmax)) - 1;  // first maximum
+    double pa = 0.0;
+    if (lane < v.A) pa = tau == 0 ? (lane == best ? 1.0 : 0.0) : (double)n / (double)tot;  // mcts.py:305-311
+    if (lane < v.A) v.h_pi[hi * v.A + lane] = pa;
+    if (lane == 0) {
+      store_board<R>(v.h_key + hi * KW, root);
+      v.h_player[hi] = player;
+    }
+    const double u = uniforms ? uniforms[g] : caro_move_uniform(v.seed, gr.uid, (uint32_t)ply);
+    const uint64_t pbits = (uint64_t)__double_as_longlong(pa);
+    double run = 0.0, mine = 0.0;
+    for (int a2 = 0; a2 < v.A; ++a2) {  // caro_sample_index: tot = tot + pi[a]; acc = acc + pi[a] -- the same chain
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pbits, a2);
+      const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pbits >> 32), a2);
+      run = run + __longlong_as_double((long long)(((uint64_t)hi32 << 32) | lo));
+      if (a2 == lane) mine = run;
+    }
+    const unsigned long long below = __ballot(lane < v.A && mine / run <= u);  // acc / tot <= u  =>  idx = a + 1
+    int idx = below ? 64 - __clzll((long long)below) : 0;
+    action = idx < v.A ? idx : v.A - 1;
+  } else {
   block_sync<ONE>();
   if (threadIdx.x == 0) {
     const int tau = (v.sbt0 > 0 && gr.step < v.sbt0) ? 1 : 0;  // utils.py:70,97-99
@@ -1309,9 +1345,6 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
     s_pi[a] = p;
   }
   block_sync<ONE>();
-  const int ply = gr.ply;
-  // game_history.append((state, cur_player, probs)), utils.py:82
-  const size_t hi = (size_t)g * v.maxply + ply;
   for (int a = threadIdx.x; a < v.A; a += block_threads<ONE>()) v.h_pi[hi * v.A + a] = s_pi[a];
   if (threadIdx.x == 0) {
     store_board<R>(v.h_key + hi * KW, root);
@@ -1320,8 +1353,9 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
     s_action = caro_sample_index(s_pi, v.A, u);  // np.random.choice(A, p=probs), utils.py:83
   }
   block_sync<ONE>();
+    action = s_action;
+  }
   // every thread replays the move on its own copy of the game (the same integers everywhere)
-  const int action = s_action;
   const bool won = R::move(v.gp, root, action, player);  // utils.py:86
   gr.root = root;
   gr.ply = ply + 1;
@@ -1349,9 +1383,9 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
       v.final_r[g] = final_r;
       v.done[g] = 1;
       v.result[g] = res;
-      ctr[C_FINISHED] += 1ull;
+      atomicAdd(ctr + C_FINISHED, 1ull);  // no return value: nothing waits for the old count
     }
-    ctr[C_PLIES] += 1ull;
+    atomicAdd(ctr + C_PLIES, 1ull);
     if (actions) actions[g] = action;
     if (done_out) done_out[g] = done;
     if (result_out) result_out[g] = res;
