@@ -223,6 +223,10 @@ def _nccl_worker(port, q):
     s = parallel.allreduce_sum(torch.tensor([3.0, 4.0], dtype=torch.float64, device="cuda"))
     m = parallel.allreduce_max(torch.tensor([7.5], dtype=torch.float64, device="cuda"))
     ok = ok and s.tolist() == [3.0, 4.0] and m.item() == 7.5
+    # bench.py's `dist` record travels by all_gather_object (pickled through device tensors on nccl)
+    got = [None]
+    dist.all_gather_object(got, {"rank": 0, "device": "cuda:0", "value": 1.5})
+    ok = ok and got == [{"rank": 0, "device": "cuda:0", "value": 1.5}] and dist.get_backend() == "nccl"
     dist.barrier()
     torch.cuda.synchronize()
     q.put(bool(ok))
