@@ -232,7 +232,8 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
     const int o = q / R, r = q - o * R;
     const float* wo = w_head + o * NF;
     float s0 = b_head[o];
-    for (int g = 0; g < 16; ++g) {
+#pragma unroll 8
+    for (int g = 0; g < 16; ++g) {  // eight pairs of reads in flight, the fma chain in channel order
       const float4 v = *reinterpret_cast<const float4*>(act + r * NF + ((g ^ (r & 15)) << 2));
       const float4 w = *reinterpret_cast<const float4*>(wo + g * 4);
       s0 = fmaf(v.x, w.x, s0); s0 = fmaf(v.y, w.y, s0);
@@ -249,7 +250,8 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
     float s = b_v1[u];
     const float* w = w_v1 + u * HW;
     const float* f = feat + bi * HW;
-    for (int c = 0; c < HW; ++c) s = fmaf(f[c], w[c], s);
+#pragma unroll 8
+    for (int c = 0; c < HW; ++c) s = fmaf(f[c], w[c], s);  // reads of eight steps in flight, the chain in cell order
     hid[k] = leaky(s, slope);
   }
   // policy head: Linear(2*HW, A) on the (c, y, x)-flattened planes -- threads from the middle up, beside the value rows
@@ -260,7 +262,9 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
     const float* f1 = feat + 512 + bi * HW;
     if (STAGED || !p.w_pT) {
       const float* w = w_p + (size_t)a * 2 * HW;
+#pragma unroll 8
       for (int c = 0; c < HW; ++c) s = fmaf(f0[c], w[c], s);
+#pragma unroll 8
       for (int c = 0; c < HW; ++c) s = fmaf(f1[c], w[HW + c], s);
     } else {
       // large boards (the matrix is 405 KB at 15x15 and stays in L2): the same chain from the TRANSPOSED matrix, so
