@@ -582,6 +582,7 @@ constexpr int WTAPS = NRES * 12;          // 60 transformed taps of 4096 floats
 constexpr int WCH = 4 * 2 * 64 * 16;      // floats per chunk (8192)
 constexpr int WNCHUNK = NRES * 6;         // 30
 constexpr int WNBUF = 3;
+constexpr int XROW2 = 127;                // first row of the 2-way tiles' exchange area (32 KiB: rows 127..254)
 static_assert(WNBUF * WCH == 2 * TPC * WCHUNK, "the ring takes the place of the two three-tap buffers");
 
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -774,6 +775,65 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     if constexpr (NSET > 12) { CARO_PAIR(12) CARO_PAIR(14) CARO_PAIR(16) CARO_PAIR(18) CARO_PAIR(20) CARO_PAIR(22) }
 #undef CARO_PAIR
     CARO_LST(layer, 1)
+    if constexpr (KS == 2) {
+      // 2-way K-split, balanced epilogue (round 3): the two waves of a tile (kq = 0 / 1: the halves of K) each FINISH one
+      // of the tile's two output rows -- wave kq row 2ty + kq -- instead of wave 0 finishing both while wave 1 idles.
+      // Each forms both rows' partial sums (the same fma chains as before, the coefficients picked by kq), keeps its own
+      // row's and hands the other to its partner through LDS: 4 ds_write_b128 + 4 ds_read_b128 per wave instead of 32 +
+      // 32 dword accesses on one wave each, and half the bias / LeakyReLU / write-back per wave.  The exchange area is
+      // the part of the activation buffer a 2-way tile never touches (rows 127..254: TB2 * HW <= 127, checked at upload),
+      // so it is written BEFORE the "inputs read" barrier, which then publishes it as well: two barriers per layer
+      // instead of three.  Sums: partial(kq 0) + partial(kq 1) as before (the addition commutes): bit-identical.
+      const bool up = kq != 0;  // wave-uniform
+      const float m0 = up ? 0.f : 1.f, m2 = up ? -1.f : 1.f, m3 = up ? -1.f : 0.f;   // my row:      {1,1,1,0} / {0,1,-1,-1}
+      const float s0 = up ? 1.f : 0.f, s2 = up ? 1.f : -1.f, s3 = up ? 0.f : -1.f;   // partner's row
+      const float* bias = p.b_res + layer * NF + ct * 32 + 4 * h;
+      const int g0 = ct * 8 + h;  // granule of group q is g0 + 2q
+      float* rowp = act + (orow0 + (up ? p.W : 0)) * NF;
+      const int kk = (orow0 + (up ? p.W : 0)) & 15;
+      const bool ov = up ? ovalid1 : ovalid0;
+      float4 bq[4], old[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + 8 * q);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        old[q] = ov ? *reinterpret_cast<const float4*>(rowp + (((g0 + 2 * q) ^ kk) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      f32x16 mine, send;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float a = fmaf(m0, accM0[e], 0.f), b = fmaf(s0, accM0[e], 0.f);
+        a = fmaf(1.f, accM1[e], a); b = fmaf(1.f, accM1[e], b);
+        a = fmaf(m2, accM2[e], a); b = fmaf(s2, accM2[e], b);
+        a = fmaf(m3, accM3[e], a); b = fmaf(s3, accM3[e], b);
+        mine[e] = a;
+        send[e] = b;
+      }
+      float* xw = act + XROW2 * NF + ((rt * 2 + ct) * 2 + kq) * 1024 + lane * 4;         // [q][lane] float4
+      const float* xr = act + XROW2 * NF + ((rt * 2 + ct) * 2 + (kq ^ 1)) * 1024 + lane * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(xw + q * 256) = make_float4(send[4 * q], send[4 * q + 1], send[4 * q + 2], send[4 * q + 3]);
+      CARO_LST(layer, 2)
+      // every wave has read this layer's input activations, and the partner's partial sums have been written
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      CARO_LST(layer, 3)
+      float4 part[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[q] = *reinterpret_cast<const float4*>(xr + q * 256);
+      CARO_LST(layer, 4)
+      // in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89); only real cells are written, the rest stay 0
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 n;
+        n.x = old[q].x + leaky((mine[4 * q] + part[q].x) + bq[q].x, slope);
+        n.y = old[q].y + leaky((mine[4 * q + 1] + part[q].y) + bq[q].y, slope);
+        n.z = old[q].z + leaky((mine[4 * q + 2] + part[q].z) + bq[q].z, slope);
+        n.w = old[q].w + leaky((mine[4 * q + 3] + part[q].w) + bq[q].w, slope);
+        if (ov) *reinterpret_cast<float4*>(rowp + (((g0 + 2 * q) ^ kk) << 2)) = n;
+      }
+    } else {
     // output transform: Y0 += {1,1,1,0}[p] * M_p,  Y1 += {0,1,-1,-1}[p] * M_p, p = 0..3 in this order
     f32x16 accY0, accY1;
 #pragma unroll
@@ -856,6 +916,7 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
       n1.w = old1[q].w + leaky(accY1[4 * q + 3] + bq[q].w, slope);
       if (ovalid0 && writer) *reinterpret_cast<float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) = n0;
       if (ovalid1 && writer) *reinterpret_cast<float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) = n1;
+    }
     }
     CARO_LST(layer, 5)
     // new activations visible to every wave; it is also the chunk barrier of the next layer's first chunk (this
@@ -1580,6 +1641,9 @@ int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats
   if (off && off[0] == '1') ncu = 0;
   n->p.ncu = ncu;
   n->p.TB2 = 64 / tpb < n->p.TB ? 64 / tpb : 0;
+  // the 2-way tiles exchange their partial sums through activation rows XROW2..254: the tile's own rows must end below
+  // (boards with an even height whose tile count divides 64 -- 8x8 -- fill 128 rows: no 2-way tiles for them)
+  if (n->p.TB2 * H * W > cnet::XROW2) n->p.TB2 = 0;
   n->p.TB4 = 32 / tpb < n->p.TB ? 32 / tpb : 0;
   return 0;
 }
