@@ -72,6 +72,7 @@ _SIGNATURES = {
     "caro_net_forward_slots": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "caro_net_create_hash": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, _P]),
     "caro_net_forward_stamped": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P]),
+    "caro_net_debug_stamps": (C.c_int, [_P, _P]),
     "caro_get_descent": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "caro_select_cancel": (C.c_int, [_P]),
     "caro_expand_backup": (C.c_int, [_P, _P, _P, _P]),

@@ -1659,7 +1659,8 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
     v.lm[g] = over ? 0 : lm + 1;
     v.pend[g] = over ? 0 : 1;
     if (v.dbg) {  // diagnostic stamps (tools/probe_stag.py): ply + park | expand + backup | whole block
-      v.dbg[(size_t)g * 8 + 5] = t2 - t1;
+      // (slot 5 carries the 100 MHz wall clock at the block's end above bit 24: tools/probe_engine_net.py's time line)
+      v.dbg[(size_t)g * 8 + 5] = ((t2 - t1) & 0xFFFFFFull) | (__builtin_amdgcn_s_memrealtime() << 24);
       v.dbg[(size_t)g * 8 + 6] = t1 - t0;
       v.dbg[(size_t)g * 8 + 7] = __builtin_amdgcn_s_memtime() - t0;
     }

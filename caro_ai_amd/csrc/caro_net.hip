@@ -582,6 +582,7 @@ constexpr int WTAPS = NRES * 12;          // 60 transformed taps of 4096 floats
 constexpr int WCH = 4 * 2 * 64 * 16;      // floats per chunk (8192)
 constexpr int WNCHUNK = NRES * 6;         // 30
 constexpr int WNBUF = 3;
+constexpr int XROW4 = 63;                 // ... of the 4-way tiles' (48 KiB: rows 63..254)
 constexpr int XROW2 = 127;                // first row of the 2-way tiles' exchange area (32 KiB: rows 127..254)
 static_assert(WNBUF * WCH == 2 * TPC * WCHUNK, "the ring takes the place of the two three-tap buffers");
 
@@ -748,6 +749,7 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     __builtin_amdgcn_sched_barrier(0);                                                                       \
   }
 
+  CARO_SHIFT_BEGIN(KS, wave)  // nothing in the product build (caro_net_exp.h)
   for (int layer = 0; layer < NRES; ++layer) {
     const int c0 = layer * 6;  // first chunk of the layer; 6 % WNBUF == 0, so chunk c0 + k sits in buffer k % WNBUF
     CARO_LST(layer, 0)
@@ -833,6 +835,90 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
         n.w = old[q].w + leaky((mine[4 * q + 3] + part[q].w) + bq[q].w, slope);
         if (ov) *reinterpret_cast<float4*>(rowp + (((g0 + 2 * q) ^ kk) << 2)) = n;
       }
+    } else if constexpr (KS == 4) {
+      // 4-way K-split, balanced epilogue: the four waves of a tile (kq = 0..3: the quarters of K) each FINISH a quarter of
+      // the tile's outputs -- output row 2ty + (kq >> 1), channel groups 2 (kq & 1) and 2 (kq & 1) + 1 -- instead of wave 0
+      // collecting 96 floats per lane in two rounds.  Every wave forms all 32 partial sums, keeps its quarter and hands
+      // the other three to their owners through activation rows the tile never touches (rows 63..254: TB4 * HW <= 63,
+      // checked at upload): 6 ds_write_b128 in front of the "inputs read" barrier, 6 ds_read_b128 behind it.  The sums
+      // are taken in the order kq = 0, 1, 2, 3 as before: bit-identical.  Two barriers per layer instead of four.
+      f32x16 accY0, accY1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float y0 = fmaf(1.f, accM0[e], 0.f), y1 = fmaf(0.f, accM0[e], 0.f);
+        y0 = fmaf(1.f, accM1[e], y0); y1 = fmaf(1.f, accM1[e], y1);
+        y0 = fmaf(1.f, accM2[e], y0); y1 = fmaf(-1.f, accM2[e], y1);
+        y0 = fmaf(0.f, accM3[e], y0); y1 = fmaf(-1.f, accM3[e], y1);
+        accY0[e] = y0;
+        accY1[e] = y1;
+      }
+      const int myrow = kq >> 1, qb = (kq & 1) * 2;  // wave-uniform
+      const float* bias = p.b_res + layer * NF + ct * 32 + 4 * h;
+      const int g0 = ct * 8 + h;  // granule of group q is g0 + 2q
+      float* rowp = act + (orow0 + (myrow ? p.W : 0)) * NF;
+      const int kk = (orow0 + (myrow ? p.W : 0)) & 15;
+      const bool ov = myrow ? ovalid1 : ovalid0;
+      float4 bq[2], old[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bq[j] = *reinterpret_cast<const float4*>(bias + 8 * (qb + j));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        old[j] = ov ? *reinterpret_cast<const float4*>(rowp + (((g0 + 2 * (qb + j)) ^ kk) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+// quarter D of the partial sums, group J of it: row D >> 1, channel group 2 (D & 1) + J   (D, J compile-time)
+#define CARO_QUARTER(D, J)                                                                                              \
+  (((D) >> 1) ? make_float4(accY1[4 * (2 * ((D) & 1) + (J))], accY1[4 * (2 * ((D) & 1) + (J)) + 1],                      \
+                            accY1[4 * (2 * ((D) & 1) + (J)) + 2], accY1[4 * (2 * ((D) & 1) + (J)) + 3])                  \
+              : make_float4(accY0[4 * (2 * ((D) & 1) + (J))], accY0[4 * (2 * ((D) & 1) + (J)) + 1],                      \
+                            accY0[4 * (2 * ((D) & 1) + (J)) + 2], accY0[4 * (2 * ((D) & 1) + (J)) + 3]))
+      float* xa = act + XROW4 * NF + lane * 4;  // [ct][owner d][source s' (the other three in order)][j][lane] float4
+      float4 mine[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        if (d == kq) {
+          mine[0] = CARO_QUARTER(d, 0);
+          mine[1] = CARO_QUARTER(d, 1);
+        } else {
+          const int sp = kq < d ? kq : kq - 1;
+          float* dst = xa + (((ct * 4 + d) * 3 + sp) * 2) * 256;
+          *reinterpret_cast<float4*>(dst) = CARO_QUARTER(d, 0);
+          *reinterpret_cast<float4*>(dst + 256) = CARO_QUARTER(d, 1);
+        }
+      }
+#undef CARO_QUARTER
+      CARO_LST(layer, 2)
+      // every wave has read this layer's input activations, and the partial sums for the other waves have been written
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      CARO_LST(layer, 3)
+      float4 part[4][2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        part[k][0] = part[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k != kq) {
+          const int sp = k < kq ? k : k - 1;
+          const float* src = xa + (((ct * 4 + kq) * 3 + sp) * 2) * 256;
+          part[k][0] = *reinterpret_cast<const float4*>(src);
+          part[k][1] = *reinterpret_cast<const float4*>(src + 256);
+        }
+      }
+      CARO_LST(layer, 4)
+      // in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89); only real cells are written, the rest stay 0
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float4 v = kq == 0 ? mine[j] : part[0][j];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          const float4 t = k == kq ? mine[j] : part[k][j];
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        float4 n;
+        n.x = old[j].x + leaky(v.x + bq[j].x, slope);
+        n.y = old[j].y + leaky(v.y + bq[j].y, slope);
+        n.z = old[j].z + leaky(v.z + bq[j].z, slope);
+        n.w = old[j].w + leaky(v.w + bq[j].w, slope);
+        if (ov) *reinterpret_cast<float4*>(rowp + (((g0 + 2 * (qb + j)) ^ kk) << 2)) = n;
+      }
     } else {
     // output transform: Y0 += {1,1,1,0}[p] * M_p,  Y1 += {0,1,-1,-1}[p] * M_p, p = 0..3 in this order
     f32x16 accY0, accY1;
@@ -868,40 +954,8 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     CARO_LST(layer, 3)
-    if (KS > 1) {
-      // partial sums of the waves kq > 0 -> ring buffer 2 (it held the layer's last chunk; the next fetch into it is
-      // issued at the barrier of the next layer's second chunk) -> added by the wave kq == 0 of the same tile, in the
-      // order kq = 1, 2, 3.  The buffer holds four partials of 8 KiB: with KS = 4 the third wave goes second.
-      float* red = wbuf + 2 * WCH;
-      constexpr int NTASK = 2 * NRT;
-      const int task = rt * 2 + ct;
-#pragma unroll
-      for (int round = 0; round < (KS == 4 ? 2 : 1); ++round) {
-        const int k_lo = round == 0 ? 1 : 3, k_hi = round == 0 ? (KS == 4 ? 2 : KS - 1) : 3;
-        if (kq >= k_lo && kq <= k_hi) {
-          float* dst = red + ((kq - k_lo) * NTASK + task) * 2048 + lane;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            dst[e * 64] = accY0[e];
-            dst[(16 + e) * 64] = accY1[e];
-          }
-        }
-        __syncthreads();
-        if (kq == 0) {
-          for (int k = k_lo; k <= k_hi; ++k) {
-            const float* src = red + ((k - k_lo) * NTASK + task) * 2048 + lane;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              accY0[e] += src[e * 64];
-              accY1[e] += src[(16 + e) * 64];
-            }
-          }
-        }
-        if (KS == 4 && round == 0) __syncthreads();  // the partials of kq = 1, 2 have been read
-      }
-    }
     CARO_LST(layer, 4)
-    const bool writer = kq == 0;
+    const bool writer = true;  // (the K-split tiles have their own epilogues above)
     // in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89); only real cells are written, the rest stay 0
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -925,6 +979,7 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     __syncthreads();
     CARO_LST(layer, 6)
   }
+  CARO_SHIFT_END(KS, wave)
 #undef CARO_STEP
 #undef CARO_AWAIT
 #undef CARO_ALOAD
@@ -941,6 +996,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   float* wbuf = lds + ACT;
 
   CARO_PST(0)
+  const unsigned long long t_abs0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0;  // diagnostic only
   int L, row0, board0, nb, nb_cap = p0.TB;
   int ks = 1;  // K-split of this workgroup's tiles (1: a full tile of TB boards)
   bool second = false;
@@ -1048,7 +1104,9 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   CARO_PST(12)
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
-    stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
+    // slot launches (the engine's own: caro_net_debug_stamps) carry the wall clock of the workgroup's START above bit 20
+    stamps[4 * blockIdx.x + 1] = gpack ? ((__builtin_amdgcn_s_memrealtime() - t_abs0) & 0xFFFFFull) | (t_abs0 << 20)
+                                       : __builtin_amdgcn_s_memrealtime() - t_r0;
     stamps[4 * blockIdx.x + 2] = t_trunk0 - t_c0;
     stamps[4 * blockIdx.x + 3] = t_trunk1 - t_c0;
     CARO_HST_PUBLISH(stamps, wbuf)  // nothing in the product build
@@ -1430,6 +1488,7 @@ struct caro_net {
   uint32_t* wtab_dev;  // tile table (f32w mode), or null
   float* wpT_dev;      // policy matrix transposed, or null
   int device;
+  unsigned long long* dbg_stamps;  // diagnostic (caro_net_debug_stamps): per-workgroup stamps of the slot launches too
 };
 
 static int nfail(int code, const std::string& m) {
@@ -1645,6 +1704,7 @@ int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats
   // (boards with an even height whose tile count divides 64 -- 8x8 -- fill 128 rows: no 2-way tiles for them)
   if (n->p.TB2 * H * W > cnet::XROW2) n->p.TB2 = 0;
   n->p.TB4 = 32 / tpb < n->p.TB ? 32 / tpb : 0;
+  if (n->p.TB4 * H * W > cnet::XROW4) n->p.TB4 = 0;  // likewise the 4-way tiles: rows XROW4..254
   return 0;
 }
 
@@ -1700,7 +1760,7 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
                          counts_dev, which, row1, probs_dev, values_dev, gpack, G, B);
     else if (n0->p.ww)
       hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
-                         counts_dev, which, row1, probs_dev, values_dev, stamps, gpack, G, B);
+                         counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B);
     else
       hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, stamps, gpack, G, B);
@@ -1765,6 +1825,14 @@ int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t
   if (n->kind != 0 || n->p.w3) return nfail(CARO_E_STATE, "stamps: float32 conv kernels only");
   return net_launch(n, n, planes_dev, counts_dev, which, -1, max_rows, probs_dev, values_dev, nullptr, 0, 0,
                     (unsigned long long*)stamps_dev, stream);
+}
+
+/* diagnostic: every later launch of this net's float32 kernels -- the engine's slot launches included -- writes its
+ * per-workgroup stamps (as caro_net_forward_stamped) to stamps_dev u64[4 * grid]; NULL switches it off */
+int caro_net_debug_stamps(caro_net* n, uint64_t* stamps_dev) {
+  if (!n) return nfail(CARO_E_INVAL, "null argument");
+  n->dbg_stamps = (unsigned long long*)stamps_dev;
+  return 0;
 }
 
 }  // extern "C"

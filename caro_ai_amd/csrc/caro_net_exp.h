@@ -57,4 +57,15 @@ extern "C" int caro_exp_read_pst(unsigned long long* out_host) {
 #define CARO_PST(n)
 #endif
 
+// 25: TIMING ONLY (results wrong): the waves of row tiles 2, 3 run one barrier behind those of row tiles 0, 1 through the
+//     whole trunk of a full tile -- the question is what the matrix pipe gains when one half's layer epilogue falls into
+//     the other half's main loop
+#if defined(CARO_EXP) && CARO_EXP == 25
+#define CARO_SHIFT_BEGIN(KS_, wave_) if ((KS_) == 1 && (wave_) >= 4) __builtin_amdgcn_s_barrier();
+#define CARO_SHIFT_END(KS_, wave_) if ((KS_) == 1 && (wave_) < 4) __builtin_amdgcn_s_barrier();
+#else
+#define CARO_SHIFT_BEGIN(KS_, wave_)
+#define CARO_SHIFT_END(KS_, wave_)
+#endif
+
 #endif

@@ -275,6 +275,10 @@ int caro_net_forward_pair_at(caro_net* n0, caro_net* n1, const float* planes_dev
 int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t* counts_dev, int which,
                              int64_t max_rows, float* probs_dev, float* values_dev, uint64_t* stamps_dev,
                              void* stream);
+/* diagnostic: from now on every launch of this net's float32 kernels -- the engine's own launches included -- writes the
+ * same per-workgroup stamps to stamps_dev u64[4 * grid] (grid <= games * batch / boards per workgroup + 2);
+ * NULL switches it off.  tools/probe_engine_net.py only */
+int caro_net_debug_stamps(caro_net* n, uint64_t* stamps_dev);
 /* MCTS.search_batch (lib/mcts.py:162-176) for every live game with the fused net(s): `searches` x
  * (caro_select -> caro_net_forward per net -> caro_expand_backup) enqueued on `stream` from one call, no host
  * synchronisation.  noise_dev: f64[searches, G, batch, A] or NULL (generated); buffers as for caro_select /

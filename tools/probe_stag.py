@@ -30,7 +30,7 @@ for rep in range(3):
     print("   expand_body phases (median / p90 / max): round-1 loads %s | insert %s | flatten %s | entries %s | rows %s | owners + edges %s | queue entries %s"
           % tuple([np.percentile(ph[:, i], [50, 90, 100]).round(0) for i in range(6)] + [np.percentile(x[ok, 7], [50, 90, 100])]))
     noise, loop, end, maxd = d[:, 0], d[:, 2], d[:, 3], d[:, 4]
-    step, exp, whole = d[:, 5], d[:, 6], d[:, 7]
+    step, exp, whole = (out[:G * 8].reshape(G, 8)[:, 5] & np.uint64(0xFFFFFF)).astype(np.float64), d[:, 6], d[:, 7]
     st = step > 500
     print("launch %d: whole block (median / p90 / p99 / max)" % rep, q(whole), "| blocks with a ply: %d" % st.sum())
     print("   expand + backup", q(exp), "| select part (to the end of its own stamps)", q(end))
