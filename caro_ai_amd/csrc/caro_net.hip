@@ -67,7 +67,7 @@ struct NetParams {
   const float* b_v2;    // [1]
   const float* w_p;     // [A][2*HW]
   const float* b_p;     // [A]
-  const float* w_pT;    // [2*HW][A]: w_p transposed (made at upload), for boards whose head block is not staged in LDS
+  const float* w_pT;    // w_p quad-transposed (made at upload: per plane [HW/4][A][4] + [HW%4][A]), for boards whose head block is not staged in LDS
   const uint4* w3;      // 3xbf16 mode: [45 taps][1536 granules] LDS image of the split residual weights, or null
   const float* ww;      // f32w mode: [5][3 dx][2 granule halves] chunks of [4 p][2 h][64 co][16] transformed residual weights (LDS image order of trunk_w), or null
   const uint32_t* wtab; // f32w mode: [128] tile of MFMA row (row tile, lane): board | ty << 8 | x << 16 | valid << 24
@@ -267,15 +267,30 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
 #pragma unroll 8
       for (int c = 0; c < HW; ++c) s = fmaf(f1[c], w[HW + c], s);
     } else {
-      // large boards (the matrix is 405 KB at 15x15 and stays in L2): the same chain from the TRANSPOSED matrix, so
-      // that the threads of a wave -- consecutive outputs a -- read consecutive floats.  Row-major, every lane walked
-      // its own 1.8 KB row: 64 cache lines per wave instruction.
-      const float* w = p.w_pT + a;
-#pragma unroll 16
-      for (int c = 0; c < HW; ++c) s = fmaf(f0[c], w[(size_t)c * A], s);
-      w += (size_t)HW * A;
-#pragma unroll 16
-      for (int c = 0; c < HW; ++c) s = fmaf(f1[c], w[(size_t)c * A], s);
+      // large boards (the matrix is 405 KB at 15x15 and stays in L2): the same chain from a QUAD-TRANSPOSED image of the
+      // matrix (made at upload: per plane [cell / 4][A][4], then the HW % 4 last cells as [cell][A]), so that the lanes
+      // of a wave -- consecutive outputs a -- read consecutive 16-byte granules and a lane gets four cells per load.
+      // Row-major, every lane walked its own 1.8 KB row (64 cache lines per wave instruction); cell-major with one
+      // float per load (round 2) the chain waited for 450 loads, 16 in flight: 60 cycles per cell.
+      const int nq = HW >> 2, rem = HW & 3;
+      const size_t half = ((size_t)HW * A + 3) & ~(size_t)3;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const float* f = pl ? f1 : f0;
+        const float* wh = p.w_pT + pl * half;
+        const float4* wq = reinterpret_cast<const float4*>(wh) + a;
+        // (eight granules in flight per lane; sixteen, or the next batch requested under the current one's 32 dependent
+        // fma, ran slower: 13.4-13.8 k cycles for the FC stage against 10.2 k -- the stage streams the 405 KB matrix at
+        // 40 bytes per cycle and compute unit, more requests in flight only evict each other)
+#pragma unroll 8
+        for (int q = 0; q < nq; ++q) {
+          const float4 w = wq[(size_t)q * A];
+          s = fmaf(f[4 * q], w.x, s); s = fmaf(f[4 * q + 1], w.y, s);
+          s = fmaf(f[4 * q + 2], w.z, s); s = fmaf(f[4 * q + 3], w.w, s);
+        }
+        const float* wr = wh + (size_t)nq * A * 4 + a;
+        for (int r = 0; r < rem; ++r) s = fmaf(f[4 * nq + r], wr[(size_t)r * A], s);
+      }
     }
     logit[k] = s;
   }
@@ -291,16 +306,38 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
       values[omap[vt]] = tanhf(s);
     }
   }
+  // the row maximum (exact in any order).  Small action counts: every thread scans its board's row.  Large ones (A > 32:
+  // 225 reads per thread at 15x15): sixteen threads per board take a strided sixteenth each, then every thread reads
+  // the sixteen partial maxima -- 30 reads instead of 225 for one more barrier.
+  float* pmax = ebuf + 1024;  // [TB][16]   (TB * A <= 1024 and A > 32: at most 512 floats, up to HEAD_STAGE_AT)
+  static_assert(768 + 20 * 32 + 256 * 4 + 128 + 1024 + 512 <= HEAD_STAGE_AT, "heads scratch layout");
+  const bool wide = A > 32;
+  if (wide) {
+    for (int idx = tid; idx < nb * 16; idx += NT) {
+      const int bi = idx >> 4, j = idx & 15;
+      const float* lg = logit + bi * A;
+      float m = -3.4e38f;
+      for (int a = j; a < A; a += 16) m = fmaxf(m, lg[a]);
+      pmax[idx] = m;
+    }
+    __syncthreads();
+  }
   for (int k = tid; k < nb * A; k += NT) {
     const int bi = k / A;
     float mx = -3.4e38f;
-    const float* lg = logit + bi * A;
-    int a = 0;
-    for (; a + 8 <= A; a += 8) {  // eight reads in flight
-      const float t0 = lg[a], t1 = lg[a + 1], t2 = lg[a + 2], t3 = lg[a + 3], t4 = lg[a + 4], t5 = lg[a + 5], t6 = lg[a + 6], t7 = lg[a + 7];
-      mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, t0), fmaxf(t1, t2)), fmaxf(fmaxf(t3, t4), fmaxf(t5, t6))), t7);
+    if (wide) {
+      const float* pm = pmax + bi * 16;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) mx = fmaxf(mx, pm[j]);
+    } else {
+      const float* lg = logit + bi * A;
+      int a = 0;
+      for (; a + 8 <= A; a += 8) {  // eight reads in flight
+        const float t0 = lg[a], t1 = lg[a + 1], t2 = lg[a + 2], t3 = lg[a + 3], t4 = lg[a + 4], t5 = lg[a + 5], t6 = lg[a + 6], t7 = lg[a + 7];
+        mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, t0), fmaxf(t1, t2)), fmaxf(fmaxf(t3, t4), fmaxf(t5, t6))), t7);
+      }
+      for (; a < A; ++a) mx = fmaxf(mx, lg[a]);
     }
-    for (; a < A; ++a) mx = fmaxf(mx, lg[a]);
     ebuf[k] = expf(logit[k] - mx);
   }
   __syncthreads();
@@ -1579,11 +1616,18 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   p.w_pT = nullptr;
   p.ncu = 0; p.TB2 = 0; p.TB4 = 0;
   if (cnet::head_span_host(HW, A) > cnet::HEAD_STAGE_MAX) {  // the policy matrix column-major for the large-board heads
-    const size_t np = (size_t)A * 2 * HW;
+    // per plane: [cell / 4][A][4], then the last HW % 4 cells as [cell][A]; a plane's image starts on a 16-byte boundary
+    const size_t half = ((size_t)HW * A + 3) & ~(size_t)3, np = 2 * half;
     const float* wp_host = packed_host + (p.w_p - n->dev);
-    std::vector<float> t(np);
+    std::vector<float> t(np, 0.f);
+    const int nq = HW / 4;
     for (int a = 0; a < A; ++a)
-      for (int c = 0; c < 2 * HW; ++c) t[(size_t)c * A + a] = wp_host[(size_t)a * 2 * HW + c];
+      for (int pl = 0; pl < 2; ++pl)
+        for (int c = 0; c < HW; ++c) {
+          const float w = wp_host[(size_t)a * 2 * HW + pl * HW + c];
+          const size_t at = c < 4 * nq ? ((size_t)(c >> 2) * A + a) * 4 + (c & 3) : (size_t)nq * A * 4 + (size_t)(c - 4 * nq) * A + a;
+          t[pl * half + at] = w;
+        }
     if (hipMalloc((void**)&n->wpT_dev, np * sizeof(float)) != hipSuccess ||
         hipMemcpy(n->wpT_dev, t.data(), np * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
       if (n->wpT_dev) (void)hipFree(n->wpT_dev);
