@@ -408,6 +408,40 @@ __device__ __forceinline__ void tile_rows(const int32_t* __restrict__ gpack, int
 }
 
 
+// tile_rows with this thread's share of gpack already in registers (k_net_forward_w requests it first thing, beside
+// the leaf count: as a load inside tile_rows -- behind the weight transfers this kernel has issued by then -- its wait
+// was a wait for the two 32 KiB weight chunks as well, 4 k cycles that the dense form spends in conv_in).
+// gv[u] = gpack[tid * cpt + u] (0 beyond G), mine = this thread's leaf count of class cls.
+constexpr int GP_PRE = 4;  // games per thread held in registers (G <= GP_PRE * NT; more: tile_rows)
+__device__ __forceinline__ void tile_rows_pre(const int (&gv)[GP_PRE], int cpt, int mine, int B, int cls, int board0,
+                                              int nb, int* sc, int* smap, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  int inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) sc[wave] = inc;
+  __syncthreads();
+  int ex = inc - mine;
+  for (int w = 0; w < wave; ++w) ex += sc[w];
+  if (ex < board0 + nb && ex + mine > board0) {
+#pragma unroll
+    for (int u = 0; u < GP_PRE; ++u) {
+      const int v = gv[u];
+      if (u >= cpt || (v >> 8) != cls) continue;
+      const int n = v & 0xFF, g = tid * cpt + u;
+      for (int j = 0; j < n; ++j) {
+        const int r = ex + j - board0;
+        if (r >= 0 && r < nb) smap[r] = g * B + j;
+      }
+      ex += n;
+    }
+  }
+  __syncthreads();
+}
+
 // `which` = 0 / 1: rows of that net only (p0 is used).  `which` = 2: both nets in ONE launch -- tiles
 // [0, ceil(L0/TB)) run net 0 on rows [0, L0), the following tiles run net 1 (p1) on rows [L0, L0+L1).
 __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p1, const float* __restrict__ planes,
@@ -1034,6 +1068,15 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
 
   CARO_PST(0)
   const unsigned long long t_abs0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0;  // diagnostic only
+  // slot form: this thread's share of the games' leaf counts is requested beside the launch's totals (tile_rows_pre)
+  const int gcpt = gpack ? (gG + NT - 1) / NT : 0;
+  const bool gpre = gpack && gcpt <= GP_PRE;
+  int gv[GP_PRE];
+#pragma unroll
+  for (int u = 0; u < GP_PRE; ++u) {
+    const int g = (int)threadIdx.x * gcpt + u;
+    gv[u] = gpre && u < gcpt && g < gG ? gpack[g] : 0;
+  }
   int L, row0, board0, nb, nb_cap = p0.TB;
   int ks = 1;  // K-split of this workgroup's tiles (1: a full tile of TB boards)
   bool second = false;
@@ -1096,6 +1139,12 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   const int R = nb * HW;  // real rows
   const int tid = threadIdx.x;
 
+  // this thread's leaf count of the tile's class: consumed HERE, in front of the weight transfers (the wait for gv is
+  // then a wait for gv alone)
+  int gmine = 0;
+#pragma unroll
+  for (int u = 0; u < GP_PRE; ++u) gmine += (gv[u] >> 8) == (second ? 1 : 0) ? (gv[u] & 0xFF) : 0;
+  asm volatile("" : "+v"(gmine));
   // the first two weight chunks are on their way into ring buffers 0 and 1 while conv_in runs; its scratch (the
   // conv_in weights, the row map) sits in buffer 2, which is fetched into only after the trunk's first barrier
   float* win = wbuf + 2 * WCH;
@@ -1117,7 +1166,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 2 x 4 chunk transfers of this thread may still be on their way
   CARO_PST(3)
   int* smap = reinterpret_cast<int*>(win + 1536);  // [TB] plane / output row of every board of this tile
-  tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
+  if (gpre) tile_rows_pre(gv, gcpt, gmine, gB, second ? 1 : 0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
+  else tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);
   CARO_PST(4)
   conv_in_mfma(p, planes, smap, act, win, R, tid);
   CARO_PST(5)

@@ -36,7 +36,10 @@ def _boards(L, shape, seed):
 
 @pytest.mark.parametrize("shape,A,weights", [((2, 6, 7), 7, "best_026_12000.dat"), ((2, 3, 3), 9, "best_005_00900.dat"),
                                              ((2, 15, 15), 225, None), ((2, 5, 5), 25, None), ((2, 10, 10), 100, None),
-                                             ((2, 6, 6), 36, None)])  # 6x6: the largest head block that is staged in LDS (two transfers)
+                                             ((2, 6, 6), 36, None),  # 6x6: the largest head block that is staged in LDS (two transfers)
+                                             # 8x8, 4x4: a 2- / 4-way tile would fill 128 / 64 activation rows and leave no
+                                             # room for the partial-sum exchange (rows 127.. / 63..): full tiles only
+                                             ((2, 8, 8), 64, None), ((2, 4, 4), 16, None)])
 @pytest.mark.parametrize("L", [1, 5, 6, 7, 29, 300])
 @pytest.mark.parametrize("mode", ["f32", "f32w", "3xbf16"])
 def test_hip_net_matches_torch_fp32(shape, A, weights, L, mode):
