@@ -193,3 +193,27 @@ def test_default_net_kernel_bits_are_the_committed_ones():
     assert set(got) == set(want)
     bad = sorted(k for k in want if got[k] != want[k])
     assert not bad, bad
+
+
+@pytest.mark.parametrize("rows", [6, 200, 700, 1500])
+def test_debug_stamps_leave_the_outputs_alone(rows):
+    """caro_net_debug_stamps (tools/probe_engine_net.py): with the stamp buffer set every launch of the net also
+    writes its per-workgroup clock; the outputs are the bits of a launch without it, at every tile class."""
+    from caro_ai_amd import _lib
+    from caro_ai_amd.net_hip import HipNet
+    L = _lib.load()
+    hn = HipNet(_net((2, 6, 7), 7, "best_026_12000.dat"), "cuda:0")
+    x = _boards(rows, (2, 6, 7), rows).to("cuda:0")
+    p0, v0 = hn(x)
+    stamps = torch.zeros(4 * 2048, dtype=torch.int64, device="cuda:0")
+    _lib.check(L.caro_net_debug_stamps(hn.h, C.c_void_p(stamps.data_ptr())))
+    p1, v1 = hn(x)
+    _lib.check(L.caro_net_debug_stamps(hn.h, None))
+    p2, v2 = hn(x)
+    torch.cuda.synchronize()
+    assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(p0, p2) and torch.equal(v0, v2)
+    s = stamps.cpu().numpy().reshape(-1, 4)
+    wg = s[s[:, 0] > 0]
+    assert len(wg) >= (rows + 5) // 6            # every workgroup with boards left its stamps
+    assert (wg[:, 3] > wg[:, 2]).all() and (wg[:, 0] > wg[:, 3]).all()   # trunk start < trunk end < total
+    hn.close()
