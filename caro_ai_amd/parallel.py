@@ -15,6 +15,7 @@ Exchanges (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box,
                      `every`-th move ONE count all-gather and ONE byte-packed payload
                      all-gather move them all.
   broadcast_weights  state_dict broadcast from rank 0 after a training step.
+  allreduce_grads    optional data-parallel training step: one flat gradient bucket summed over the ranks.
   allreduce_sum      arena W/L/D counters, expansion counters.
 """
 import os
@@ -227,6 +228,24 @@ class TupleGatherer:
                 "players": allb[:, 8 * KW:8 * KW + 4].contiguous().view(torch.int32).reshape(tot).to(out_dev),
                 "z": allb[:, 8 * KW + 4:8 * KW + 8].contiguous().view(torch.int32).reshape(tot).to(out_dev),
                 "pi": allb[:, 8 * KW + 8:].contiguous().view(self.pi_dtype).reshape(tot, A).to(out_dev)}
+
+
+def allreduce_grads(params):
+    """data-parallel training step (SURVEY 8(f)1 "optional DDP grad all-reduce"): SUM of every parameter's gradient
+    over the ranks, as ONE flat bucket (the net is 0.3-1.2 MB: a single collective, latency bound over xGMI).  The
+    caller has already scaled its loss by its share of the global batch, so the sum IS the full-batch gradient."""
+    if not is_dist():
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    allreduce_sum(flat)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
 
 
 def broadcast_weights(net, src=0):

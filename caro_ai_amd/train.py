@@ -15,7 +15,8 @@ artefacts as the reference:
 
 Declared deviations: a fresh tree per game instead of one store shared across games,
 eval-mode batch-norm during search.  Multi-GPU: games are sharded (caro_ai_amd.parallel), tuples are
-all-gathered, rank 0 trains and broadcasts the weights.
+all-gathered, rank 0 trains and broadcasts the weights (--ddp: every rank trains on its share of each batch and the
+gradients are all-reduced, train_neural_net).
 
     python -m caro_ai_amd.train -n run -g 0 --cuda --games 256 --iterations 50
 """
@@ -101,20 +102,44 @@ def loss_terms(out_logits, out_values, probs, values):
 
 
 def train_neural_net(game, replay_buffer, net, optimizer, device="cuda:0", train_rounds=cfg.TRAIN_ROUNDS,
-                     batch_size=cfg.BATCH_SIZE, generator=None):
+                     batch_size=cfg.BATCH_SIZE, generator=None, ddp=False):
     """TRAIN_ROUNDS SGD steps on batches sampled from the replay buffer; returns the mean losses
-    (what train.py:113-117 sends to TensorBoard as loss_total / loss_value / loss_policy)."""
+    (what train.py:113-117 sends to TensorBoard as loss_total / loss_value / loss_policy).
+
+    ddp=True (several ranks, every rank calls this with the SAME buffer content and the same `generator` state -- the
+    gathered tuples are identical everywhere): the ranks draw the same batch, each runs forward / backward on its
+    share rank::world of it with the loss scaled by share / batch, the gradients are summed over the ranks
+    (parallel.allreduce_grads: one flat bucket over RCCL) and every rank takes the same optimizer step, so the weights
+    stay identical without a broadcast.  The sum is the gradient of the reference's full-batch loss EXCEPT for the
+    batch-norm statistics, which each rank takes over its own share (declared deviation; the default, ddp=False, is the
+    reference's single-device step on rank 0 followed by a weight broadcast)."""
     net.train()
     sums = np.zeros(3)
+    rank, world = 0, 1
+    if ddp and parallel.is_dist():
+        rank, _, world = parallel.env_rank()
     for _ in range(train_rounds):
         states, players, probs, values = replay_buffer.sample(batch_size, generator)
-        x = replay_buffer.planes(states, players)
+        if world > 1:
+            states, players, probs, values = (t[rank::world] for t in (states, players, probs, values))
+        share = states.shape[0] / batch_size
         optimizer.zero_grad()
-        out_logits, out_values = net(x)
-        loss, loss_value, loss_policy = loss_terms(out_logits, out_values, probs, values)
-        loss.backward()
+        if states.shape[0]:
+            x = replay_buffer.planes(states, players)
+            out_logits, out_values = net(x)
+            loss, loss_value, loss_policy = loss_terms(out_logits, out_values, probs, values)
+            (loss * share).backward()
+            local = torch.stack([loss.detach(), loss_value.detach(), loss_policy.detach()]).double() * share
+        else:
+            local = torch.zeros(3, dtype=torch.float64, device=states.device)
+        if world > 1:
+            for p in net.parameters():  # a rank with an empty share still takes part in the collective
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            parallel.allreduce_grads(list(net.parameters()))
+            parallel.allreduce_sum(local)
         optimizer.step()
-        sums += [loss.item(), loss_value.item(), loss_policy.item()]
+        sums += local.cpu().numpy()
     sums /= train_rounds
     return {"loss_total": sums[0], "loss_value": sums[1], "loss_policy": sums[2]}
 
@@ -235,6 +260,9 @@ def parse_args(argv=None):
     p.add_argument("--games", type=int, default=256, help="self-play games per iteration (reference: PLAY_EPISODES=1)")
     p.add_argument("--iterations", type=int, default=0, help="stop after this many iterations (0 = run for ever)")
     p.add_argument("--saves", default="saves")
+    p.add_argument("--ddp", action="store_true",
+                   help="several ranks: every rank trains on its share of each batch, gradients all-reduced "
+                        "(default: rank 0 trains, the weights are broadcast)")
     return p.parse_args(argv)
 
 
@@ -265,10 +293,16 @@ def main(argv=None):
                 len(replay_buffer)), flush=True)
         if len(replay_buffer) < cfg.MIN_REPLAY_TO_TRAIN:
             continue
-        if rank == 0:
+        if args.ddp and world > 1:
+            gen = torch.Generator(device=replay_buffer.device)
+            gen.manual_seed(step_idx)  # every rank draws the same batches from its (identical) buffer
+            losses = train_neural_net(game, replay_buffer, net, optimizer, device, generator=gen, ddp=True)
+        elif rank == 0:
             losses = train_neural_net(game, replay_buffer, net, optimizer, device)
+        if rank == 0:
             for k, v in losses.items():
                 writer.add_scalar(k, v, step_idx)
+        # (ddp: the parameters are already identical; the batch-norm running statistics are each rank's own: rank 0's go out)
         parallel.broadcast_weights(net)
         if step_idx % cfg.EVALUATE_EVERY_STEP == 0:
             win_ratio = evaluate(game, net, best_net.target_model, rounds=cfg.EVALUATION_ROUNDS, device=device,

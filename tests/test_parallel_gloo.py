@@ -335,3 +335,81 @@ def test_play_cli_two_ranks_on_one_gpu_equals_single_rank():
     assert res[0][0] == {os.path.basename(k): v for k, v in agents.items()}
     assert res[0][1] == {(os.path.basename(i), os.path.basename(j)): v for (i, j), v in pairs.items()}
     assert sum(res[0][1][("best_026_12000.dat", "best_025_10600.dat")]) == 6
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from caro_ai_amd import parallel
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    from caro_ai_amd.train import DeviceReplayBuffer, train_neural_net
+    parallel.init(backend="gloo")
+    torch.set_num_threads(1)
+    game = ConnectFour()
+    net, opt, buf = _ddp_setup(game, Net, DeviceReplayBuffer)
+    gen = torch.Generator().manual_seed(5)
+    losses = train_neural_net(game, buf, net, opt, device="cpu", train_rounds=3, batch_size=24, generator=gen, ddp=True)
+    q.put((rank, losses, {k: v.numpy().copy() for k, v in net.state_dict().items()
+                          if "running" not in k and "num_batches" not in k}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _ddp_setup(game, Net, DeviceReplayBuffer):
+    """same net, optimizer and replay content wherever it is called; batch-norm in eval mode inside train() so that
+    the statistics do not depend on how the batch is split (the one declared difference of the ddp step)"""
+    torch.manual_seed(11)
+    net = Net(game.obs_shape, game.action_space)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.train = lambda mode=True, _m=m: torch.nn.Module.train(_m, False)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+    buf = DeviceReplayBuffer(game, 64, "cpu")
+    rng = np.random.default_rng(3)
+    states, players = [], []
+    s, pl = game.initial_state, 1
+    for _ in range(40):  # a few legal positions
+        mv = game.possible_moves(s)
+        s2, won = game.move(s, int(rng.choice(mv)), pl)
+        states.append(s2); players.append(1 - pl)
+        s, pl = (game.initial_state, 1) if won or not game.possible_moves(s2) else (s2, 1 - pl)
+    pi = rng.random((40, 7)); pi /= pi.sum(1, keepdims=True)
+    buf.extend({"states": torch.from_numpy(game.to_keys(states).astype(np.int64)).reshape(40, -1),
+                "players": torch.tensor(players, dtype=torch.int32), "pi": torch.from_numpy(pi),
+                "z": torch.from_numpy(rng.integers(-1, 2, 40))})
+    return net, opt, buf
+
+
+def test_ddp_training_step_two_ranks_equals_one():
+    """train_neural_net(ddp=True) on two gloo ranks: both end with the same parameters, and -- with the batch-norm
+    statistics frozen, the one thing the split changes -- they are the single-process step's parameters."""
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    from caro_ai_amd.train import DeviceReplayBuffer, train_neural_net
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        r, losses, sd = q.get(timeout=300)
+        got[r] = (losses, sd)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for k in got[0][1]:
+        assert np.array_equal(got[0][1][k], got[1][1][k]), k       # identical on both ranks, bit for bit
+    assert got[0][0] == got[1][0]
+    torch.set_num_threads(1)
+    game = ConnectFour()
+    net, opt, buf = _ddp_setup(game, Net, DeviceReplayBuffer)
+    gen = torch.Generator().manual_seed(5)
+    one = train_neural_net(game, buf, net, opt, device="cpu", train_rounds=3, batch_size=24, generator=gen)
+    for k, v in net.state_dict().items():
+        if k in got[0][1]:
+            assert np.allclose(v.numpy(), got[0][1][k], rtol=1e-4, atol=1e-6), k
+    for k in one:
+        assert abs(one[k] - got[0][0][k]) < 1e-5 * max(1.0, abs(one[k])), (k, one[k], got[0][0][k])
