@@ -820,6 +820,9 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     __builtin_amdgcn_sched_barrier(0);                                                                       \
   }
 
+  float4 res0[4], res1[4];  // full tile: the lane's own output cells of the last layer (the next layer's residual input)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) res0[q] = res1[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   CARO_SHIFT_BEGIN(KS, wave)  // nothing in the product build (caro_net_exp.h)
   for (int layer = 0; layer < NRES; ++layer) {
     const int c0 = layer * 6;  // first chunk of the layer; 6 % WNBUF == 0, so chunk c0 + k sits in buffer k % WNBUF
@@ -1013,10 +1016,18 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     float4 bq[4], old0[4], old1[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + 8 * q);
+    if (layer == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      old0[q] = ovalid0 ? *reinterpret_cast<const float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
-      old1[q] = ovalid1 ? *reinterpret_cast<const float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < 4; ++q) {
+        old0[q] = ovalid0 ? *reinterpret_cast<const float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        old1[q] = ovalid1 ? *reinterpret_cast<const float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {  // this lane wrote these very cells in the last layer's epilogue: they stayed in registers
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        old0[q] = res0[q];
+        old1[q] = res1[q];
+      }
     }
     CARO_LST(layer, 2)
     // every wave has read this layer's input activations (its LDS reads were waited for in the last step): they may be
@@ -1041,6 +1052,8 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
       n1.w = old1[q].w + leaky(accY1[4 * q + 3] + bq[q].w, slope);
       if (ovalid0 && writer) *reinterpret_cast<float4*>(row0p + (((g0 + 2 * q) ^ k0) << 2)) = n0;
       if (ovalid1 && writer) *reinterpret_cast<float4*>(row1p + (((g0 + 2 * q) ^ k1) << 2)) = n1;
+      res0[q] = ovalid0 ? n0 : make_float4(0.f, 0.f, 0.f, 0.f);
+      res1[q] = ovalid1 ? n1 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     }
     CARO_LST(layer, 5)
