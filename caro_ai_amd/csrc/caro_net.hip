@@ -871,9 +871,14 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
       float4 bq[4], old[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + 8 * q);
+      if (layer == 0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        old[q] = ov ? *reinterpret_cast<const float4*>(rowp + (((g0 + 2 * q) ^ kk) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q)
+          old[q] = ov ? *reinterpret_cast<const float4*>(rowp + (((g0 + 2 * q) ^ kk) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {  // the cells this wave finished in the last layer (res0, as in the full tile)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) old[q] = res0[q];
+      }
       f32x16 mine, send;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -908,6 +913,7 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
         n.z = old[q].z + leaky((mine[4 * q + 2] + part[q].z) + bq[q].z, slope);
         n.w = old[q].w + leaky((mine[4 * q + 3] + part[q].w) + bq[q].w, slope);
         if (ov) *reinterpret_cast<float4*>(rowp + (((g0 + 2 * q) ^ kk) << 2)) = n;
+        res0[q] = ov ? n : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else if constexpr (KS == 4) {
       // 4-way K-split, balanced epilogue: the four waves of a tile (kq = 0..3: the quarters of K) each FINISH a quarter of
@@ -935,9 +941,14 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
       float4 bq[2], old[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) bq[j] = *reinterpret_cast<const float4*>(bias + 8 * (qb + j));
+      if (layer == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        old[j] = ov ? *reinterpret_cast<const float4*>(rowp + (((g0 + 2 * (qb + j)) ^ kk) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 2; ++j)
+          old[j] = ov ? *reinterpret_cast<const float4*>(rowp + (((g0 + 2 * (qb + j)) ^ kk) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) old[j] = res0[j];
+      }
 // quarter D of the partial sums, group J of it: row D >> 1, channel group 2 (D & 1) + J   (D, J compile-time)
 #define CARO_QUARTER(D, J)                                                                                              \
   (((D) >> 1) ? make_float4(accY1[4 * (2 * ((D) & 1) + (J))], accY1[4 * (2 * ((D) & 1) + (J)) + 1],                      \
@@ -992,6 +1003,7 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
         n.z = old[j].z + leaky(v.z + bq[j].z, slope);
         n.w = old[j].w + leaky(v.w + bq[j].w, slope);
         if (ov) *reinterpret_cast<float4*>(rowp + (((g0 + 2 * (qb + j)) ^ kk) << 2)) = n;
+        res0[j] = ov ? n : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
     // output transform: Y0 += {1,1,1,0}[p] * M_p,  Y1 += {0,1,-1,-1}[p] * M_p, p = 0..3 in this order
