@@ -35,6 +35,6 @@ for rows in [int(a) for a in sys.argv[1:]] or [200, 717, 1434]:
           "conv_in", "chunks arrived + barrier"]
     print("   prologue:", " | ".join("%s %.0f" % (n, np.median(q[:, i + 1] - q[:, i])) for i, n in enumerate(pn)),
           "| total %.0f" % np.median(q[:, 6] - q[:, 0]))
-    hn = ["1x1 convolutions", "FC stage", "softmax + stores", "tail"]
-    print("   heads:", " | ".join("%s %.0f" % (n, np.median(q[:, 9 + i] - q[:, 8 + i])) for i, n in enumerate(hn)),
+    hnames = ["1x1 convolutions", "FC stage", "softmax + stores", "tail"]
+    print("   heads:", " | ".join("%s %.0f" % (n, np.median(q[:, 9 + i] - q[:, 8 + i])) for i, n in enumerate(hnames)),
           "| total %.0f" % np.median(q[:, 12] - q[:, 8]))
