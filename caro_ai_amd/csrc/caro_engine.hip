@@ -1663,6 +1663,8 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
       v.dbg[(size_t)g * 8 + 5] = ((t2 - t1) & 0xFFFFFFull) | (__builtin_amdgcn_s_memrealtime() << 24);
       v.dbg[(size_t)g * 8 + 6] = t1 - t0;
       v.dbg[(size_t)g * 8 + 7] = __builtin_amdgcn_s_memtime() - t0;
+      // where the tree wave ran (HW_ID: wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13), above the depth in slot 4
+      v.dbg[(size_t)g * 8 + 4] |= (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8;
     }
   }
 }

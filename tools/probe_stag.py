@@ -29,7 +29,18 @@ for rep in range(3):
     ph = np.diff(x[ok, :7], axis=1)
     print("   expand_body phases (median / p90 / max): round-1 loads %s | insert %s | flatten %s | entries %s | rows %s | owners + edges %s | queue entries %s"
           % tuple([np.percentile(ph[:, i], [50, 90, 100]).round(0) for i in range(6)] + [np.percentile(x[ok, 7], [50, 90, 100])]))
-    noise, loop, end, maxd = d[:, 0], d[:, 2], d[:, 3], d[:, 4]
+    raw4 = out[:G * 8].reshape(G, 8)[:, 4]
+    noise, loop, end, maxd = d[:, 0], d[:, 2], d[:, 3], (raw4 & np.uint64(0xFF)).astype(np.float64)
+    hw = (raw4 >> np.uint64(8)).astype(np.int64)
+    simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+    if rep == 0:
+        place = {}
+        for b in range(G):
+            place.setdefault((b % 8, int(se[b]), int(sh[b]), int(cu[b]), int(simd[b])), []).append(b)
+        per = np.bincount([len(v_) for v_ in place.values()], minlength=5)
+        print("   tree waves per (XCD, SE, SH, CU, SIMD): histogram of 1, 2, 3, 4+ =", per[1], per[2], per[3], per[4:].sum(),
+              "| SIMD ids used:", np.bincount(simd, minlength=4))
+        print("   blocks 0..15 ->", [(int(b % 8), int(se[b]), int(cu[b]), int(simd[b])) for b in range(16)])
     step, exp, whole = (out[:G * 8].reshape(G, 8)[:, 5] & np.uint64(0xFFFFFF)).astype(np.float64), d[:, 6], d[:, 7]
     st = step > 500
     print("launch %d: whole block (median / p90 / p99 / max)" % rep, q(whole), "| blocks with a ply: %d" % st.sum())
