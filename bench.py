@@ -158,51 +158,91 @@ def _free_port():
     return port
 
 
-def self_launch(n):
+def self_launch(n, argv=None, script=None, poll_s=0.2, timeout_s=1500.0):
     """`python bench.py --gpus N` with WORLD_SIZE unset: start the N ranks ourselves (one child process per GPU,
     the environment torchrun would give them), relay what they print, return the worst exit code.  This parent
-    never initialises the GPU (`device_count()` does not, on this image) and skips the CPU baseline."""
+    never touches the GPU runtime: the GPUs are counted from the KFD topology in sysfs (parallel.visible_gpu_count,
+    honouring ROCR_/HIP_VISIBLE_DEVICES), not through torch.cuda; it skips the CPU baseline.
+    All children are polled together: the first one that fails (or the deadline) ends the others at once instead
+    of leaving them in init_process_group / a collective until their own time-outs."""
     import subprocess
-    have = torch.cuda.device_count()
+    from caro_ai_amd import parallel
+    have = parallel.visible_gpu_count()
     if have < n and not os.environ.get("CARO_SHARE_GPU"):
-        print("[bench] --gpus %d but %d visible GPU(s); set CARO_SHARE_GPU=1 (+ CARO_DIST_BACKEND=gloo) to rehearse "
-              "on fewer" % (n, have), file=sys.stderr)
+        print("[bench] --gpus %d but %d visible GPU(s) in the KFD topology; set CARO_SHARE_GPU=1 (+ "
+              "CARO_DIST_BACKEND=gloo) to rehearse on fewer" % (n, have), file=sys.stderr)
         return 2
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n),
                LOCAL_WORLD_SIZE=str(n))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
     procs = []
-    for r in range(n):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
-    rcs = []
-    for p in procs:  # stdout / stderr are inherited: rank 0's JSON line lands on our stdout as it is
-        try:
-            rcs.append(p.wait(timeout=1500))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(124)
-    worst = max(rcs, key=abs) if rcs else 1
+    for r in range(n):  # stdout / stderr are inherited: rank 0's JSON line lands on our stdout as it is
+        procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
+    rcs = [None] * n
+    deadline = time.monotonic() + timeout_s
+    failed = None
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+                if rcs[i] not in (None, 0) and failed is None:
+                    failed = i
+        if failed is not None or time.monotonic() > deadline:
+            break
+        time.sleep(poll_s)
+    if any(rc is None for rc in rcs):  # a rank failed or the deadline passed: end the survivors
+        why = "rank %d exited with code %s" % (failed, rcs[failed]) if failed is not None else "deadline passed"
+        print("[bench] %s: terminating the other ranks" % why, file=sys.stderr, flush=True)
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                p.terminate()
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+                rcs[i] = 124 if failed is None else 143
+    worst = rcs[failed] if failed is not None else max(rcs, key=abs)
     if worst:
         print("[bench] rank exit codes: %s" % rcs, file=sys.stderr)
     return worst
 
 
-def dist_record(world, device, value_local):
-    """what the collective layer really is in this run: backend, world size, each rank's device and own value"""
+def dist_record(world, device, value_local, want_world):
+    """what the collective layer really is in this run: backend, world size, each rank's device and own value.
+    Raises if the run is not what --gpus asked for: world size != --gpus, or two ranks on one device without
+    CARO_SHARE_GPU (a wrong LOCAL_RANK -> device mapping would otherwise pass as an N-GPU number)."""
     import socket
     import torch.distributed as dist
+    props = torch.cuda.get_device_properties(device)
     mine = {"rank": int(os.environ.get("RANK", "0")), "device": str(device),
-            "device_name": torch.cuda.get_device_name(device), "pid": os.getpid(), "host": socket.gethostname(),
-            "value": value_local}
+            "device_name": torch.cuda.get_device_name(device),
+            # distinguishes physical GPUs even when every rank calls its own `cuda:0` (per-rank HIP_VISIBLE_DEVICES)
+            "device_uuid": str(getattr(props, "uuid", "")) or None,
+            "pci_bus_id": getattr(props, "pci_bus_id", None),
+            "pid": os.getpid(), "host": socket.gethostname(), "value": value_local}
     if world == 1:
-        return {"backend": None, "world_size": 1, "ranks": [mine]}
-    ranks = [None] * world
-    dist.all_gather_object(ranks, mine)
-    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-            "collectives": "RCCL over xGMI" if dist.get_backend() == "nccl" else "gloo (rehearsal, host memory)",
-            "ranks": ranks}
+        rec = {"backend": None, "world_size": 1, "ranks": [mine]}
+    else:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        rec = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+               "collectives": "RCCL over xGMI" if dist.get_backend() == "nccl" else "gloo (rehearsal, host memory)",
+               "ranks": ranks}
+    vals = [r["value"] for r in rec["ranks"]]
+    rec["value_min"], rec["value_max"] = min(vals), max(vals)
+    rec["shared_gpu"] = bool(os.environ.get("CARO_SHARE_GPU"))
+    if rec["world_size"] != want_world:
+        raise SystemExit("[bench] world size %d != --gpus %d" % (rec["world_size"], want_world))
+    # two ranks sit on one GPU only if host, device index, PCI bus id and uuid ALL agree
+    ident = [(r["host"], r["device"], r["pci_bus_id"], r["device_uuid"]) for r in rec["ranks"]]
+    if len(set(ident)) != len(ident) and not rec["shared_gpu"]:
+        raise SystemExit("[bench] two ranks on one GPU without CARO_SHARE_GPU: %s" % ident)
+    return rec
 
 
 # ------------------------------------------------------------------ one timed configuration
@@ -379,8 +419,27 @@ class Leg:
             # hip3x issues 6 bf16 MFMA flops per algorithmic flop: priced against the dense bf16 peak / 6
             peak = MFMA_F32_PEAK_TFS if args.net != "hip3x" else MFMA_BF16_PEAK_TFS / 6.0
             kname = NET_KERNEL[args.net]
-            roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": pmc.get(kname, {}).get("hbm"),
+            # What the matrix pipe EXECUTES per launch.  hipw (row-Winograd F(2,3)): 60 transformed taps x 32 MFMAs x
+            # 8 waves x 4096 flop per workgroup of TB boards, tile padding and the last partial tile included -- 2/3 of
+            # the 3x3 multiplies of the direct form.  hip / hip3x: the direct form executes its algorithmic count.
+            executed = None
+            if args.net == "hipw":
+                tb = self.hipnet.L.caro_net_boards_per_workgroup(self.hipnet.h)
+                wg_flops = self.hipnet.workgroup_mfma_flops()
+                executed = math.ceil(leaves_per_launch / tb) * wg_flops / avg_s / 1e12
+            ex = executed if executed is not None else achieved
+            roofline = {"bound": "mfma", "kernel": kname,
+                        # `achieved` / `frac` = flops the MFMA pipe executes per launch / launch time
+                        # (a utilisation figure, <= 1 by construction, comparable with the PMC busy fraction);
+                        # the direct-convolution count is kept beside it as algorithmic_*
+                        "achieved": ex, "peak": peak, "unit": "TFLOP/s", "frac": ex / peak,
+                        "algorithmic_achieved": achieved, "algorithmic_frac": achieved / peak,
+                        "note": "achieved = flops the matrix pipe executes per launch (Winograd form: fewer multiplies "
+                                "than the direct convolution; tile padding included) / launch time measured with HIP "
+                                "events in this run; algorithmic_* prices SURVEY 8(d)'s direct-convolution flops per "
+                                "leaf over the same time and can exceed 1 for a Winograd kernel; mfma_busy_pmc is the "
+                                "hardware's own count from the committed --pmc pass",
+                        "traffic": pmc.get(kname, {}).get("hbm"),
                         "traffic_source": (traffic_note + "; the net's algorithmic bytes per launch are planes + "
                                            "priors + the weights once (%.2f MB): the measured figure is higher because "
                                            "every XCD's L2 reads the weight taps itself -- harmless for a kernel bound "
@@ -391,19 +450,10 @@ class Leg:
                         if pmc.get(kname) else None,
                         "mfma_busy_pmc": pmc.get(kname, {}).get("mfma_busy"),
                         "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), rocprofv3 --pmc pass of "
-                                          "this configuration (%s): the primary utilisation figure" % PMC_FILE
+                                          "this configuration (%s)" % PMC_FILE
                         if pmc.get(kname, {}).get("mfma_busy") else None,
                         "avg_launch_us": avg_s * 1e6, "launches_timed": n, "leaves_per_launch": leaves_per_launch,
                         "flops_per_leaf": flops_per_leaf}
-            if args.net == "hipw":
-                # the Winograd form issues 2/3 of the 3x3-conv multiplies: what the MFMA pipe itself executes
-                # (60 taps x 32 MFMAs x 8 waves x 4096 flop per workgroup of TB boards, padding included)
-                tb = self.hipnet.L.caro_net_boards_per_workgroup(self.hipnet.h)
-                issued = math.ceil(leaves_per_launch / tb) * 60 * 32 * 8 * 4096.0 / avg_s / 1e12
-                roofline["note"] = ("achieved = algorithmic (direct-convolution) flops per launch / launch time; "
-                                    "mfma_issued = flops the MFMA pipe executes in the F(2,3) form; the PMC MFMA-busy "
-                                    "fraction of the same kernel is in " + PMC_FILE)
-                roofline["mfma_issued"] = {"achieved": issued, "frac": issued / peak}
             kernel_us += S * avg_s * 1e6
         if roofline is None:  # torch evaluators: the net is not our kernel; the tree walk is the dominant own kernel
             roofline = roofline_tree
@@ -535,7 +585,7 @@ def main():
     leg = Leg(args, args.game, args.games, args.searches, args.batch, args.arena, rank, world, device,
               evict=args.evict, node_cap=args.node_cap)
     res = leg.run(args.steps, args.warmup, profile=not args.no_profile)
-    dist_rec = dist_record(world, device, res.pop("value_local"))
+    dist_rec = dist_record(world, device, res.pop("value_local"), args.gpus)
     sustained = None
     if world == 1 and headline and args.sustained_moves > 0:
         # the timed region above is ~0.1 s; the same engine keeps playing: a steady-state figure with finished games

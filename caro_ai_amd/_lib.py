@@ -85,6 +85,7 @@ _SIGNATURES = {
     "caro_drain_parked_begin": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "caro_counters": (C.c_int, [_P, _P, _P]),
     "caro_live_games": (C.c_int, [_P, _P, _P]),
+    "caro_pending_leaves": (C.c_int, [_P, _P, _P]),
     "caro_debug_stamps": (C.c_int, [_P, C.c_int]),
     "caro_debug_read": (C.c_int, [_P, _P, C.c_int64, _P]),
     "caro_profile_enable": (C.c_int, [_P, C.c_int]),

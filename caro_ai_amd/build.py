@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libcaro_hip.so")
 SOURCES = [os.path.join(CSRC, "caro_engine.hip"), os.path.join(CSRC, "caro_net.hip")]
 DEPS = SOURCES + [os.path.join(CSRC, "caro_rules.h"), os.path.join(CSRC, "caro_variants.h"),
-                  os.path.join(CSRC, "caro_host.inc"), os.path.join(CSRC, "caro_net_exp.h"),
+                  os.path.join(CSRC, "caro_host.inc"),
                   os.path.join(HERE, "..", "include", "caro_hip.h"),
                   os.path.join(HERE, "..", "include", "caro_noise.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

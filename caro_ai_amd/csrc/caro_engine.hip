@@ -534,6 +534,7 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
     }
   } else if (helper_nz) {
     while (*helper_flag == 0) __builtin_amdgcn_s_sleep(2);  // the noise wave started when this one did: rarely waits
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // pairs with the noise wave's release: the rows behind the flag
 #pragma unroll
     for (int j = 0; j < APL; ++j) nz[j] = helper_nz[b * AP + l * APL + j];
   } else {
@@ -1595,19 +1596,28 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
   __shared__ int s_flag;
   const int g = blockIdx.x;
   if (threadIdx.x == 0) s_flag = 0;
-  __syncthreads();  // the only s_barrier of the block: the flag is clear before the noise wave can set it
+  // One round of loads for everything that depends on g alone, by BOTH waves and in FRONT of the block's only
+  // s_barrier: the barrier waits for them (the fence in __syncthreads drains vmcnt), so the noise wave holds the
+  // game's uid / ply / clock as they were when the block started -- whatever the tree wave writes later (the ply in
+  // step_body, the restart in park_and_restart, lm at the end) cannot reach it.  Both waves wait the same latency side
+  // by side; the tree wave needed these values first thing anyway.
+  const int w = v.wait[g];
+  int lm = v.lm[g];
+  const int pend = v.pend[g];
+  GameRegs<GEO> gr = load_game<GEO>(v, g);
+  __syncthreads();  // also: the flag is clear before the noise wave can set it
   if (threadIdx.x >= 64) {
     // the noise wave: rows of the minibatch the tree wave is about to select.  A game whose ply is due moves first:
     // its rows are those of the NEXT ply's minibatch 0 (if the ply ends the game the slot restarts on an empty tree,
     // or stays finished: no descent gets as far as using a row).
-    const int go = v.wait[g] == 0 && v.done[g] == 0;
-    int lm_h = go ? v.lm[g] : 0;
-    uint32_t ply_h = go ? (uint32_t)v.ply[g] : 0u;
+    const int go = w == 0 && gr.done == 0;
+    int lm_h = go ? lm : 0;
+    uint32_t ply_h = go ? (uint32_t)gr.ply : 0u;
     if (lm_h == v.stag_S) {
       lm_h = 0;
       ply_h += 1u;
     }
-    noise_wave<GEO>(v, B, go, go ? v.uid[g] : 0ull, ply_h, lm_h, s_nz, &s_flag);
+    noise_wave<GEO>(v, B, go, go ? gr.uid : 0ull, ply_h, lm_h, s_nz, &s_flag);
     return;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1617,11 +1627,6 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
     rows_cur[2] = B;
   }
   const unsigned long long t0 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
-  // one round of loads for everything that depends on g alone
-  const int w = v.wait[g];
-  int lm = v.lm[g];
-  const int pend = v.pend[g];
-  GameRegs<GEO> gr = load_game<GEO>(v, g);
   if (w > 0) {  // not started yet
     if (threadIdx.x == 0) {
       v.wait[g] = w - 1;
@@ -1806,6 +1811,15 @@ __global__ void k_sum_counters(View v) {
 __global__ void k_count_live(View v, int32_t* out) {
   int c = 0;
   for (int g = threadIdx.x; g < v.G; g += blockDim.x) c += v.done[g] == 0;
+  atomicAdd(out, c);
+}
+
+// unique leaves selected but not booked as expansions yet: the counters' identity at any point of a run is
+// sims == expansions + terminals + dropped + pending (+ the leaves of overflowed minibatches)
+__global__ void k_count_pending(View v, int all_pending, int32_t* out) {
+  int c = 0;
+  for (int g = threadIdx.x; g < v.G; g += blockDim.x)
+    if (v.stag_S ? v.pend[g] != 0 : all_pending) c += v.g_nleaf[g];
   atomicAdd(out, c);
 }
 
@@ -2156,6 +2170,7 @@ int caro_noise_batch(uint64_t seed, int64_t M, int A, double alpha, const uint64
 }
 
 // ---- engine
+static int reset_games_impl(caro_engine* h, const int32_t* first_player_dev, void* stream);
 int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   if (!cfg || !out) return fail(CARO_E_INVAL, "null argument");
   const Variant var = pick_variant(cfg->game_kind, cfg->n);
@@ -2267,7 +2282,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   HIPCHK(hipHostMalloc((void**)&h->pinned, 64, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&h->pinned64, 128, hipHostMallocDefault));
   *out = h;
-  rc = caro_reset_games(h, nullptr, nullptr);
+  rc = reset_games_impl(h, nullptr, nullptr);
   if (rc) { caro_engine_destroy(h); *out = nullptr; return rc; }
   if (v.stag_S) {
     HIPCHK(hipMemset(v.dirty, 0, sizeof(int32_t) * T));
@@ -2287,8 +2302,7 @@ void caro_engine_destroy(caro_engine* h) {
   delete h;
 }
 
-int caro_reset_games(caro_engine* h, const int32_t* first_player_dev, void* stream) {
-  if (!h) return fail(CARO_E_INVAL, "null engine");
+static int reset_games_impl(caro_engine* h, const int32_t* first_player_dev, void* stream) {
   DISPATCH(h->var, hipLaunchKernelGGL(k_reset<GEO>, dim3(h->v.G), dim3(256), 0, (hipStream_t)stream, h->v,
                                       first_player_dev));
   HIPCHK(hipGetLastError());
@@ -2296,8 +2310,17 @@ int caro_reset_games(caro_engine* h, const int32_t* first_player_dev, void* stre
   return 0;
 }
 
+// A staggered engine carries per-game state the lock-step entry points know nothing about (lm, pend, wait, parked
+// records, flipped / dirty key tables): every lock-step mutator refuses it instead of leaving that state stale.
+int caro_reset_games(caro_engine* h, const int32_t* first_player_dev, void* stream) {
+  if (!h) return fail(CARO_E_INVAL, "null engine");
+  if (h->v.stag_S) return fail(CARO_E_STATE, "caro_reset_games: the engine runs in staggered mode (per-game clocks, pending minibatches, parked games); use caro_search_staggered / caro_drain_parked_begin");
+  return reset_games_impl(h, first_player_dev, stream);
+}
+
 int caro_set_roots(caro_engine* h, const uint64_t* keys, const int32_t* players, void* stream) {
   if (!h || !keys || !players) return fail(CARO_E_INVAL, "null argument");
+  if (h->v.stag_S) return fail(CARO_E_STATE, "caro_set_roots: the engine runs in staggered mode (per-game clocks, pending minibatches, parked games); use caro_search_staggered / caro_drain_parked_begin");
   DISPATCH(h->var, hipLaunchKernelGGL(k_set_roots<GEO>, dim3((h->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                                       h->v, keys, players));
   HIPCHK(hipGetLastError());
@@ -2308,6 +2331,7 @@ int caro_select(caro_engine* h, int batch, int mb_index, const double* noise, fl
                 void* stream) {
   if (!h || !planes) return fail(CARO_E_INVAL, "null argument");
   if (batch < 1 || batch > h->v.maxB) return fail(CARO_E_INVAL, "batch exceeds max_batch of the engine");
+  if (h->v.stag_S) return fail(CARO_E_STATE, "caro_select: the engine runs in staggered mode (per-game clocks, pending minibatches, parked games); use caro_search_staggered / caro_drain_parked_begin");
   if (h->select_pending) return fail(CARO_E_STATE, "caro_select called twice without caro_expand_backup");
   const int lpd = variant_lpd(h->var);
   hipStream_t st = (hipStream_t)stream;
@@ -2354,6 +2378,7 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
   const int64_t max_rows = (int64_t)h->v.G * batch;
   const size_t noise_stride = (size_t)h->v.G * batch * h->v.A;
   if (batch < 1 || batch > h->v.maxB) return fail(CARO_E_INVAL, "batch exceeds max_batch of the engine");
+  if (h->v.stag_S) return fail(CARO_E_STATE, "caro_search_batch: the engine runs in staggered mode (per-game clocks, pending minibatches, parked games); use caro_search_staggered / caro_drain_parked_begin");
   if (h->select_pending) return fail(CARO_E_STATE, "caro_search_batch with a pending caro_select");
   hipStream_t st = (hipStream_t)stream;
   // one 64-lane wavefront per game: the fused tree kernel (k_tree), two launches per minibatch
@@ -2470,6 +2495,7 @@ int caro_policy(caro_engine* h, double* pi, int32_t* counts, void* stream) {
 
 int caro_step(caro_engine* h, const double* uniforms, int32_t* actions, int32_t* done, int32_t* result, void* stream) {
   if (!h) return fail(CARO_E_INVAL, "null engine");
+  if (h->v.stag_S) return fail(CARO_E_STATE, "caro_step: the engine runs in staggered mode (per-game clocks, pending minibatches, parked games); use caro_search_staggered / caro_drain_parked_begin");
   if (h->select_pending) return fail(CARO_E_STATE, "caro_step with a pending caro_select");
   const int p0 = prof_begin(h, PK_STEP, (hipStream_t)stream);
   DISPATCH(h->var, hipLaunchKernelGGL(k_step<GEO>, dim3(h->v.G), dim3(64), 0, (hipStream_t)stream, h->v, uniforms,
@@ -2488,6 +2514,7 @@ int caro_step(caro_engine* h, const double* uniforms, int32_t* actions, int32_t*
 int caro_drain_tuples_begin(caro_engine* h, int64_t cap, uint64_t* states, int32_t* players, double* pi, int32_t* z,
                             int64_t* games, int recycle, void* stream) {
   if (!h || !states || !players || !pi || !z) return fail(CARO_E_INVAL, "null argument");
+  if (h->v.stag_S) return fail(CARO_E_STATE, "caro_drain_tuples_begin: the engine runs in staggered mode (per-game clocks, pending minibatches, parked games); use caro_search_staggered / caro_drain_parked_begin");
   if (h->select_pending) return fail(CARO_E_STATE, "caro_drain_tuples with a pending caro_select");
   if (h->drain_pending) return fail(CARO_E_STATE, "caro_drain_tuples_begin twice without caro_drain_tuples_end");
   hipStream_t st = (hipStream_t)stream;
@@ -2631,6 +2658,17 @@ int caro_live_games(caro_engine* h, int32_t* live, void* stream) {
   HIPCHK(hipMemcpyAsync(h->pinned + 4, h->live, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   *live = h->pinned[4];
+  return 0;
+}
+
+int caro_pending_leaves(caro_engine* h, int32_t* pending, void* stream) {
+  if (!h || !pending) return fail(CARO_E_INVAL, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(h->live, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_count_pending, dim3(1), dim3(256), 0, st, h->v, h->select_pending, h->live);
+  HIPCHK(hipMemcpyAsync(h->pinned + 4, h->live, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *pending = h->pinned[4];
   return 0;
 }
 

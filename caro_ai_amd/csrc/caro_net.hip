@@ -36,7 +36,6 @@
 
 #include "../../include/caro_hip.h"
 #include "../../include/caro_noise.h"
-#include "caro_net_exp.h"  // experiment switches: every macro is the product behaviour unless -DCARO_EXP=N
 
 namespace cnet {
 
@@ -219,8 +218,8 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
   const float* w_p = STAGED ? b_v2 + 1 : p.w_head + nsmall;
   const float* b_p = w_p + (size_t)A * 2 * HW;
   float* feat = scratch;  // [3][256]: value plane, policy plane 0, policy plane 1 (row indexed)
-  CARO_HST_BEGIN(scratch, tid)  // nothing in the product build (caro_net_exp.h)
-  CARO_HST(0)
+  /*@HST_BEGIN(scratch, tid)*/
+  /*@HST(0)*/
   float* hid = feat + 768;              // [TB][20]
   float* logit = feat + 768 + 20 * 32;  // [TB * A] (TB * A <= 1024, see caro_net_create)
   float* stat = logit + 256 * 4;        // [TB][2] max, sum  (logit region sized 1024 floats)
@@ -242,8 +241,8 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
     feat[o * 256 + r] = leaky(s0, slope);
   }
   __syncthreads();
-  CARO_HST(1)
-  CARO_PST(9)
+  /*@HST(1)*/
+  /*@PST(9)*/
   // value head: Linear(HW,20) + LeakyReLU -- threads from 0 up
   for (int k = tid; k < nb * 20; k += NT) {
     const int bi = k / 20, u = k - bi * 20;
@@ -295,8 +294,8 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
     logit[k] = s;
   }
   __syncthreads();
-  CARO_HST(2)
-  CARO_PST(10)
+  /*@HST(2)*/
+  /*@PST(10)*/
   // Linear(20,1) + tanh on the last wave; beside it the softmax terms exp(logit - max), one thread per action
   {
     const int vt = tid - (NT - 64);
@@ -353,8 +352,8 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
     stat[2 * tid + 1] = sum;
   }
   __syncthreads();
-  CARO_HST(3)
-  CARO_PST(11)
+  /*@HST(3)*/
+  /*@PST(11)*/
   for (int k = tid; k < nb * A; k += NT) {
     const int bi = k / A;
     probs[(size_t)omap[bi] * A + (k - bi * A)] = ebuf[k] / stat[2 * bi + 1];
@@ -686,9 +685,10 @@ __device__ __forceinline__ void fetch_heads(const float* hp, int hspan, unsigned
   if (hspan > NT * 4) dma_b128(src + NT, dst + NT * 16);
 }
 
-// CARO_CHUNK_BARRIER / CARO_FETCH_ON: the chunk barrier and the weight fetch of the product build; the removal builds
-// of the timing experiments redefine them in caro_net_exp.h (measured at 1434 leaves: trunk 296 k cycles, 293 k / 289 k /
-// 281 k without barriers / fetches / both: the fetches cost what their 960 KiB per workgroup take of the LDS write port).
+// Comments of the form /*@NAME(...)*/ are the probe points of the timing experiments: tools/exp/build_exp.py turns them
+// into macro calls in a COPY of this file (tools/exp/caro_net_exp.h); here they are comments and nothing else.
+// (Measured that way at 1434 leaves: trunk 296 k cycles; 293 k / 289 k / 281 k without chunk barriers / weight fetches /
+// both: the fetches cost what their 960 KiB per workgroup take of the LDS write port.)
 template <int KS>
 __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* wbuf, int nb, int tid, int hspan) {
   const float slope = p.slope;
@@ -780,9 +780,9 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
   if ((T) % NQ == 0) {                                                                                       \
     if ((T) != 0) {                                                                                          \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
-      CARO_CHUNK_BARRIER                                                                                     \
+      /*@CHUNK_BARRIER*/ __syncthreads();                                                                    \
     }                                                                                                        \
-    if (CARO_FETCH_ON && c0 + (T) / NQ + 2 < WNCHUNK) fetch_chunk(p.ww, c0 + (T) / NQ + 2, wring, tid);      \
+    if (/*@FETCH_ON*/ c0 + (T) / NQ + 2 < WNCHUNK) fetch_chunk(p.ww, c0 + (T) / NQ + 2, wring, tid);         \
     else if (c0 + (T) / NQ + 2 == WNCHUNK && hspan) fetch_heads(p.w_head, hspan, wring, tid);                \
   }                                                                                                          \
   {                                                                                                          \
@@ -823,10 +823,10 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
   float4 res0[4], res1[4];  // full tile: the lane's own output cells of the last layer (the next layer's residual input)
 #pragma unroll
   for (int q = 0; q < 4; ++q) res0[q] = res1[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  CARO_SHIFT_BEGIN(KS, wave)  // nothing in the product build (caro_net_exp.h)
+  /*@SHIFT_BEGIN(KS, wave)*/
   for (int layer = 0; layer < NRES; ++layer) {
     const int c0 = layer * 6;  // first chunk of the layer; 6 % WNBUF == 0, so chunk c0 + k sits in buffer k % WNBUF
-    CARO_LST(layer, 0)
+    /*@LST(layer, 0)*/
     f32x16 accM0, accM1, accM2, accM3;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -850,7 +850,7 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
     if constexpr (NSET > 6) { CARO_PAIR(6) CARO_PAIR(8) CARO_PAIR(10) }
     if constexpr (NSET > 12) { CARO_PAIR(12) CARO_PAIR(14) CARO_PAIR(16) CARO_PAIR(18) CARO_PAIR(20) CARO_PAIR(22) }
 #undef CARO_PAIR
-    CARO_LST(layer, 1)
+    /*@LST(layer, 1)*/
     if constexpr (KS == 2) {
       // 2-way K-split, balanced epilogue (round 3): the two waves of a tile (kq = 0 / 1: the halves of K) each FINISH one
       // of the tile's two output rows -- wave kq row 2ty + kq -- instead of wave 0 finishing both while wave 1 idles.
@@ -894,16 +894,16 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(xw + q * 256) = make_float4(send[4 * q], send[4 * q + 1], send[4 * q + 2], send[4 * q + 3]);
-      CARO_LST(layer, 2)
+      /*@LST(layer, 2)*/
       // every wave has read this layer's input activations, and the partner's partial sums have been written
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      CARO_LST(layer, 3)
+      /*@LST(layer, 3)*/
       float4 part[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) part[q] = *reinterpret_cast<const float4*>(xr + q * 256);
-      CARO_LST(layer, 4)
+      /*@LST(layer, 4)*/
       // in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89); only real cells are written, the rest stay 0
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -970,12 +970,12 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
         }
       }
 #undef CARO_QUARTER
-      CARO_LST(layer, 2)
+      /*@LST(layer, 2)*/
       // every wave has read this layer's input activations, and the partial sums for the other waves have been written
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      CARO_LST(layer, 3)
+      /*@LST(layer, 3)*/
       float4 part[4][2];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -987,7 +987,7 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
           part[k][1] = *reinterpret_cast<const float4*>(src + 256);
         }
       }
-      CARO_LST(layer, 4)
+      /*@LST(layer, 4)*/
       // in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89); only real cells are written, the rest stay 0
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -1041,14 +1041,14 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
         old1[q] = res1[q];
       }
     }
-    CARO_LST(layer, 2)
+    /*@LST(layer, 2)*/
     // every wave has read this layer's input activations (its LDS reads were waited for in the last step): they may be
     // overwritten.  A bare s_barrier: __syncthreads() would first wait for the loads just requested
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    CARO_LST(layer, 3)
-    CARO_LST(layer, 4)
+    /*@LST(layer, 3)*/
+    /*@LST(layer, 4)*/
     const bool writer = true;  // (the K-split tiles have their own epilogues above)
     // in place: v = v + leaky(conv(v) + b)   (lib/model.py:85-89); only real cells are written, the rest stay 0
 #pragma unroll
@@ -1068,14 +1068,14 @@ __device__ __forceinline__ void trunk_w(const NetParams& p, float* act, float* w
       res1[q] = ovalid1 ? n1 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     }
-    CARO_LST(layer, 5)
+    /*@LST(layer, 5)*/
     // new activations visible to every wave; it is also the chunk barrier of the next layer's first chunk (this
     // wave's share of its second chunk has arrived, nobody reads this layer's last chunks any more)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    CARO_LST(layer, 6)
+    /*@LST(layer, 6)*/
   }
-  CARO_SHIFT_END(KS, wave)
+  /*@SHIFT_END(KS, wave)*/
 #undef CARO_STEP
 #undef CARO_AWAIT
 #undef CARO_ALOAD
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   float* act = lds;
   float* wbuf = lds + ACT;
 
-  CARO_PST(0)
+  /*@PST(0)*/
   const unsigned long long t_abs0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0;  // diagnostic only
   // slot form: this thread's share of the games' leaf counts is requested beside the launch's totals (tile_rows_pre)
   const int gcpt = gpack ? (gG + NT - 1) / NT : 0;
@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
     board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * nb_cap;
   }
   if (board0 >= L) return;
-  CARO_PST(1)
+  /*@PST(1)*/
   const NetParams p = second ? p1 : p0;
   unsigned long long t_c0 = 0, t_r0 = 0;  // diagnostic only, as in k_net_forward
   if (stamps) {
@@ -1187,22 +1187,21 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   // global memory, so only w_in has to be covered by the 320-lane transfer (what comes along behind it is not used).
   static_assert(2 * (WCH / 4 / NT) == 8, "s_waitcnt vmcnt(8) below counts 2 chunks x WCH / 4 / NT transfers per thread");
   static_assert(320 * 4 >= 9 * 2 * NF, "the 320-lane transfer must cover w_in [9][2][64]");
-  CARO_PST(2)
+  /*@PST(2)*/
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 2 x 4 chunk transfers of this thread may still be on their way
-  CARO_PST(3)
+  /*@PST(3)*/
   int* smap = reinterpret_cast<int*>(win + 1536);  // [TB] plane / output row of every board of this tile
   if (gpre) tile_rows_pre(gv, gcpt, gmine, gB, second ? 1 : 0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
   else tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);
-  CARO_PST(4)
+  /*@PST(4)*/
   conv_in_mfma(p, planes, smap, act, win, R, tid);
-  CARO_PST(5)
+  /*@PST(5)*/
   const int slot_v = tid < nb ? smap[tid] : 0;
   unsigned long long t_trunk0 = 0;
   if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // conv_in's output and the two chunks are visible to every wave
-  CARO_PST(6)
-
+  /*@PST(6)*/
   // head parameters staged in LDS during the trunk's last chunks when they fit (heads_f32)
   const int hspan = head_span(HW, p.A) <= HEAD_STAGE_MAX ? head_span(HW, p.A) : 0;
   if (ks == 1) trunk_w<1>(p, act, wbuf, nb, tid, hspan);
@@ -1210,10 +1209,10 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
   else trunk_w<4>(p, act, wbuf, nb, tid, hspan);
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
-  CARO_PST(8)
+  /*@PST(8)*/
   if (hspan) heads_f32<true>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
   else heads_f32<false>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
-  CARO_PST(12)
+  /*@PST(12)*/
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
     // slot launches (the engine's own: caro_net_debug_stamps) carry the wall clock of the workgroup's START above bit 20
@@ -1221,7 +1220,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
                                        : __builtin_amdgcn_s_memrealtime() - t_r0;
     stamps[4 * blockIdx.x + 2] = t_trunk0 - t_c0;
     stamps[4 * blockIdx.x + 3] = t_trunk1 - t_c0;
-    CARO_HST_PUBLISH(stamps, wbuf)  // nothing in the product build
+    /*@HST_PUBLISH(stamps, wbuf)*/
   }
 }
 

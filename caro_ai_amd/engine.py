@@ -314,6 +314,13 @@ class SelfPlayEngine:
         _lib.check(self.L.caro_live_games(self.h, C.addressof(out), self._stream()))
         return out.value
 
+    def pending_leaves(self):
+        """unique leaves selected but not booked as expansions yet (staggered mode: every game's pending minibatch):
+        sims == expansions + terminals + dropped + pending at any point of a run without overflows"""
+        out = C.c_int32(0)
+        _lib.check(self.L.caro_pending_leaves(self.h, C.addressof(out), self._stream()))
+        return out.value
+
     def tree_sizes(self):
         out = torch.empty(self.G * self.n_stores, dtype=torch.int32, device=self.device)
         _lib.check(self.L.caro_tree_sizes(self.h, _ptr(out), self._stream()))

@@ -156,6 +156,13 @@ class HipNet:
         except Exception:
             pass
 
+    def workgroup_mfma_flops(self):
+        """flops ONE workgroup of the mode's trunk executes on the matrix pipe (v_mfma_f32_32x32x2_f32 = 4096 flop),
+        padding rows included: what bench.py's `roofline.achieved` counts.  f32w: 5 layers x 12 transformed taps
+        (4 p x 3 dx), each 32 k-steps on 8 waves; f32 (direct): 5 x 9 taps."""
+        taps = {"f32w": 60, "f32": 45}.get(self.mode)
+        return None if taps is None else taps * 32 * 8 * 4096.0
+
     def forward_dev(self, planes, counts_dev_ptr, which, max_rows, probs, values, stream):
         _lib.check(self.L.caro_net_forward(self.h, planes.data_ptr(), counts_dev_ptr, which, max_rows,
                                            probs.data_ptr(), values.data_ptr(), stream))

@@ -249,12 +249,70 @@ def allreduce_grads(params):
 
 
 def broadcast_weights(net, src=0):
-    if is_dist():
-        for t in net.state_dict().values():
-            if _via_host(t):
-                h = t.cpu()
-                dist.broadcast(h, src=src)
-                t.copy_(h)
-            else:
-                dist.broadcast(t, src=src)
+    """state_dict of rank `src` to every rank as ONE flat byte buffer (62 tensors, 0.76-1.2 MB: one latency-bound
+    collective instead of 62; float and integer buffers -- num_batches_tracked -- travel side by side as bytes)"""
+    if not is_dist():
+        return net
+    tensors = [t for t in net.state_dict().values() if t.numel()]
+    if not tensors:
+        return net
+    via_host = _via_host(tensors[0])
+    dev = torch.device("cpu") if via_host else tensors[0].device
+    flat = torch.cat([t.detach().contiguous().reshape(-1).view(torch.uint8).to(dev) for t in tensors])
+    dist.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for t in tensors:
+            n = t.numel() * t.element_size()
+            # (clone: a view of another element size needs an aligned storage offset)
+            t.copy_(flat[off:off + n].clone().view(t.dtype).reshape(t.shape).to(t.device))
+            off += n
     return net
+
+
+# ------------------------------------------------------------------ GPUs visible to a launcher, without the runtime
+def _kfd_gpu_nodes(root="/sys/class/kfd/kfd/topology/nodes"):
+    """KFD topology nodes that are GPUs (simd_count > 0; CPU nodes have none), in node order"""
+    out = []
+    try:
+        names = sorted(os.listdir(root), key=lambda x: int(x) if x.isdigit() else 1 << 30)
+    except OSError:
+        return out
+    for nm in names:
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(root, nm, "properties")) if " " in line)
+        except OSError:
+            continue  # a node this process may not read (cgroup device filter): not a GPU it can use
+        if int(props.get("simd_count", "0").strip() or 0) > 0:
+            out.append(nm)
+    return out
+
+
+def visible_gpu_count(root=None, env=None):
+    """Number of GPUs a child process would see, WITHOUT touching the HIP runtime (a launcher must not initialise the
+    GPU before it starts its ranks: no `torch.cuda.*` call here): the KFD topology's GPU nodes, narrowed by
+    ROCR_VISIBLE_DEVICES and then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES the way the runtime applies them (a list
+    of indices -- or UUIDs, counted as one device each -- cut at the first invalid entry)."""
+    env = os.environ if env is None else env
+    if root is None:  # CARO_KFD_TOPOLOGY: another topology directory (tests)
+        root = env.get("CARO_KFD_TOPOLOGY", "/sys/class/kfd/kfd/topology/nodes")
+    n = len(_kfd_gpu_nodes(root))
+
+    def narrow(n, var):
+        v = env.get(var)
+        if v is None:
+            return n
+        cnt = 0
+        for tok in v.split(","):
+            tok = tok.strip()
+            if not tok:
+                break
+            if tok.lstrip("-").isdigit():
+                if not 0 <= int(tok) < n:
+                    break
+            cnt += 1
+        return min(cnt, n)
+
+    n = narrow(n, "ROCR_VISIBLE_DEVICES")
+    hip = "HIP_VISIBLE_DEVICES" if "HIP_VISIBLE_DEVICES" in env else "CUDA_VISIBLE_DEVICES"
+    return narrow(n, hip)

@@ -153,64 +153,84 @@ def staggered_ok(game, batch):
 
 def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0, searches=cfg.MCTS_SEARCHES,
               batch=cfg.MCTS_BATCH_SIZE, concurrent=None, stagger=False):
-    """Play n_games with the (best) net against itself, tuples appended on the device.
+    """Play n_games (per rank) with the (best) net against itself, tuples appended on the device.
     Returns speed_steps, speed_nodes, steps, nodes (train.py:49-58).
+
+    WHICH games: slot g of this rank plays uids uid_base + rank*G + g (+ k * world * G for its k-th restart), and the
+    games wanted are the first n_games of that sequence (local index k*G + g < n_games) -- the same set whether the
+    engine runs lock-step or staggered, whatever finishes first.  With G == n_games (the default) every slot plays
+    exactly its own uid to the end and nothing restarts.  With fewer slots than games the slots restart; slots that
+    run ahead may start games beyond the wanted set while the last wanted ones finish: those are played but their
+    tuples are DROPPED, so the replay buffer never holds a length-biased "first to finish" sample.
     stagger=True (the CLI's choice where the geometry allows): the engine's staggered mode -- every game on its own
-    minibatch clock, finished games restarted in place -- played until at least n_games have finished; the games a
-    slot started beyond that are dropped unfinished.  Each finished game is the one the lock-step form plays for the
-    same uid; only the ORDER in which games reach the replay buffer differs."""
+    minibatch clock; each game is the one the lock-step form plays for the same uid, only the ORDER in which games
+    reach the replay buffer differs."""
     from caro_ai_amd.engine import SelfPlayEngine
     rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
-    G = int(concurrent or n_games)
+    G = max(1, min(int(concurrent or n_games), int(n_games)))
     stagger = bool(stagger) and staggered_ok(game, batch)
+    restarts = n_games > G
+    base, stride = uid_base + rank * G, world * G
     eng = SelfPlayEngine(game, G, net1=net, max_batch=batch, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, seed=seed,
-                         device=device, searches_hint=searches, uid_base=uid_base + rank * G, uid_stride=world * G,
-                         stagger=stagger)
+                         device=device, searches_hint=searches, uid_base=base, uid_stride=stride,
+                         stagger=stagger, stagger_recycle=restarts)
     t0 = time.time()
-    finished = steps = 0
-    if stagger:
-        gatherer = parallel.TupleGatherer(every=1 << 30, pi_dtype=torch.float32)
-        while finished < n_games:
-            d = eng.move(searches, batch)  # host-pipelined: hands out the rows parked during the previous pass
-            if d is not None and int(d["games"].shape[0]):
-                finished += int(d["games"].shape[0])
-                steps += int(d["games"][:, 3].sum().item())
-                gatherer.push(d)
-        d = eng.flush()
-        if d is not None and int(d["games"].shape[0]):
-            finished += int(d["games"].shape[0])
-            steps += int(d["games"][:, 3].sum().item())
-            gatherer.push(d)
-        out = gatherer.flush()
-        if out is not None:
-            replay_buffer.extend(out)
-        c = eng.counters()
-        dt = time.time() - t0
-        eng.close()
-        return {"speed_steps": steps / dt, "speed_nodes": c["expansions"] / dt, "steps": steps,
-                "nodes": c["expansions"], "games": finished}
-    # multi-GPU: every rank plays the same number of moves (the loop below is driven by rank-local counts, so the
-    # exchange is batched and flushed once at the end, when every rank has left the loop)
+    st = {"finished": 0, "steps": 0, "dropped": 0}
+    slot_gen = np.zeros(G, dtype=np.int64)                  # generation each slot is playing (lock-step bookkeeping)
+    last_gen = (n_games - 1 - np.arange(G)) // G             # last wanted generation of each slot
     gatherer = parallel.TupleGatherer(every=1 << 30, pi_dtype=torch.float32)
-    while finished < n_games:
-        eng.search(searches, batch)
-        eng.step()
-        d = eng.drain(recycle=finished + eng.G < n_games)
-        ng = int(d["games"].shape[0])
-        if ng:
-            finished += ng
-            steps += int(d["games"][:, 3].sum().item())
+
+    def take(d):
+        """keep the tuples of the wanted games of one drain"""
+        if d is None or not int(d["games"].shape[0]):
+            return
+        recs = d["games"]
+        off = recs[:, 0] - base
+        k, g = off // stride, off % stride
+        want = (off >= 0) & (g < G) & (k * G + g < n_games)
+        nwant = int(want.sum().item())
+        st["finished"] += nwant
+        st["dropped"] += int(recs.shape[0]) - nwant
+        st["steps"] += int(recs[want, 3].sum().item())
+        np.maximum.at(slot_gen, g[want].cpu().numpy(), k[want].cpu().numpy() + 1)
+        if nwant == int(recs.shape[0]):
             gatherer.push(d)
-        elif eng.live_games() == 0:
-            break
+        elif nwant:
+            keep = torch.repeat_interleave(want, recs[:, 3] + 1)  # a game of s steps holds s + 1 rows
+            gatherer.push({f: d[f][keep] for f in ("states", "players", "pi", "z")})
+
+    if stagger:
+        # every pass of `searches` launches is one ply per game on average; a game has at most HW plies and sits out
+        # fewer than `searches` launches at the start: a bound on the passes that a healthy run never reaches
+        hw = game.obs_shape[1] * game.obs_shape[2]
+        max_passes = (hw + 4) * (-(-n_games // G)) + 8
+        passes = 0
+        while st["finished"] < n_games:
+            take(eng.move(searches, batch, recycle=restarts))  # host-pipelined: hands out the previous pass's rows
+            passes += 1
+            if passes > max_passes:
+                raise _lib.CaroError("self_play: %d of %d games finished after %d passes" % (st["finished"], n_games, passes))
+        take(eng.flush())
+    else:
+        while st["finished"] < n_games:
+            eng.search(searches, batch)
+            eng.step()
+            # restart drained slots while some slot still has a wanted generation to begin
+            d = eng.drain(recycle=bool(restarts and (slot_gen < last_gen).any()))
+            ng = int(d["games"].shape[0])
+            take(d)
+            if not ng and eng.live_games() == 0:
+                break
+    # multi-GPU: the loop above is driven by rank-local counts, so the exchange is ONE collective at the end, when every
+    # rank has left its loop
     out = gatherer.flush()
     if out is not None:
         replay_buffer.extend(out)
     c = eng.counters()
     dt = time.time() - t0
     eng.close()
-    return {"speed_steps": steps / dt, "speed_nodes": c["expansions"] / dt, "steps": steps,
-            "nodes": c["expansions"], "games": finished}
+    return {"speed_steps": st["steps"] / dt, "speed_nodes": c["expansions"] / dt, "steps": st["steps"],
+            "nodes": c["expansions"], "games": st["finished"], "games_dropped": st["dropped"]}
 
 
 def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="cuda:0", seed=0):

@@ -142,7 +142,11 @@ int caro_leaf_counts_dev(caro_engine* h, const int32_t** counts_dev);
 /* Second half (mcts.py:281-287): _create_node (:178-190) for every unique leaf
  * with prior row probs_dev f32[L, A] (softmax ALREADY applied, mcts.py:216) and
  * _backup (:225-246) of terminals (sim order) then new leaves (first-seen
- * order) with values_dev f32[L] (mcts.py:217). Rows are those of caro_select. */
+ * order) with values_dev f32[L] (mcts.py:217). Rows are those of caro_select.
+ * BUFFER SIZES: probs_dev and values_dev must be ALLOCATED for n_games * max_batch rows (the size of the planes buffer
+ * handed to caro_select), whatever L is: the kernel requests a game's value rows before it knows the game's leaf
+ * count (one memory latency less per minibatch), so it reads up to max_batch - 1 rows past the last leaf row --
+ * never past row n_games * max_batch.  Rows >= L are read and ignored; they need not be initialised. */
 int caro_expand_backup(caro_engine* h, const float* probs_dev, const float* values_dev, void* stream);
 
 /* get_policy_value (lib/mcts.py:289-313) of every game's root with the tau the
@@ -188,6 +192,10 @@ int caro_debug_stamps(caro_engine* h, int on);
 int caro_debug_read(caro_engine* h, uint64_t* out_host, int64_t n_u64, void* stream);
 /* number of live (unfinished) games; synchronises */
 int caro_live_games(caro_engine* h, int32_t* live, void* stream);
+/* unique leaves that have been selected but not yet booked as expansions (between caro_select and
+ * caro_expand_backup; in staggered mode the pending minibatch of every game).  At any point of a run
+ * sims == expansions + terminals + dropped + pending (+ the leaves of overflowed minibatches); synchronises */
+int caro_pending_leaves(caro_engine* h, int32_t* pending, void* stream);
 
 /* ---- inspection (tests, MCTS shim: the four public dicts of lib/mcts.py:29-36) ---- */
 /* len(MCTS) per tree: out_dev i32[G*n_stores] */
@@ -303,7 +311,11 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
  *   caro_search_staggered   `launches` x (tree kernel -> net kernel); on average every game moves once per
  *                           `searches` launches
  *   caro_drain_parked_begin tuples of the parked games, as caro_drain_tuples_begin (no recycle flag: the slots have
- *                           restarted already); finish with caro_drain_tuples_end */
+ *                           restarted already); finish with caro_drain_tuples_end
+ * A staggered engine is driven by these two calls only: the lock-step mutators (caro_reset_games, caro_set_roots,
+ * caro_select, caro_search_batch, caro_step, caro_drain_tuples[_begin]) return CARO_E_STATE on it -- they know nothing
+ * of its per-game clocks, pending minibatches and parked records.  Read-only calls (caro_counters, caro_get_roots,
+ * caro_policy, caro_lookup_nodes, caro_tree_sizes, caro_pending_leaves ...) work on both kinds. */
 int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int launches, int batch, float* planes_dev,
                           uint64_t* leaf_keys_dev, float* probs_dev, float* values_dev, void* stream);
 int caro_drain_parked_begin(caro_engine* h, int64_t cap, uint64_t* states_dev, int32_t* players_dev, double* pi_dev,

@@ -220,3 +220,225 @@ def test_staggered_tiny_search_counts(S):
     the reference itself divides by a zero visit total, lib/mcts.py:304-311) and three"""
     _check_against_oracle({"kind": "c4"}, 16, 40, 2, S, 8, 1, seed=90 + S, uid_base=0, form="fused", stagger=True,
                           searches_hint=S)
+
+
+# ------------------------------------------------------------------ the launches bench.py times, at the sizes it times them
+def _full_size_staggered(d, G, S, B, sbt0, n_stores, salts, seed, n_finish, keep_every, max_moves):
+    """A staggered engine at a BASELINE configuration's full size with the exact table net(s) on the device (the
+    launches are bench.py's -- k_tree_stag + slot rows + a device evaluator that reads the leaf counts itself --, only
+    the evaluator is the exact one), slots restarted in place until `n_finish` games have finished.  Checks the
+    size-independent properties (nothing overflows, the sims identity incl. the pending minibatches, every finished
+    game a legal game with a well-formed z, every uid played once) and returns the kept sample {uid: record} --
+    first and later generations of a slot alike -- with the oracle's games of the same uids."""
+    game = _game_of(d)
+    evs = [_synth(game, "fused", s) for s in salts]
+    eng = _engine(game, G, evs, n_stores=n_stores, max_batch=B, steps_before_tau_0=sbt0, seed=seed, uid_base=0,
+                  stagger=True, searches_hint=S)
+    kept, games, moves, finished = {}, [], 0, 0
+    while finished < n_finish:
+        eng.search(S, B)   # S launches: on average every game makes one ply
+        moves += 1
+        dr = eng.drain(recycle=True)
+        ng = dr["games"].shape[0]
+        if ng:
+            gr = dr["games"].cpu().numpy()
+            finished += ng
+            games.append(gr)
+            z = dr["z"].cpu().numpy()
+            st = pi = pl = None
+            off = 0
+            for uid, first, result, steps in gr.tolist():
+                n = steps + 1
+                zz = z[off:off + n]
+                # z alternates back from the last mover: +1 / -1 for a win, all 0 for a draw (utils.py:101-106)
+                assert zz[0] == (1 if result != 0 else 0) and (np.abs(zz) == abs(int(zz[0]))).all(), uid
+                assert (zz[1::2] == -zz[0]).all() and (zz[0::2] == zz[0]).all(), uid
+                if uid % keep_every == 3:
+                    if st is None:
+                        st, pi, pl = dr["states"].cpu().numpy(), dr["pi"].cpu().numpy(), dr["players"].cpu().numpy()
+                    kept[uid] = (first, result, steps, st[off:off + n].copy(), pi[off:off + n].copy(), zz.copy(),
+                                 pl[off:off + n].copy())
+                off += n
+            assert off == z.shape[0]
+        assert moves < max_moves
+    c = eng.counters()
+    pending = eng.pending_leaves()
+    eng.close()
+    games = np.concatenate(games)
+    assert c["overflows"] == 0
+    assert c["sims"] % B == 0 and c["sims"] <= moves * S * G * B
+    assert c["expansions"] + c["terminals"] + c["dropped"] + pending == c["sims"]
+    assert c["finished"] >= len(games) >= n_finish and len(set(games[:, 0].tolist())) == len(games)
+    hw = game.obs_shape[1] * game.obs_shape[2]
+    assert (games[:, 3] >= 6).all() and (games[:, 3] < hw).all()  # four in a row: no game ends before the 7th ply
+    ref = _oracle_games(d, kept.keys(), seed, sbt0, S, B, n_stores, salts=salts if len(salts) == 2 else (salts[0], salts[0]))
+    for uid, (first, result, steps, st, pi, z, pl) in kept.items():
+        r = ref[uid]
+        assert (first, result, steps) == (r["first"], r["result"], r["steps"]), uid
+        assert game.from_keys(st.view(np.uint64)) == r["states"][::-1], uid
+        assert pl.tolist() == r["players"][::-1].tolist(), uid
+        assert np.array_equal(pi, r["pi"][::-1]), uid
+        assert z.tolist() == r["z"][::-1].tolist(), uid
+    return c, games, kept, moves
+
+
+def test_config2_full_size_staggered_whole_games_vs_oracle():
+    """BASELINE config 2 as bench.py runs it: 1024 connect-four games, 25 x 8 sims/move, tau = 1
+    for 10 plies, staggered, slots restarted in place until >= 2048 games have finished; the sampled finished games --
+    first, second and third generation of their slots -- equal the oracle's game of the same uid ply by ply (boards,
+    players, float64 pi, z, result, steps)."""
+    c, games, kept, moves = _full_size_staggered({"kind": "c4"}, 1024, 25, 8, 10, 1, (0,), seed=21, n_finish=2048,
+                                                 keep_every=64, max_moves=400)
+    gens = sorted({uid // 1024 for uid in kept})
+    print("config 2 staggered, full size: %d passes of 25 launches, %d games finished, %d sampled (generations %s), "
+          "sims %d, expansions %d" % (moves, len(games), len(kept), gens, c["sims"], c["expansions"]))
+    assert len(kept) >= 16 and gens[0] == 0 and gens[-1] >= 1
+
+
+def test_config5_full_size_staggered_two_nets_whole_games_vs_oracle():
+    """BASELINE config 5's shape as bench.py runs it: 512 arena matches, two (salted table) nets,
+    one tree per player, 100 x 8 sims/move, tau = 0 from move 0, staggered with restarts until >= 512 matches have
+    finished; sampled matches equal the oracle's ply by ply."""
+    c, games, kept, moves = _full_size_staggered({"kind": "c4"}, 512, 100, 8, 0, 2, (0x1111, 0x2222), seed=5,
+                                                 n_finish=512, keep_every=48, max_moves=200)
+    print("config 5 staggered, full size: %d passes of 100 launches, %d matches finished, %d sampled, sims %d, "
+          "expansions %d" % (moves, len(games), len(kept), c["sims"], c["expansions"]))
+    assert len(kept) >= 8
+
+
+def _two_real_nets(game, names):
+    import os
+    from caro_ai_amd.lib.model import Net
+    from tests.conftest import GOLDEN
+    nets = []
+    for nm in names:
+        net = Net(game.obs_shape, game.action_space)
+        net.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", nm), map_location="cpu"))
+        nets.append(net.to(DEV).eval())
+    return nets
+
+
+def _games_by_uid(game, tuples, recs):
+    ST = np.concatenate([t["states"] for t in tuples])
+    PI = np.concatenate([t["pi"] for t in tuples])
+    by_uid, off = {}, 0
+    for uid, first, result, steps in recs.tolist():
+        n = steps + 1
+        by_uid[uid] = (first, result, steps, ST[off:off + n][::-1].copy(), PI[off:off + n][::-1].copy())
+        off += n
+    return by_uid
+
+
+def test_staggered_two_real_nets_vs_reference_recorded_arena_800_sims():
+    """Config 5's launches with the two REAL nets on the GPU: best_026 vs best_025, 100 x 8
+    sims/move, tau = 0, one tree per player, staggered -- against the 8 arena games RECORDED FROM THE REFERENCE
+    (tests/golden/arena_c4_800.json.gz).  A staggered engine cannot be stopped after a ply, but its replay rows carry
+    pi of every ply (tau = 0: the one-hot of the first maximum of root N = the move played): each game is compared ply
+    by ply for as long as it follows the recorded boards.  Tolerance as for the lock-step comparison
+    (tests/test_gpu_shim.py::test_real_weights_gpu_net_arena_800_sims): >= 99 % of the compared plies carry the
+    reference's pi, and a game that matched at every ply ends with the recorded result and step count.
+    Beside it, exactly: the staggered engine's games are the lock-step engine's games bit for bit (same size, same
+    nets: every launch of either stays in the net kernel's smallest tile class)."""
+    from caro_ai_amd.engine import SelfPlayEngine
+    from tests.conftest import load_golden
+    d = load_golden("arena_c4_800.json.gz")
+    game = _game_of(d)
+    games = d["games"]
+    g0 = games[0]
+    n = len(games)
+    assert [gm["uid"] for gm in games] == list(range(g0["uid"], g0["uid"] + n))
+    n1, n2 = _two_real_nets(game, d["weights"])
+    out = []
+    for stagger in (True, False):
+        eng = SelfPlayEngine(game, n, net1=n1, net2=n2, n_stores=2, max_batch=8, seed=g0["seed"], uid_base=g0["uid"],
+                             steps_before_tau_0=0, first_player_mode=2, device=DEV, searches_hint=100, stagger=stagger,
+                             stagger_recycle=False)
+        tuples, recs = eng.play_until(100, 8, recycle=False)
+        assert eng.live_games() == 0 and eng.counters()["overflows"] == 0
+        eng.close()
+        out.append(_games_by_uid(game, tuples, recs))
+    stag, lock = out
+    assert sorted(stag) == sorted(lock) == [gm["uid"] for gm in games]
+    for uid in stag:
+        a, b = stag[uid], lock[uid]
+        assert a[:3] == b[:3] and a[3].tobytes() == b[3].tobytes() and a[4].tobytes() == b[4].tobytes(), uid
+    total = same = whole = 0
+    for gm in games:
+        first, result, steps, st, pis = stag[gm["uid"]]
+        assert first == gm["first_player"]
+        states = game.from_keys(st.view(np.uint64))
+        ok = True
+        for ply in range(min(len(states), gm["plies"])):
+            if str(states[ply]) != gm["states"][ply]:
+                break
+            total += 1
+            if pis[ply].tolist() == gm["pi"][ply]:
+                same += 1
+            else:
+                ok = False
+        else:
+            if ok and len(states) == gm["plies"]:
+                assert (result, steps) == (gm["result"], gm["steps"]), gm["uid"]
+                whole += 1
+    print("staggered two-net arena vs reference-recorded games: identical pi on %d / %d plies, %d / %d whole games"
+          % (same, total, whole, n))
+    assert total >= 100 and same / total >= 0.99 and whole >= 6
+
+
+def test_lock_step_mutators_refuse_a_staggered_engine():
+    """a staggered engine carries per-game clocks, pending minibatches and parked records the lock-step
+    entry points know nothing about -- they return CARO_E_STATE instead of leaving that state stale"""
+    from caro_ai_amd import _lib
+    game = _game_of({"kind": "c4"})
+    eng = _engine(game, 8, [_synth(game, "fused")], max_batch=8, stagger=True, searches_hint=5)
+    eng.search(5, 8)
+    for call in (lambda: eng.reset(), lambda: eng.set_roots([game.initial_state] * 8, [0] * 8),
+                 lambda: _lib.check(eng.L.caro_step(eng.h, None, None, None, None, None)),
+                 lambda: _lib.check(eng.L.caro_search_batch(eng.h, eng.evaluators[0].h, None, 1, 8, None,
+                                                            eng.planes.data_ptr(), None, eng._probs.data_ptr(),
+                                                            eng._values.data_ptr(), None)),
+                 lambda: _lib.check(eng.L.caro_select(eng.h, 8, 0, None, eng.planes.data_ptr(), None, None))):
+        with pytest.raises(_lib.CaroError, match="-71|staggered"):
+            call()
+    # the engine is still usable and its games still the oracle's
+    tuples, games = eng.play_until(5, 8, n_finished=8)
+    assert eng.counters()["overflows"] == 0
+    eng.close()
+    ref = _oracle_games({"kind": "c4"}, games[:, 0], 0, 10, 5, 8, 1)
+    for uid, first, result, steps in games.tolist():
+        assert (first, result, steps) == (ref[uid]["first"], ref[uid]["result"], ref[uid]["steps"]), uid
+
+
+@pytest.mark.parametrize("n_games,concurrent", [(48, None), (80, 32)])
+def test_train_self_play_plays_the_same_games_staggered_and_lock_step(n_games, concurrent):
+    """train.self_play must put the SAME set of games into the replay buffer whichever schedule runs
+    -- the first n_games uids of the rank's sequence, each played to its end -- not "whatever finishes first" (which is
+    biased towards short games).  With the real net, 48 slots x one game each and 32 slots x 80 games: the replay rows
+    of the two schedules are equal as multisets (boards, players, float32 pi, z), and so are the step totals."""
+    import os
+    from caro_ai_amd import train
+    from caro_ai_amd.lib.model import Net
+    from tests.conftest import GOLDEN
+    game = _game_of({"kind": "c4"})
+    net = Net(game.obs_shape, game.action_space)
+    net.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", "best_026_12000.dat"), map_location="cpu"))
+    net = net.to(DEV).eval()
+    rows = []
+    for stagger in (False, True):
+        rb = train.DeviceReplayBuffer(game, 20000, DEV)
+        sp = train.self_play(game, rb, net, n_games, device=DEV, seed=7, uid_base=300, searches=8, batch=8,
+                             concurrent=concurrent, stagger=stagger)
+        assert sp["games"] == n_games and len(rb) == sp["steps"] + n_games
+        if concurrent is None:
+            assert sp["games_dropped"] == 0  # one slot per game: nothing beyond the wanted set is ever started
+        n = len(rb)
+        rec = np.concatenate([rb.states[:n].cpu().numpy().view(np.uint8).reshape(n, -1),
+                              rb.players[:n].cpu().numpy().view(np.uint8).reshape(n, -1),
+                              rb.pi[:n].cpu().numpy().view(np.uint8).reshape(n, -1),
+                              rb.z[:n].cpu().numpy().view(np.uint8).reshape(n, -1)], axis=1)
+        rows.append((sorted(map(bytes, rec)), sp["steps"]))
+    assert rows[0][1] == rows[1][1]
+    assert rows[0][0] == rows[1][0]
+    # the empty board opens every game: exactly n_games such rows (a dropped or half-played game would show here)
+    empty = np.array([game.to_keys([game.initial_state])[0]]).view(np.uint8).tobytes()
+    assert sum(1 for r in rows[1][0] if r.startswith(empty)) == n_games

@@ -1,7 +1,7 @@
-// caro_net_exp.h -- the switches of the net kernel's TIMING EXPERIMENTS, kept out of the product source.
-// The product build (CARO_EXP undefined) gets the plain definitions at the bottom and nothing else.  tools/build_exp.sh N
-// compiles caro_net.hip with -DCARO_EXP=N into caro_ai_amd/libcaro_exp<N>.so (never loaded by the package; the results of
-// the removal builds are WRONG, only the clock is read):
+// caro_net_exp.h -- the switches of the net kernel's TIMING EXPERIMENTS.  NOT part of the product: caro_net.hip does not
+// include it.  tools/exp/build_exp.py N turns the product source's /*@NAME(...)*/ comments into these macros in a copy
+// of the file and compiles that copy with -DCARO_EXP=N into tools/exp/_build/libcaro_exp<N>.so (the results of the
+// removal builds are WRONG, only the clock is read):
 //   20  phase stamps of the heads (1x1 convolutions | FC stage | softmax), packed into stamp word 1
 //   21  no chunk barriers in the trunk      22  no weight fetches      23  neither
 #ifndef CARO_NET_EXP_H

@@ -1,4 +1,4 @@
-"""Phase cycles of heads_f32 (build with tools/build_exp.sh 20, run with CARO_HIP_LIB=caro_ai_amd/libcaro_exp20.so)."""
+"""Phase cycles of heads_f32 (build with tools/exp/build_exp.py 20, run with CARO_HIP_LIB=tools/exp/_build/libcaro_exp20.so)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

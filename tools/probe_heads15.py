@@ -1,4 +1,4 @@
-"""heads_f32 phase cycles on a 15x15 board (tools/build_exp.sh 20; CARO_HIP_LIB=caro_ai_amd/libcaro_exp20.so)."""
+"""heads_f32 phase cycles on a 15x15 board (tools/exp/build_exp.py 20; CARO_HIP_LIB=tools/exp/_build/libcaro_exp20.so)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

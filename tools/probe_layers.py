@@ -1,5 +1,5 @@
-"""Per-layer clock of the row-Winograd trunk (experiment build 24: tools/build_exp.sh 24, then
-CARO_HIP_LIB=caro_ai_amd/libcaro_exp24.so python tools/probe_layers.py [rows ...])."""
+"""Per-layer clock of the row-Winograd trunk (experiment build 24: tools/exp/build_exp.py 24, then
+CARO_HIP_LIB=tools/exp/_build/libcaro_exp24.so python tools/probe_layers.py [rows ...])."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
