@@ -233,7 +233,8 @@ def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_ba
             "nodes": c["expansions"], "games": st["finished"], "games_dropped": st["dropped"]}
 
 
-def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="cuda:0", seed=0):
+def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="cuda:0", seed=0,
+             reference_stores=False):
     """challenger (net1) vs champion (net2): `rounds` games, 20 x 16 sims, tau = 0 from move 0, one tree per
     player; returns challenger_win / (wins + losses + draws)  (train.py:120-149).
     With several ranks each plays a contiguous share of the rounds (round = game uid, so the set of games is the
@@ -244,9 +245,28 @@ def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="c
     left by earlier ones; here every round is an independent game with fresh trees (play.py:47 semantics, SURVEY
     Q3) -- that is what lets the rounds run concurrently and shard across ranks; (2) the reference draws the
     opening side with np.random.choice(2) per round, here it alternates with the round's uid (uid & 1), so a run
-    is reproducible.  The promote / keep decision can therefore differ from the reference's for the same nets."""
-    from caro_ai_amd.lib.utils import play_games
+    is reproducible.  The promote / keep decision can therefore differ from the reference's for the same nets.
+
+    reference_stores=True: the reference's evaluate itself (train.py:134-149) -- ONE pair [MCTS, MCTS] built before
+    the loop and reused by every round, the rounds one after another through the single-game API
+    (`lib.utils.play_game`: the opener by np.random.choice(2), one Dirichlet row per descent and one choice per ply
+    from numpy's global stream, exactly the reference's draws), trees on the GPU.  Sequential by construction (round
+    r searches on what rounds < r left behind), so only rank 0 plays and the counters are shared.  Pinned against
+    rounds recorded from the reference: tests/test_gpu_shim.py::test_evaluate_with_reference_stores_*."""
     rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
+    if reference_stores:
+        from caro_ai_amd.lib import mcts as mcts_mod
+        from caro_ai_amd.lib.utils import play_game
+        res = []
+        if rank == 0:
+            stores = [mcts_mod.MCTS(game, tree_device=device), mcts_mod.MCTS(game, tree_device=device)]
+            for _ in range(rounds):
+                r, _ = play_game(game, stores, None, challenger, champion, steps_before_tau_0=0, mcts_searches=20,
+                                 mcts_batch_size=16, device=device)
+                res.append(r)
+        wins, losses, draws = parallel.allreduce_counts((res.count(1), res.count(-1), res.count(0)), device)
+        return wins / max(1, wins + losses + draws)
+    from caro_ai_amd.lib.utils import play_games
     lo, n = parallel.shard_rounds(rounds, rank, world)
     res = []
     if n:
@@ -280,6 +300,9 @@ def parse_args(argv=None):
     p.add_argument("--games", type=int, default=256, help="self-play games per iteration (reference: PLAY_EPISODES=1)")
     p.add_argument("--iterations", type=int, default=0, help="stop after this many iterations (0 = run for ever)")
     p.add_argument("--saves", default="saves")
+    p.add_argument("--reference-evaluate", action="store_true",
+                   help="arena gate with the reference's store semantics: one pair of MCTS stores reused by all "
+                        "rounds, rounds played one after another (default: independent rounds, concurrent, sharded)")
     p.add_argument("--ddp", action="store_true",
                    help="several ranks: every rank trains on its share of each batch, gradients all-reduced "
                         "(default: rank 0 trains, the weights are broadcast)")
@@ -326,7 +349,7 @@ def main(argv=None):
         parallel.broadcast_weights(net)
         if step_idx % cfg.EVALUATE_EVERY_STEP == 0:
             win_ratio = evaluate(game, net, best_net.target_model, rounds=cfg.EVALUATION_ROUNDS, device=device,
-                                 seed=step_idx)
+                                 seed=step_idx, reference_stores=args.reference_evaluate)
             if rank == 0:
                 print("Net evaluated, win ratio = %.2f" % win_ratio)
             writer.add_scalar("eval_win_ratio", win_ratio, step_idx)

@@ -561,3 +561,173 @@ def test_fused_tree_kernel_equals_stepwise_kernels(two_nets, monkeypatch):
     for x, y in zip(ta, tb):
         for u, w_ in zip(x, y):
             assert np.array_equal(u, w_)
+
+
+# ------------------------------------------------------------------ SURVEY Q3 through the Level-1 shim: the caller's stores persist
+class _TableDraws:
+    """What tests/golden/make_golden_r4.py did to the reference, done to the shim: np.random.dirichlet /
+    np.random.choice replaced by the counter-based tables keyed (seed, game uid, ply, sim), the opener draw
+    `np.random.choice(2)` -> uid & 1, F.softmax -> identity (the table net returns priors, not logits).  The reference
+    counts sims per find_leaf call; the shim draws its rows per minibatch (`batch` rows when the root is expanded,
+    none otherwise -- lib/mcts.py:123,131), so sim = minibatch index * batch + row.  Also records, after every
+    search_batch, what the reference's trace holds: root board / player, root N / W / Q, len(store)."""
+
+    def __init__(self):
+        self.seed = self.uid = 0
+        self.trace = []
+
+    def new_game(self, seed, uid):
+        self.seed, self.uid, self.ply = seed, uid, -1
+        self.trace = []
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        from caro_ai_amd.lib.mcts import MCTS
+        from oracle.oracle import move_uniform, noise_row
+        h = self
+        self._saved = (np.random.dirichlet, np.random.choice, F.softmax, MCTS.search_batch, MCTS.search_minibatch)
+        sb, smb = MCTS.search_batch, MCTS.search_minibatch
+
+        def dirichlet(alpha, size=None):
+            assert size is None  # the step-wise path draws row by row
+            row = noise_row(h.seed, h.uid, h.ply, h.mb * h.batch + h.b, len(alpha), alpha[0])
+            h.b += 1
+            return row
+
+        def choice(a, p=None):
+            if p is None:
+                assert a == 2
+                return h.uid & 1
+            u = move_uniform(h.seed, h.uid, h.ply)
+            cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+            cdf /= cdf[-1]
+            return int(np.searchsorted(cdf, u, side="right"))
+
+        def search_batch(self_, count, batch_size, state_int, player, net, device="cpu"):
+            h.ply += 1
+            h.mb, h.batch = -1, batch_size
+            r = sb(self_, count, batch_size, state_int, player, net, device)
+            nd = self_._lookup(state_int)
+            h.trace.append({"state": str(state_int), "player": int(player), "N": [int(x) for x in nd["N"][0]],
+                            "W": [float(np.float32(x)) for x in nd["W"][0]],
+                            "W_f32": [int(x) for x in nd["strong"][0]],
+                            "Q": [float(x) for x in self_._q_list(nd)], "nodes": len(self_)})
+            return r
+
+        def search_minibatch(self_, batch_size, state_int, player, net, device="cpu"):
+            h.mb += 1
+            h.b = 0
+            return smb(self_, batch_size, state_int, player, net, device)
+
+        np.random.dirichlet, np.random.choice = dirichlet, choice
+        F.softmax = lambda x, dim=1: x
+        MCTS.search_batch, MCTS.search_minibatch = search_batch, search_minibatch
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as F
+        from caro_ai_amd.lib.mcts import MCTS
+        np.random.dirichlet, np.random.choice, F.softmax, MCTS.search_batch, MCTS.search_minibatch = self._saved
+
+
+def _table_module(game, salt):
+    """a lib.model.Net whose forward IS the table net (priors straight out: the softmax is the identity here)"""
+    from caro_ai_amd.lib.model import Net
+    from tests.synth_net import SynthNet
+
+    class M(Net):
+        def forward(self, x):
+            P, v = SynthNet(int(np.prod(x.shape[1:])), self.actions_n, x.device, salt)(x)
+            return P, v.reshape(-1, 1)
+
+    return M(game.obs_shape, game.action_space)
+
+
+def _check_trace(got, want, tag):
+    assert len(got) == len(want), tag
+    for ply, (a, b) in enumerate(zip(got, want)):
+        for k in ("state", "player", "N", "W_f32", "W", "Q", "nodes"):
+            assert a[k] == b[k], (tag, ply, k, a[k], b[k])
+
+
+def test_play_game_on_a_shared_store_across_games_vs_reference():
+    """INTEGRATION.md Level 1 promises that `play_game(game, mcts_store, ...)` runs unchanged with the CALLER's store
+    surviving across calls.  ref train.py:184-193 + :41-47: three consecutive self-play games on ONE `MCTS`
+    (10 x 8 sims, tau = 1 for 10 plies, opener drawn by play_game), recorded from the reference
+    (tests/golden/persist_selfplay_c4.json.gz): root N / W / Q after every search, len(store), the replay rows,
+    result and steps -- exact."""
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.mcts import MCTS
+    from caro_ai_amd.lib.utils import play_game
+    d = load_golden("persist_selfplay_c4.json.gz")
+    g = ConnectFour()
+    net = _table_module(g, d["salts"][0])
+    store = MCTS(g)
+    rb = collections.deque(maxlen=5000)
+    with _TableDraws() as h:
+        for gm in d["games"]:
+            h.new_game(gm["seed"], gm["uid"])
+            n0 = len(rb)
+            r, steps = play_game(g, store, rb, net, net, d["steps_before_tau_0"], d["searches"], d["batch"],
+                                 device="cuda:0")
+            assert (r, steps) == (gm["result"], gm["steps"]), gm["uid"]
+            _check_trace(h.trace, gm["trace"], gm["uid"])
+            assert len(store) == gm["store_len_after"]
+            new = list(rb)[n0:]
+            assert [str(s) for s, _, _, _ in new] == gm["replay"]["states"]
+            assert [p for _, p, _, _ in new] == gm["replay"]["players"]
+            assert [list(pi) for _, _, pi, _ in new] == gm["replay"]["pi"]
+            assert [z for _, _, _, z in new] == gm["replay"]["z"]
+    store.clear()  # ref train.py:217: a new best net empties the store
+    assert len(store) == 0
+
+
+def test_play_game_on_the_evaluate_pair_across_rounds_vs_reference():
+    """ref train.py:134-141: one pair [MCTS, MCTS] reused by every round of `evaluate` (20 x 16 sims, tau = 0, no
+    replay buffer, challenger != champion): four rounds recorded from the reference, through the shim with the
+    caller's two persistent stores -- exact"""
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.mcts import MCTS
+    from caro_ai_amd.lib.utils import play_game
+    d = load_golden("persist_evaluate_c4.json.gz")
+    g = ConnectFour()
+    challenger, champion = _table_module(g, d["salts"][0]), _table_module(g, d["salts"][1])
+    stores = [MCTS(g), MCTS(g)]
+    with _TableDraws() as h:
+        for gm in d["rounds"]:
+            h.new_game(gm["seed"], gm["uid"])
+            r, steps = play_game(g, stores, None, challenger, champion, 0, d["searches"], d["batch"], device="cuda:0")
+            assert (r, steps) == (gm["result"], gm["steps"]), gm["uid"]
+            _check_trace(h.trace, gm["trace"], gm["uid"])
+            assert [len(stores[0]), len(stores[1])] == gm["store_len_after"]
+
+
+def test_evaluate_with_reference_stores_reproduces_the_reference_rounds():
+    """train.evaluate(..., reference_stores=True) is the reference's evaluate: its rounds are the recorded ones (the
+    per-round games are checked through the trace hook), its return value the recorded win ratio; the default
+    (independent rounds) is a different, declared, experiment and need not agree"""
+    from caro_ai_amd import train
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    d = load_golden("persist_evaluate_c4.json.gz")
+    g = ConnectFour()
+    challenger, champion = _table_module(g, d["salts"][0]), _table_module(g, d["salts"][1])
+    rounds = d["rounds"]
+    with _TableDraws() as h:
+        import caro_ai_amd.lib.utils as U
+        inner, seen = U.play_game, []
+
+        def play_game(*a, **k):  # evaluate knows nothing of uids: hand the harness each round's key
+            gm = rounds[len(seen)]
+            h.new_game(gm["seed"], gm["uid"])
+            r = inner(*a, **k)
+            _check_trace(h.trace, gm["trace"], gm["uid"])
+            seen.append(r)
+            return r
+
+        U.play_game = play_game
+        try:
+            ratio = train.evaluate(g, challenger, champion, rounds=len(rounds), device="cuda:0", reference_stores=True)
+        finally:
+            U.play_game = inner
+    assert [r for r, _ in seen] == [gm["result"] for gm in rounds]
+    assert ratio == d["win_ratio"]

@@ -130,19 +130,28 @@ def test_self_play_replay_rows_are_the_drained_tuples():
     n_games, G, S, B = 96, 32, 5, 4
     rb = train.DeviceReplayBuffer(game, 4096, DEV)
     sp = train.self_play(game, rb, net, n_games, device=DEV, seed=5, uid_base=0, searches=S, batch=B, concurrent=G)
-    assert sp["games"] >= n_games
-    # the same games again, every drain copied to the host at once
+    assert sp["games"] == n_games
+    # the same games again, every drain copied to the host at once.  self_play's rule: the wanted games are uids
+    # 0 .. n_games - 1 (slot g plays g, g + G, g + 2G); drained slots restart while some slot still has a wanted
+    # generation to begin; games beyond the wanted set are played but their rows dropped
     eng = SelfPlayEngine(game, G, net1=net, max_batch=B, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, seed=5, device=DEV,
                          searches_hint=S, uid_base=0, uid_stride=G)
     rows, finished = [], 0
+    slot_gen = np.zeros(G, dtype=np.int64)
+    last_gen = (n_games - 1 - np.arange(G)) // G
     while finished < n_games:
         eng.search(S, B)
         eng.step()
-        d = eng.drain(recycle=finished + G < n_games)
+        d = eng.drain(recycle=bool((slot_gen < last_gen).any()))
         ng = int(d["games"].shape[0])
         if ng:
-            finished += ng
-            rows.append(_host(d))
+            h = _host(d)
+            recs = h["games"]
+            want = recs[:, 0] < n_games
+            np.maximum.at(slot_gen, recs[want, 0] % G, recs[want, 0] // G + 1)
+            finished += int(want.sum())
+            keep = np.repeat(want, recs[:, 3] + 1)
+            rows.append({k: h[k][keep] for k in ("states", "players", "pi", "z")})
         elif eng.live_games() == 0:
             break
     eng.close()

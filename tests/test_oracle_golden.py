@@ -341,3 +341,59 @@ def test_config4_conv_net_games_400_sims():
             oo.set_net(1, fn)
 
         _check_game(o, g, setup)
+
+
+# --------------------------------------------------------------- persistent stores (make_golden_r4.py)
+def _replay_on_persistent_stores(o, games, sbt0, searches, batch, two_stores):
+    """The reference's play_game loop (lib/utils.py:63-99) driven step by step on stores that are NOT cleared between
+    games -- train.py:184-193's shared self-play store, train.py:134-141's pair of evaluate stores -- with the
+    recorded root N / W / Q (+ float32 flags) and len(store) checked after every search_batch."""
+    from oracle.oracle import move_uniform, sample_index
+    for gm in games:
+        o.set_stream(gm["seed"], gm["uid"])
+        state, player, step = o.initial_state, gm["first_player"], 0
+        result = None
+        for ply, tr in enumerate(gm["trace"]):
+            assert (str(state), player) == (tr["state"], tr["player"]), (gm["uid"], ply)
+            st = player if two_stores else 0
+            o.search_batch(searches, batch, state, player, store=st, which_net=player if two_stores else 0, ply=ply)
+            nd = o.get_node(state, store=st)
+            assert nd["N"].tolist() == tr["N"], (gm["uid"], ply)
+            assert nd["W"].tolist() == tr["W"] and nd["W_is_f32"].tolist() == tr["W_f32"], (gm["uid"], ply)
+            assert nd["Q"].tolist() == tr["Q"], (gm["uid"], ply)
+            assert o.store_len(st) == tr["nodes"], (gm["uid"], ply)
+            tau = 1 if step < sbt0 else 0
+            a = sample_index(o.get_policy(state, tau, store=st), move_uniform(gm["seed"], gm["uid"], ply))
+            state, won = o.move(state, a, player)
+            if won:
+                result = 1 if player == 0 else -1
+                break
+            player = 1 - player
+            if not o.possible_moves(state):
+                result = 0
+                break
+            step += 1
+        assert ply == gm["plies"] - 1 and (result, step) == (gm["result"], gm["steps"]), gm["uid"]
+        lens = [o.store_len(s) for s in range(2 if two_stores else 1)]
+        assert lens == (gm["store_len_after"] if two_stores else [gm["store_len_after"]])
+
+
+def test_shared_self_play_store_across_games_vs_reference():
+    """ref train.py:184-193 + :41-47: ONE MCTS for every self-play game -- the second and third game search on the
+    statistics the earlier ones left (the root is expanded from the first minibatch on, so even the number of
+    Dirichlet rows differs from a fresh store's)"""
+    d = load_golden("persist_selfplay_c4.json.gz")
+    o = make_oracle(d, 1)
+    o.use_synth_net(*d["salts"])
+    _replay_on_persistent_stores(o, d["games"], d["steps_before_tau_0"], d["searches"], d["batch"], False)
+    assert d["games"][1]["trace"][0]["nodes"] > d["games"][0]["store_len_after"] - 1  # game 2 started on a full store
+
+
+def test_evaluate_pair_of_stores_across_rounds_vs_reference():
+    """ref train.py:134-141: the pair [MCTS, MCTS] is built once and reused by all rounds (20 x 16 sims, tau = 0)"""
+    d = load_golden("persist_evaluate_c4.json.gz")
+    o = make_oracle(d, 2)
+    o.use_synth_net(*d["salts"])
+    _replay_on_persistent_stores(o, d["rounds"], d["steps_before_tau_0"], d["searches"], d["batch"], True)
+    res = [g["result"] for g in d["rounds"]]
+    assert d["win_ratio"] == res.count(1) / len(res)
