@@ -62,6 +62,9 @@ _SIGNATURES = {
     "caro_net_destroy": (None, [_P]),
     "caro_net_enable_3xbf16": (C.c_int, [_P, _P, C.c_int64]),
     "caro_net_enable_winograd": (C.c_int, [_P, _P, C.c_int64]),
+    "caro_net_winograd2d_size": (C.c_int, []),
+    "caro_net_winograd2d_supported": (C.c_int, [C.c_int, C.c_int]),
+    "caro_net_enable_winograd2d": (C.c_int, [_P, _P, C.c_int64]),
     "caro_net_boards_per_workgroup": (C.c_int, [_P]),
     "caro_net_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P]),
     "caro_stream_create_partition": (C.c_int, [C.c_int, C.c_int, C.c_int, _P]),

@@ -70,6 +70,7 @@ struct NetParams {
   const uint4* w3;      // 3xbf16 mode: [45 taps][1536 granules] LDS image of the split residual weights, or null
   const float* ww;      // f32w mode: [5][3 dx][2 granule halves] chunks of [4 p][2 h][64 co][16] transformed residual weights (LDS image order of trunk_w), or null
   const uint32_t* wtab; // f32w mode: [128] tile of MFMA row (row tile, lane): board | ty << 8 | x << 16 | valid << 24
+  const float* ww2;     // f32w2 mode: [5][8 chunks][2 b][4 a][2 h][64 co][8] 2-D Winograd F(2x2,3x3) transformed residual weights (LDS image order of trunk_w2d), or null
   int ncu, TB2, TB4;    // f32w mode: compute units; boards per workgroup of the 2- / 4-way K-split overflow tiles (0: off)
 };
 
@@ -77,6 +78,17 @@ __device__ __forceinline__ int aoff(int row, int c) {
   return row * NF + ((((c >> 2) ^ (row & 15)) << 2) | (c & 3));
 }
 __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+// Swizzle key of activation row r: granule g of the row lives in 16-byte slot g ^ key.  The default (r & 15) serves
+// the row-oriented kernels.  K2D (one board per workgroup, the 2-D Winograd trunk): the 16 lanes of a ds_read_b128
+// group there read the same cell offset of 16 tiles (8 tile columns x 2 tile rows), so the key is built from the
+// cell's tile coordinates -- ((x + 1) >> 1) & 7 | ((y + 1) >> 1 & 1) << 3 -- and is distinct over such a group.
+template <bool K2D>
+__device__ __forceinline__ int akey(int r, int W) {
+  if constexpr (!K2D) return r & 15;
+  const int y = r / W, x = r - y * W;
+  return (((x + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
+}
 
 constexpr int NT = 512;  // threads per workgroup
 
@@ -127,6 +139,7 @@ __device__ __forceinline__ void conv_in_f32(const NetParams& p, const float* __r
 // per thread whose 144 weight reads per thread kept the LDS return path busy for 9 k cycles.  Wave = column tile
 // (wave & 1) x row tiles (wave >> 1) and (wave >> 1) + 4; lane (i, h) feeds row 32 rt + i with plane h: 9 loads per row
 // tile instead of 18.  Output layout = the trunk's (a lane holds 4 groups of 4 consecutive channels of its row).
+template <bool K2D = false>
 __device__ __forceinline__ void conv_in_mfma(const NetParams& p, const float* __restrict__ planes, const int* smap,
                                              float* act, const float* win, int R, int tid) {
   const int HW = p.HW;
@@ -169,7 +182,7 @@ __device__ __forceinline__ void conv_in_mfma(const NetParams& p, const float* __
         const int c4 = ct * 8 + 2 * q + h;
         const float4 out = make_float4(leaky(acc[4 * q], slope), leaky(acc[4 * q + 1], slope),
                                        leaky(acc[4 * q + 2], slope), leaky(acc[4 * q + 3], slope));
-        *reinterpret_cast<float4*>(act + r * NF + ((c4 ^ (r & 15)) << 2)) = out;
+        *reinterpret_cast<float4*>(act + r * NF + ((c4 ^ akey<K2D>(r, p.W)) << 2)) = out;
       }
     }
   }
@@ -188,7 +201,7 @@ constexpr int HEAD_STAGE_MAX = 4096;  // floats
 __device__ __forceinline__ int head_span(int HW, int A) { return 3 * NF + 3 + 20 * HW + 20 + 20 + 1 + A * 2 * HW + A; }
 static inline int head_span_host(int HW, int A) { return 3 * NF + 3 + 20 * HW + 20 + 20 + 1 + A * 2 * HW + A; }
 
-template <bool STAGED>
+template <bool STAGED, bool K2D = false>
 __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, float* scratch,
                                           float* __restrict__ probs, float* __restrict__ values, int slot_v, int nb,
                                           int R, int tid) {
@@ -231,9 +244,10 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
     const int o = q / R, r = q - o * R;
     const float* wo = w_head + o * NF;
     float s0 = b_head[o];
+    const int rkey = akey<K2D>(r, p.W);
 #pragma unroll 8
     for (int g = 0; g < 16; ++g) {  // eight pairs of reads in flight, the fma chain in channel order
-      const float4 v = *reinterpret_cast<const float4*>(act + r * NF + ((g ^ (r & 15)) << 2));
+      const float4 v = *reinterpret_cast<const float4*>(act + r * NF + ((g ^ rkey) << 2));
       const float4 w = *reinterpret_cast<const float4*>(wo + g * 4);
       s0 = fmaf(v.x, w.x, s0); s0 = fmaf(v.y, w.y, s0);
       s0 = fmaf(v.z, w.z, s0); s0 = fmaf(v.w, w.w, s0);
@@ -1226,6 +1240,346 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
 
 
 // ===================================================================================================
+// 2-D Winograd form F(2x2,3x3) ("f32w2") for LARGE boards (one board per workgroup: 12x12 .. 15x15): the same float32
+// network function with 16 / 36 of the direct form's multiplies (the row form above: 24 / 36).  Reference:
+// lib/model.py:36-47,85-89 (five 64 -> 64 3x3 convolutions with a residual each).
+//     output tile (ty, tx) = cells (2ty + u, 2tx + v), u, v in {0, 1};  d[r][j] = input cell (2ty-1+r, 2tx-1+j), zero outside
+//     V[a][b] = sum_rj Bt[a][r] Bt[b][j] d[r][j]      Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]      (adds only)
+//     U[a][b] = sum    G[a][ky] G[b][kx] w[ky][kx]    G  = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]          (host, float64, one rounding)
+//     M[a][b] = sum_ci U[a][b][co][ci] V[a][b][ci]                                                       (MFMA)
+//     Y[u][v] = sum_ab At[u][a] At[v][b] M[a][b]      At = [1 1 1 0; 0 1 -1 -1]
+// GEMM rows are the 64 tiles of a board (8 x 8 for 15 x 15: exactly two 32-row MFMA blocks, no padding rows; the row
+// form needs 120 tiles in 128 rows), 16 transformed taps of K = 64.  Work split: wave = (row tile rt, column tile ct,
+// bh) -- 32 tiles x 32 channels, and the wave's HALF of the taps: b in {1, 0} for bh = 0, b in {2, 3} for bh = 1, all
+// four a.  A wave keeps the four accumulators M[0..3][b] of ONE b at a time:
+//     phase 0  b = 1 | 2:  K loop, then Z[u] = sum_a At[u][a] M[a][b] (32 registers) stays behind
+//     phase 1  b = 0 | 3:  K loop, then the same fold
+// and FINISHES output column v = bh of its tiles:  Y[u][0] = Z[u][b=0] + Z[u][1] + Z[u][2]  (bh = 0; Z[u][2] comes from
+// the partner wave), Y[u][1] = Z[u][1] - Z[u][2] - Z[u][3]  (bh = 1; Z[u][1] from the partner).  What a wave hands to its
+// partner is exactly its phase-0 fold.  The exchange needs no extra LDS: after the "inputs read" barrier the activation
+// buffer is dead, so the partner's partial sums are written INTO THE PARTNER'S OUTPUT CELLS, read back from there behind
+// a second barrier and overwritten with the finished activations (three barriers per layer).
+// Operand stream per (b, channel granule): 8 cell reads (4 tile rows x the 2 columns b combines) + 4 weight granules
+// -> column combine, row transform (as the row form: V0 = c0-c2, V1 = c1+c2, V2 = c2-c1, V3 = c1-c3) -> 16 MFMAs.
+// Weight chunk = 32 KiB = [2 b of the phase][4 a][2 h][64 co][2 channel granules]: 8 chunks per layer (4 per phase)
+// through the same ring of three buffers, one workgroup barrier per chunk (32 MFMAs of a wave).
+// Activation rows keep the index cell = y * W + x; their granule swizzle key is akey<true> (tile coordinates), under
+// which the 16 lanes of every ds_read_b128 group -- 8 tile columns x 2 tile rows, see the lane -> tile map below --
+// read 16 different slots for any cell offset.
+constexpr int W2NCHUNK = NRES * 8;        // 40 chunks of WCH floats
+constexpr int W2SETS = 16;                // operand sets per layer and wave: 2 phases x 8 channel granules
+
+__device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float* wbuf, int tid) {
+  const float slope = p.slope;
+  const int H = p.H, W = p.W;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 31, h = lane >> 5;
+  const int ct = wave & 1, rt = (wave >> 1) & 1, bh = wave >> 2;
+  // lane -> tile.  ds_read_b128 is served in the lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half
+  // (MI355X_MICROARCH.md, LDS): quads 0,3,5,6 form group 0 and quads 1,2,4,7 group 1, and quad >> 1 numbers the quads
+  // of either group 0..3.  Position q = 0..15 inside the group -> tile column q & 7, tile row (group * 2 + (q >> 3)).
+  const int quad = i >> 2, grp = (0x96 >> quad) & 1, qq = ((quad >> 1) << 2) | (i & 3);
+  const int tx = qq & 7, ty = rt * 4 + grp * 2 + (qq >> 3);
+  const bool tvalid = ty < ((H + 1) >> 1) && tx < ((W + 1) >> 1);
+  const unsigned abase = lds_addr(act);
+  const unsigned wring = lds_addr(wbuf);
+  // LDS byte address of input cell (r, j) of the tile, channel granule 8h (+ G, XORed in per set), swizzle key folded
+  // in.  A cell outside the board reads the zero row -- any of its slots: the one the virtual cell's key selects, which
+  // keeps the lanes of a group on different slots.
+  auto caddr = [&](int r, int j) -> unsigned {
+    const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + j;
+    const bool ok = tvalid && y >= 0 && y < H && x >= 0 && x < W;
+    const int row = ok ? y * W + x : ZROW;
+    const int key = ((tx + (j >> 1)) & 7) | (((ty + (r >> 1)) & 1) << 3);
+    return abase + (unsigned)(row * NF + (((h * 8) ^ key) << 2)) * 4u;
+  };
+  // the two input columns a phase combines, c_r = d[r][jA] + sg * d[r][jB]:
+  //   bh 0: phase 0 (b = 1)  x1 + x2      phase 1 (b = 0)  x0 - x2
+  //   bh 1: phase 0 (b = 2)  x2 - x1      phase 1 (b = 3)  x1 - x3
+  const int jA0 = bh ? 2 : 1, jB0 = bh ? 1 : 2, jA1 = bh ? 1 : 0, jB1 = bh ? 3 : 2;
+  const float sg0 = bh ? -1.f : 1.f, sg1 = -1.f;
+  unsigned ra[2][4], rb[2][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    ra[0][r] = caddr(r, jA0); rb[0][r] = caddr(r, jB0);
+    ra[1][r] = caddr(r, jA1); rb[1][r] = caddr(r, jB1);
+  }
+  // this lane's weight row in ring buffer 0: [b = bh][a = 0][h][co = ct*32 + i], 2 granules of 16 bytes, the granule
+  // index XORed with (co >> 3) & 1 (lanes i and i ^ 8.. of a read group then sit on different slots)
+  const unsigned wlane = wring + (unsigned)(bh * 16384 + (h * 64 + ct * 32 + i) * 32 + (((i >> 3) & 1) << 4));
+  // output side (weights are the first MFMA operand: a lane's 16 accumulator registers are 4 groups q of 4 consecutive
+  // channels ct*32 + 8q + 4h + 0..3 of ITS tile): this wave finishes cells (2ty + u, 2tx + bh), its partner the
+  // cells (2ty + u, 2tx + 1 - bh)
+  const int xo = 2 * tx + bh, xp = 2 * tx + 1 - bh;
+  const int g0 = ct * 8 + h;  // granule of channel group q is g0 + 2q
+  int orow[2], prow[2], okey[2], pkey[2];
+  bool ovalid[2], pvalid[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int y = 2 * ty + u;
+    ovalid[u] = tvalid && y < H && xo < W;
+    pvalid[u] = tvalid && y < H && xp < W;
+    orow[u] = y * W + xo;
+    prow[u] = y * W + xp;
+    okey[u] = (((xo + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
+    pkey[u] = (((xp + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
+  }
+
+  f4v CA0, CA1, CA2, CA3, CB0, CB1, CB2, CB3;  // the 4 x 2 input cells of the operand set in flight
+  f4v W0, W1, W2, W3, X0, X1, X2, X3;          // its weight granules: two sets, the MFMAs read one while the other loads
+// operand set T of the layer: phase T >> 3, channel granule G = T & 7 of the lane half, chunk T >> 1 of the layer
+#define W2_ALOAD(B0, B1, B2, B3, T)                                                                          \
+  {                                                                                                          \
+    constexpr int ph_ = (T) >> 3, G_ = (T) & 7, cq_ = (T) >> 1;                                              \
+    const unsigned wa_ = (wlane + rbuf[cq_ % WNBUF]) ^ ((unsigned)(G_ & 1) << 4);                            \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CA0) : "v"(ra[ph_][0] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CB0) : "v"(rb[ph_][0] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CA1) : "v"(ra[ph_][1] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CB1) : "v"(rb[ph_][1] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CA2) : "v"(ra[ph_][2] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CB2) : "v"(rb[ph_][2] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CA3) : "v"(ra[ph_][3] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CB3) : "v"(rb[ph_][3] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(B0) : "v"(wa_));                                               \
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(B1) : "v"(wa_));                                   \
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(B2) : "v"(wa_));                                   \
+    asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(B3) : "v"(wa_));                                  \
+  }
+// every LDS read this wave has issued is complete (the compiler does not know of the reads above)
+#define W2_AWAIT(B0, B1, B2, B3)                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                        \
+               : "+v"(CA0), "+v"(CA1), "+v"(CA2), "+v"(CA3), "+v"(CB0), "+v"(CB1), "+v"(CB2), "+v"(CB3),     \
+                 "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3));
+// One step of the layer's software pipeline (the structure of trunk_w's): set T was requested a whole burst ago; wait,
+// at the first set of a chunk pass the chunk's ONE workgroup barrier (this wave's share of chunk c+1 has arrived ->
+// barrier -> chunk c+1 visible to every wave, nobody reads chunk c-1 any more -> chunk c+2 goes into that buffer),
+// combine the columns, form each transformed operand in front of its first MFMA, request set T+1 behind the first
+// round of MFMAs, issue the other twelve.
+#define W2_STEP(T, B0, B1, B2, B3, NB0, NB1, NB2, NB3)                                                       \
+  W2_AWAIT(B0, B1, B2, B3)                                                                                   \
+  if ((T) % 2 == 0) {                                                                                        \
+    if ((T) != 0) {                                                                                          \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+      __syncthreads();                                                                                       \
+    }                                                                                                        \
+    if (c0 + (T) / 2 + 2 < W2NCHUNK) fetch_chunk(p.ww2, c0 + (T) / 2 + 2, wring, tid);                       \
+  }                                                                                                          \
+  {                                                                                                          \
+    const float sg_ = ((T) >> 3) ? sg1 : sg0;                                                                \
+    const f4v c0_ = CA0 + sg_ * CB0, c1_ = CA1 + sg_ * CB1, c2_ = CA2 + sg_ * CB2, c3_ = CA3 + sg_ * CB3;    \
+    const f4v v0 = c0_ - c2_;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.x, v0.x, accM0, 0, 0, 0);                                \
+    const f4v v1 = c1_ + c2_;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.x, v1.x, accM1, 0, 0, 0);                                \
+    const f4v v2 = c2_ - c1_;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.x, v2.x, accM2, 0, 0, 0);                                \
+    const f4v v3 = c1_ - c3_;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.x, v3.x, accM3, 0, 0, 0);                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if ((T) + 1 < W2SETS) W2_ALOAD(NB0, NB1, NB2, NB3, ((T) + 1) % W2SETS)                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.y, v0.y, accM0, 0, 0, 0);                                \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.y, v1.y, accM1, 0, 0, 0);                                \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.y, v2.y, accM2, 0, 0, 0);                                \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.y, v3.y, accM3, 0, 0, 0);                                \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.z, v0.z, accM0, 0, 0, 0);                                \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.z, v1.z, accM1, 0, 0, 0);                                \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.z, v2.z, accM2, 0, 0, 0);                                \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.z, v3.z, accM3, 0, 0, 0);                                \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.w, v0.w, accM0, 0, 0, 0);                                \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.w, v1.w, accM1, 0, 0, 0);                                \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.w, v2.w, accM2, 0, 0, 0);                                \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.w, v3.w, accM3, 0, 0, 0);                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  }
+#define W2_PAIR(T)                                                                                           \
+  W2_STEP(T, W0, W1, W2, W3, X0, X1, X2, X3)                                                                 \
+  W2_STEP((T) + 1, X0, X1, X2, X3, W0, W1, W2, W3)
+// Z[u] = sum_a At[u][a] M[a]: u = 0: M0 + M1 + M2, u = 1: M1 - M2 - M3 (left to right)
+#define W2_FOLD(Z0_, Z1_)                                                                                    \
+  _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                           \
+    Z0_[e] = (accM0[e] + accM1[e]) + accM2[e];                                                               \
+    Z1_[e] = (accM1[e] - accM2[e]) - accM3[e];                                                               \
+  }
+#define W2_ZERO                                                                                              \
+  _Pragma("unroll") for (int e = 0; e < 16; ++e) { accM0[e] = 0.f; accM1[e] = 0.f; accM2[e] = 0.f; accM3[e] = 0.f; }
+
+  for (int layer = 0; layer < NRES; ++layer) {
+    const int c0 = layer * 8;  // first chunk of the layer; chunk c0 + k sits in ring buffer (c0 + k) % WNBUF
+    unsigned rbuf[WNBUF];
+#pragma unroll
+    for (int k = 0; k < WNBUF; ++k) rbuf[k] = (unsigned)((c0 + k) % WNBUF) * (WCH * 4);
+    f32x16 accM0, accM1, accM2, accM3, Zs0, Zs1, Zt0, Zt1;
+    W2_ZERO
+    // (the per-set addresses are re-formed in every layer: hoisted out of the layer loop they would take 128 registers)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(ra[0][r]), "+v"(rb[0][r]), "+v"(ra[1][r]), "+v"(rb[1][r]));
+    W2_ALOAD(W0, W1, W2, W3, 0)
+    W2_PAIR(0) W2_PAIR(2) W2_PAIR(4) W2_PAIR(6)
+    W2_FOLD(Zs0, Zs1)   // phase 0 (b = 1 | 2): what this wave keeps AND what it hands to its partner
+    W2_ZERO
+    W2_PAIR(8) W2_PAIR(10) W2_PAIR(12) W2_PAIR(14)
+    W2_FOLD(Zt0, Zt1)   // phase 1 (b = 0 | 3)
+    // ---- epilogue.  Requested in front of the barrier: the bias (global memory) and the OLD values of this wave's
+    // output cells (the residual input; only this wave ever writes these cells)
+    const float* bias = p.b_res + layer * NF + ct * 32 + 4 * h;
+    float4 bq[4], old0[4], old1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + 8 * q);
+    float* own0 = act + orow[0] * NF;
+    float* own1 = act + orow[1] * NF;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      old0[q] = ovalid[0] ? *reinterpret_cast<const float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      old1[q] = ovalid[1] ? *reinterpret_cast<const float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // every wave has read this layer's input activations (and this wave its old values): the buffer may be overwritten
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {  // the partner's partial sums go into the partner's output cells
+      float* pr0 = act + prow[0] * NF;
+      float* pr1 = act + prow[1] * NF;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (pvalid[0])
+          *reinterpret_cast<float4*>(pr0 + (((g0 + 2 * q) ^ pkey[0]) << 2)) = make_float4(Zs0[4 * q], Zs0[4 * q + 1], Zs0[4 * q + 2], Zs0[4 * q + 3]);
+        if (pvalid[1])
+          *reinterpret_cast<float4*>(pr1 + (((g0 + 2 * q) ^ pkey[1]) << 2)) = make_float4(Zs1[4 * q], Zs1[4 * q + 1], Zs1[4 * q + 2], Zs1[4 * q + 3]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // finish: bh 0: Y = (Z[b=0] + Z[b=1]) + Z[b=2](received);  bh 1: Y = (Z[b=1](received) - Z[b=2]) - Z[b=3];
+    // then in place v = v + leaky(conv(v) + bias)  (lib/model.py:85-89); only real cells are written
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 r0 = ovalid[0] ? *reinterpret_cast<const float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 r1 = ovalid[1] ? *reinterpret_cast<const float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float y0[4], y1[4];
+      const float rr0[4] = {r0.x, r0.y, r0.z, r0.w}, rr1[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = 4 * q + j;
+        if (bh == 0) {
+          y0[j] = (Zt0[e] + Zs0[e]) + rr0[j];
+          y1[j] = (Zt1[e] + Zs1[e]) + rr1[j];
+        } else {
+          y0[j] = (rr0[j] - Zs0[e]) - Zt0[e];
+          y1[j] = (rr1[j] - Zs1[e]) - Zt1[e];
+        }
+      }
+      float4 n0, n1;
+      n0.x = old0[q].x + leaky(y0[0] + bq[q].x, slope);
+      n0.y = old0[q].y + leaky(y0[1] + bq[q].y, slope);
+      n0.z = old0[q].z + leaky(y0[2] + bq[q].z, slope);
+      n0.w = old0[q].w + leaky(y0[3] + bq[q].w, slope);
+      n1.x = old1[q].x + leaky(y1[0] + bq[q].x, slope);
+      n1.y = old1[q].y + leaky(y1[1] + bq[q].y, slope);
+      n1.z = old1[q].z + leaky(y1[2] + bq[q].z, slope);
+      n1.w = old1[q].w + leaky(y1[3] + bq[q].w, slope);
+      if (ovalid[0]) *reinterpret_cast<float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) = n0;
+      if (ovalid[1]) *reinterpret_cast<float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) = n1;
+    }
+    // new activations visible to every wave; also the chunk barrier of the next layer's first chunk (this wave's share
+    // of its second chunk has arrived, nobody reads this layer's last chunks any more)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef W2_ZERO
+#undef W2_FOLD
+#undef W2_PAIR
+#undef W2_STEP
+#undef W2_AWAIT
+#undef W2_ALOAD
+}
+
+// One board per workgroup (TB = 1); launch interface, prologue (slot-row map, conv_in on the matrix pipe) and heads of
+// k_net_forward_w, activation rows keyed by akey<true>.
+__global__ __launch_bounds__(NT, 2) void k_net_forward_w2(NetParams p0, NetParams p1,
+                                                            const float* __restrict__ planes,
+                                                            const int32_t* __restrict__ counts, int which, int row1,
+                                                            float* __restrict__ probs, float* __restrict__ values,
+                                                            unsigned long long* __restrict__ stamps,
+                                                            const int32_t* __restrict__ gpack, int gG, int gB) {
+  __shared__ __attribute__((aligned(256))) float lds[LDS_FLOATS];  // trunk_w2d XORs granule bits into LDS addresses
+  float* act = lds;
+  float* wbuf = lds + ACT;
+  // slot form: this thread's share of the games' leaf counts is requested beside the launch's totals (tile_rows_pre)
+  const int gcpt = gpack ? (gG + NT - 1) / NT : 0;
+  const bool gpre = gpack && gcpt <= GP_PRE;
+  int gv[GP_PRE];
+#pragma unroll
+  for (int u = 0; u < GP_PRE; ++u) {
+    const int g = (int)threadIdx.x * gcpt + u;
+    gv[u] = gpre && u < gcpt && g < gG ? gpack[g] : 0;
+  }
+  int L, row0, board0;
+  bool second = false;
+  if (which < 2) {
+    L = counts[which];
+    row0 = which ? counts[0] : 0;
+    board0 = blockIdx.x;
+  } else {
+    const int L0 = counts[0];
+    second = (int)blockIdx.x >= L0;
+    L = second ? counts[1] : L0;
+    row0 = second ? (row1 >= 0 ? row1 : L0) : 0;
+    board0 = second ? (int)blockIdx.x - L0 : (int)blockIdx.x;
+  }
+  if (board0 >= L) return;
+  const NetParams p = second ? p1 : p0;
+  unsigned long long t_c0 = 0, t_r0 = 0;  // diagnostic only (stamps == nullptr in every product launch)
+  if (stamps) {
+    t_c0 = __builtin_amdgcn_s_memtime();
+    t_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  const int nb = 1;
+  const int HW = p.HW;
+  const int R = HW;
+  const int tid = threadIdx.x;
+  int gmine = 0;
+#pragma unroll
+  for (int u = 0; u < GP_PRE; ++u) gmine += (gv[u] >> 8) == (second ? 1 : 0) ? (gv[u] & 0xFF) : 0;
+  asm volatile("" : "+v"(gmine));
+  // the first two weight chunks are on their way into ring buffers 0 and 1 while conv_in runs; its scratch (the conv_in
+  // weights, the row map) sits in buffer 2, which is fetched into only after the trunk's first barrier
+  float* win = wbuf + 2 * WCH;
+  if (tid < 320) dma_b128(reinterpret_cast<const float4*>(p.w_in) + tid,
+                          __builtin_amdgcn_readfirstlane(lds_addr(win) + (unsigned)(tid >> 6) * 1024u));
+  fetch_chunk(p.ww2, 0, lds_addr(wbuf), tid);
+  fetch_chunk(p.ww2, 1, lds_addr(wbuf), tid);
+  for (int k = tid + (R * NF) / 4; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  static_assert(2 * (WCH / 4 / NT) == 8, "s_waitcnt vmcnt(8) below counts 2 chunks x WCH / 4 / NT transfers per thread");
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // conv_in's weights have arrived; the 2 x 4 chunk transfers may be on their way
+  int* smap = reinterpret_cast<int*>(win + 1536);
+  if (gpre) tile_rows_pre(gv, gcpt, gmine, gB, second ? 1 : 0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
+  else tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);
+  conv_in_mfma<true>(p, planes, smap, act, win, R, tid);
+  const int slot_v = tid < nb ? smap[tid] : 0;
+  unsigned long long t_trunk0 = 0;
+  if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // conv_in's output and the two chunks are visible to every wave
+  trunk_w2d(p, act, wbuf, tid);
+  unsigned long long t_trunk1 = 0;
+  if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
+  heads_f32<false, true>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
+  if (stamps && tid == 0) {
+    stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
+    stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
+    stamps[4 * blockIdx.x + 2] = t_trunk0 - t_c0;
+    stamps[4 * blockIdx.x + 3] = t_trunk1 - t_c0;
+  }
+}
+
+
+// ===================================================================================================
 // 3 x bf16 mode (opt-in): the same network function with the 3x3 convolutions evaluated on the bf16 MFMA
 // pipe.  Every float32 operand x is split exactly into three bf16 terms x = hi + mid + lo (+ <= 2^-27 |x|),
 // and a product is accumulated as hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid in float32: the dropped
@@ -1597,6 +1951,7 @@ struct caro_net {
   uint4* w3_dev;  // split residual weights (3xbf16 mode), or null
   float* ww_dev;  // transformed residual weights (f32w mode), or null
   uint32_t* wtab_dev;  // tile table (f32w mode), or null
+  float* ww2_dev;      // 2-D Winograd transformed residual weights (f32w2 mode), or null
   float* wpT_dev;      // policy matrix transposed, or null
   int device;
   unsigned long long* dbg_stamps;  // diagnostic (caro_net_debug_stamps): per-workgroup stamps of the slot launches too
@@ -1655,6 +2010,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   n->w3_dev = nullptr;
   n->ww_dev = nullptr;
   n->wtab_dev = nullptr;
+  n->ww2_dev = nullptr;
   n->wpT_dev = nullptr;
   const size_t pad = (size_t)cnet::TPC * cnet::WCHUNK;  // k_net_forward reads one chunk past the last tap
   if (hipMalloc((void**)&n->dev, (n_floats + pad) * sizeof(float)) != hipSuccess) {
@@ -1687,6 +2043,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   p.w3 = nullptr;
   p.ww = nullptr;
   p.wtab = nullptr;
+  p.ww2 = nullptr;
   p.w_pT = nullptr;
   p.ncu = 0; p.TB2 = 0; p.TB4 = 0;
   if (cnet::head_span_host(HW, A) > cnet::HEAD_STAGE_MAX) {  // the policy matrix column-major for the large-board heads
@@ -1826,11 +2183,38 @@ int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats
   return 0;
 }
 
+/* f32w2 mode (large boards): upload the 2-D Winograd F(2x2,3x3) transformed residual weights, already in the LDS image
+ * order of trunk_w2d -- [5 layers][8 chunks = phase * 4 + granule pair][2 b of the phase][4 a][2 h][64 co][8 floats],
+ * packed by caro_ai_amd/net_hip.py:pack_net_w2 -- from then on the forward calls of this net run k_net_forward_w2.
+ * One board per workgroup, its 2x2-output tiles in two 32-row MFMA blocks: boards of 12x12 .. 15x15 cells. */
+int caro_net_winograd2d_size(void) { return cnet::W2NCHUNK * cnet::WCH; }
+int caro_net_winograd2d_supported(int H, int W) {
+  return (255 / (H * W) == 1 && ((H + 1) / 2) <= 8 && ((W + 1) / 2) <= 8) ? 1 : 0;
+}
+int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_floats) {
+  if (!n || !ww2_host) return nfail(CARO_E_INVAL, "null argument");
+  if (n->kind != 0) return nfail(CARO_E_STATE, "not a conv net");
+  if (n->p.w3 || n->p.ww) return nfail(CARO_E_STATE, "net is already in another arithmetic mode");
+  if (!caro_net_winograd2d_supported(n->p.H, n->p.W))
+    return nfail(CARO_E_INVAL, "2-D Winograd form: boards of one per workgroup with at most 8 x 8 tiles (12x12 .. 15x15)");
+  const int64_t want = (int64_t)cnet::W2NCHUNK * cnet::WCH;
+  if (n_floats != want) return nfail(CARO_E_INVAL, "transformed weight image has the wrong size");
+  if (hipSetDevice(n->device) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
+  if (!n->ww2_dev && hipMalloc((void**)&n->ww2_dev, want * sizeof(float)) != hipSuccess)
+    return nfail(CARO_E_NOMEM, "hipMalloc failed");
+  if (hipMemcpy(n->ww2_dev, ww2_host, want * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+    return nfail(CARO_E_HIP, "hipMemcpy failed");
+  n->p.TB = 1;
+  n->p.ww2 = n->ww2_dev;
+  return 0;
+}
+
 void caro_net_destroy(caro_net* n) {
   if (!n) return;
   if (n->w3_dev) (void)hipFree(n->w3_dev);
   if (n->ww_dev) (void)hipFree(n->ww_dev);
   if (n->wtab_dev) (void)hipFree(n->wtab_dev);
+  if (n->ww2_dev) (void)hipFree(n->ww2_dev);
   if (n->wpT_dev) (void)hipFree(n->wpT_dev);
   if (n->dev) (void)hipFree(n->dev);
   delete n;
@@ -1853,6 +2237,7 @@ int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro
   n->w3_dev = nullptr;
   n->ww_dev = nullptr;
   n->wtab_dev = nullptr;
+  n->ww2_dev = nullptr;
   n->wpT_dev = nullptr;
   n->p.H = H; n->p.W = W; n->p.HW = H * W; n->p.A = A; n->p.TB = 4;
   *out = n;
@@ -1876,6 +2261,9 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
     if (n0->p.w3)
       hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, gpack, G, B);
+    else if (n0->p.ww2)
+      hipLaunchKernelGGL(cnet::k_net_forward_w2, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
+                         counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B);
     else if (n0->p.ww)
       hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B);
@@ -1889,7 +2277,7 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
 static int pair_ok(const caro_net* n0, const caro_net* n1) {
   if (n0->p.H != n1->p.H || n0->p.W != n1->p.W || n0->p.A != n1->p.A) return nfail(CARO_E_INVAL, "nets differ in shape");
   if (n0->kind != n1->kind || (n0->p.w3 == nullptr) != (n1->p.w3 == nullptr) ||
-      (n0->p.ww == nullptr) != (n1->p.ww == nullptr))
+      (n0->p.ww == nullptr) != (n1->p.ww == nullptr) || (n0->p.ww2 == nullptr) != (n1->p.ww2 == nullptr))
     return nfail(CARO_E_INVAL, "nets differ in kind / arithmetic mode");
   return 0;
 }

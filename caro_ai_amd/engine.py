@@ -26,7 +26,8 @@ COUNTER_NAMES = ["sims", "levels", "expansions", "terminals", "dropped", "overfl
 
 
 # inference= values served by the fused HIP net kernel -> HipNet mode
-HIP_NET_MODES = {"hip": "f32", "hipw": "f32w", "hip3x": "3xbf16"}
+# hipw: Winograd, the form chosen by the board (row form F(2,3); 2-D form F(2x2,3x3) from 13x13 up); hipw1 / hipw2 force one
+HIP_NET_MODES = {"hip": "f32", "hipw": "f32w", "hipw1": "f32w1", "hipw2": "f32w2", "hip3x": "3xbf16"}
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None

@@ -80,6 +80,53 @@ def pack_net_w(net: Net) -> np.ndarray:
     return out.reshape(-1)
 
 
+# 2-D Winograd F(2x2,3x3): which transformed column b a (phase, b-half) pair of the kernel processes (trunk_w2d)
+W2_PHASE_B = ((1, 2), (0, 3))  # [phase][bh]
+
+
+def wino2d_weights(w: np.ndarray) -> np.ndarray:
+    """U[a][b][co][ci] = sum_{ky,kx} G[a][ky] G[b][kx] w[co][ci][ky][kx], float64"""
+    return np.einsum("ak,bl,oikl->aboi", _WINO_G, _WINO_G, w.astype(np.float64))
+
+
+def pack_net_w2(net: Net) -> np.ndarray:
+    """float32[5][8 chunks][2 bh][4 a][2 h][64 co][8]: the transformed taps of the five residual layers in the LDS image
+    order of k_net_forward_w2 / trunk_w2d.  Chunk c = phase * 4 + cq holds, for the two b of the phase (W2_PHASE_B) and
+    all four a, the channel granules G = 2 cq and 2 cq + 1 of both lane halves: channels 32 h + 4 G + 0..3 at 16-byte
+    slot (G & 1) ^ ((co >> 3) & 1) of row (bh, a, h, co).  float64 transform, rounded once."""
+    net = net.eval()
+    out = np.zeros((5, 8, 2, 4, 2, 64, 8), np.float32)
+    co = np.arange(64)
+    for li, blk in enumerate(net.residual_blocks()):
+        w, _ = _fold(blk)
+        u = wino2d_weights(w.cpu().numpy())                    # [a, b, co, ci]
+        for phase in range(2):
+            for bh in range(2):
+                b = W2_PHASE_B[phase][bh]
+                for cq in range(4):
+                    for gi in range(2):
+                        G = 2 * cq + gi
+                        for h in range(2):
+                            ch = 32 * h + 4 * G
+                            blk4 = u[:, b, :, ch:ch + 4].astype(np.float32)  # [a, co, 4]
+                            slot = gi ^ ((co >> 3) & 1)                       # [co]
+                            for a in range(4):
+                                for sl in range(2):
+                                    m = slot == sl
+                                    out[li, phase * 4 + cq, bh, a, h, m, sl * 4:sl * 4 + 4] = blk4[a, m]
+    return out.reshape(-1)
+
+
+def wino2d_pays(H: int, W: int) -> bool:
+    """the 2-D form executes 64 tiles x 16 taps per board, the row form ceil(tiles / 32) * 32 x 12 with
+    ceil(H / 2) * W tiles: take the 2-D form where it is supported and at least 1/4 cheaper (13x13 up)"""
+    L = _lib.load()
+    if not L.caro_net_winograd2d_supported(H, W):
+        return False
+    rows = -(-(((H + 1) // 2) * W) // 32) * 32
+    return 64 * 16 <= 0.75 * rows * 12
+
+
 def _bf16_rne(x32: np.ndarray) -> np.ndarray:
     """float32 -> bf16 bits, round to nearest even (the rounding of k_net_forward_3x's bf16_rne)"""
     u = x32.view(np.uint32).astype(np.uint64)
@@ -118,7 +165,9 @@ def pack_net_3x(net: Net) -> np.ndarray:
 
 class HipNet:
     """Device-resident packed weights + the forward launch.
-    mode "f32w" (default): float32 on v_mfma_f32_32x32x2_f32, the 3x3 convolutions in row-Winograd F(2,3) form.
+    mode "f32w" (default): float32 on v_mfma_f32_32x32x2_f32, the 3x3 convolutions in Winograd form -- the row form
+                 F(2,3) ("f32w1"), or on large boards (13x13 up, one board per workgroup) the 2-D form F(2x2,3x3) ("f32w2").
+    mode "f32w1" / "f32w2": that form, forced.
     mode "f32": the same with direct 3x3 convolutions (a plain fma chain in k order).
     mode "3xbf16": opt-in, 3x3 convolutions on the bf16 MFMA pipe with three-way split operands."""
 
@@ -135,11 +184,17 @@ class HipNet:
         _lib.check(self.L.caro_net_create(self.H, self.W, self.A, negative_slope, packed.ctypes.data, packed.size,
                                           self.device.index or 0, C.byref(h)))
         self.h = h
+        if mode == "f32w":
+            mode = "f32w2" if wino2d_pays(self.H, self.W) else "f32w1"
         self.mode = mode
-        if mode == "3xbf16":
+        if mode == "f32w2":
+            w2 = pack_net_w2(net)
+            assert w2.size == self.L.caro_net_winograd2d_size()
+            _lib.check(self.L.caro_net_enable_winograd2d(self.h, w2.ctypes.data, w2.size))
+        elif mode == "3xbf16":
             w3 = pack_net_3x(net)
             _lib.check(self.L.caro_net_enable_3xbf16(self.h, w3.ctypes.data, w3.size))
-        elif mode == "f32w":
+        elif mode == "f32w1":
             ww = pack_net_w(net)
             _lib.check(self.L.caro_net_enable_winograd(self.h, ww.ctypes.data, ww.size))
         else:
@@ -158,9 +213,11 @@ class HipNet:
 
     def workgroup_mfma_flops(self):
         """flops ONE workgroup of the mode's trunk executes on the matrix pipe (v_mfma_f32_32x32x2_f32 = 4096 flop),
-        padding rows included: what bench.py's `roofline.achieved` counts.  f32w: 5 layers x 12 transformed taps
-        (4 p x 3 dx), each 32 k-steps on 8 waves; f32 (direct): 5 x 9 taps."""
-        taps = {"f32w": 60, "f32": 45}.get(self.mode)
+        padding rows included: what bench.py's `roofline.achieved` counts.  f32w1: 5 layers x 12 transformed taps
+        (4 p x 3 dx), each 32 k-steps on 8 waves; f32 (direct): 5 x 9 taps; f32w2: 5 x 16 taps on 64 tiles."""
+        if self.mode == "f32w2":  # 5 layers x 16 taps x (2 row tiles x 2 column tiles) blocks of 32 k-steps
+            return 5 * 16 * 4 * 32 * 4096.0
+        taps = {"f32w1": 60, "f32": 45}.get(self.mode)
         return None if taps is None else taps * 32 * 8 * 4096.0
 
     def forward_dev(self, planes, counts_dev_ptr, which, max_rows, probs, values, stream):

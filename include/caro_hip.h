@@ -242,6 +242,14 @@ int caro_net_enable_3xbf16(caro_net* n, const uint16_t* w3_host, int64_t n_u16);
  * library re-orders them into the chunks its kernel streams ([layer][dx][granule half][p]) at upload.
  * Lowers caro_net_boards_per_workgroup if 128 / (ceil(H/2)*W) is smaller. */
 int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats);
+/* f32w2 mode for LARGE boards (one board per workgroup: 12x12 .. 15x15): the 3x3 convolutions of lib/model.py:36-47 in
+ * 2-D Winograd F(2x2,3x3) form -- 16 / 36 of the direct form's multiplies (the row form of caro_net_enable_winograd:
+ * 24 / 36), the same float32 network function within the tolerance of tests/test_gpu_net.py.  ww2_host: the transformed
+ * weights in kernel order, caro_net_winograd2d_size() floats (caro_ai_amd/net_hip.py:pack_net_w2).  Mutually exclusive
+ * with the other arithmetic modes of a net. */
+int caro_net_winograd2d_size(void);
+int caro_net_winograd2d_supported(int H, int W);
+int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_floats);
 void caro_net_destroy(caro_net* n);
 int caro_net_boards_per_workgroup(const caro_net* n);
 /* rows [row0, row0 + L) of planes_dev f32[max_rows,2,H,W] -> probs_dev f32[.,A] (softmaxed), values_dev f32[.]

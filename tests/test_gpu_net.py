@@ -41,9 +41,13 @@ def _boards(L, shape, seed):
                                              # room for the partial-sum exchange (rows 127.. / 63..): full tiles only
                                              ((2, 8, 8), 64, None), ((2, 4, 4), 16, None)])
 @pytest.mark.parametrize("L", [1, 5, 6, 7, 29, 300])
-@pytest.mark.parametrize("mode", ["f32", "f32w", "3xbf16"])
+@pytest.mark.parametrize("mode", ["f32", "f32w", "f32w1", "3xbf16"])
 def test_hip_net_matches_torch_fp32(shape, A, weights, L, mode):
+    """f32w = the Winograd form the board gets by default (2-D F(2x2,3x3) at 15x15, the row form elsewhere in this
+    list); f32w1 = the row form everywhere"""
     from caro_ai_amd.net_hip import HipNet
+    if mode == "f32w1" and shape[1] < 13:
+        pytest.skip("f32w is the row form already")
     net = _net(shape, A, weights)
     x = _boards(L, shape, L)
     with torch.no_grad():
@@ -65,6 +69,56 @@ def test_hip_net_matches_torch_fp32(shape, A, weights, L, mode):
     e_ref = (p_ref.double() - p64).abs().max().item()
     assert e_hip < max(4 * e_ref, 1e-6), (e_hip, e_ref)
     assert torch.allclose(p.sum(1), torch.ones(L), atol=1e-5)
+    hn.close()
+
+
+@pytest.mark.parametrize("n", [12, 13, 14, 15])
+@pytest.mark.parametrize("L", [1, 2, 31, 257, 700])
+def test_winograd_2d_form_on_large_boards(n, L):
+    """k_net_forward_w2 (2-D Winograd F(2x2,3x3), one board per workgroup: 12x12 .. 15x15; lib/model.py:36-47,85-89):
+    the same float32 function within the tolerance of the other forms, independent of where a board sits in the
+    launch, and -- two nets in one launch -- the bits of two single launches."""
+    from caro_ai_amd import _lib
+    from caro_ai_amd.net_hip import HipNet, wino2d_pays
+    assert wino2d_pays(15, 15) and wino2d_pays(13, 13) and not wino2d_pays(6, 7) and not wino2d_pays(11, 11)
+    shape, A = (2, n, n), n * n
+    net = _net(shape, A, None, seed=n)
+    x = _boards(L, shape, 100 * n + L)
+    with torch.no_grad():
+        lg, vl = net(x)
+        p_ref = torch.softmax(lg, dim=1)
+        lg64, _ = net.double()(x.double())
+        p64 = torch.softmax(lg64, dim=1)
+    net.float()
+    hn = HipNet(net, "cuda:0", mode="f32w2")
+    assert hn.mode == "f32w2" and hn.L.caro_net_boards_per_workgroup(hn.h) == 1
+    xg = x.to("cuda:0")
+    p, v = hn(xg)
+    torch.cuda.synchronize()
+    e_hip = (p.cpu().double() - p64).abs().max().item()
+    e_ref = (p_ref.double() - p64).abs().max().item()
+    assert e_hip < max(4 * e_ref, 1e-6), (e_hip, e_ref)
+    assert (p.cpu() - p_ref).abs().max().item() < 1e-4 and (v.cpu() - vl[:, 0]).abs().max().item() < 1e-4
+    assert torch.allclose(p.sum(1), torch.ones(L, device="cuda:0"), atol=1e-5)
+    # a board's outputs do not depend on its row: the launch reversed gives the rows reversed, bit for bit
+    p2, v2 = hn(xg.flip(0).contiguous())
+    assert torch.equal(p2.flip(0), p) and torch.equal(v2.flip(0), v)
+    if L >= 2:  # two nets in one launch
+        net_b = _net(shape, A, None, seed=n + 50)
+        hb = HipNet(net_b, "cuda:0", mode="f32w2")
+        l0 = L // 3
+        counts = torch.tensor([l0, L - l0], dtype=torch.int32, device="cuda:0")
+        pa = torch.full((L, A), -1.0, device="cuda:0"); va = torch.full((L,), -9.0, device="cuda:0")
+        pb = torch.full((L, A), -1.0, device="cuda:0"); vb = torch.full((L,), -9.0, device="cuda:0")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(hn.L.caro_net_forward_pair(hn.h, hb.h, xg.data_ptr(), counts.data_ptr(), L, pa.data_ptr(),
+                                              va.data_ptr(), st))
+        hn.forward_dev(xg, counts.data_ptr(), 0, L, pb, vb, st)
+        hb.forward_dev(xg, counts.data_ptr(), 1, L, pb, vb, st)
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(va, vb)
+        assert torch.equal(pa[:l0], p[:l0])
+        hb.close()
     hn.close()
 
 

@@ -468,9 +468,10 @@ def test_config4_conv_net_exact_with_reference_net_arithmetic():
         eng.close()
 
 
-@pytest.mark.parametrize("inference", ["hipw", "hip"])
+@pytest.mark.parametrize("inference", ["hipw", "hipw1", "hip"])
 def test_config4_conv_net_on_gpu_vs_reference_games(inference):
-    """The same recorded games against the engine with the net ON THE GPU (fused HIP kernel, large-board tiles),
+    """The same recorded games against the engine with the net ON THE GPU (fused HIP kernel: hipw = the 2-D Winograd
+    form F(2x2,3x3) that config 4 runs from round 4 on, hipw1 = the row form, hip = direct convolutions),
     all games in one engine, eviction + 4 096-node cap.  Stated tolerance as for Connect4: >= 99 %
     of the compared plies carry the reference's root visit vector, |d pi| <= 0.15 elsewhere, and a game that
     matched at every ply ends with the recorded result and step count."""
