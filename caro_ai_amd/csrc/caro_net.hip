@@ -1418,11 +1418,15 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
     // (the per-set addresses are re-formed in every layer: hoisted out of the layer loop they would take 128 registers)
 #pragma unroll
     for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(ra[0][r]), "+v"(rb[0][r]), "+v"(ra[1][r]), "+v"(rb[1][r]));
+    /*@LST(layer, 0)*/
     W2_ALOAD(W0, W1, W2, W3, 0)
     W2_PAIR(0) W2_PAIR(2) W2_PAIR(4) W2_PAIR(6)
+    /*@LST(layer, 1)*/
     W2_FOLD(Zs0, Zs1)   // phase 0 (b = 1 | 2): what this wave keeps AND what it hands to its partner
     W2_ZERO
+    /*@LST(layer, 2)*/
     W2_PAIR(8) W2_PAIR(10) W2_PAIR(12) W2_PAIR(14)
+    /*@LST(layer, 3)*/
     W2_FOLD(Zt0, Zt1)   // phase 1 (b = 0 | 3)
     // ---- epilogue.  Requested in front of the barrier: the bias (global memory) and the OLD values of this wave's
     // output cells (the residual input; only this wave ever writes these cells)
@@ -1437,10 +1441,12 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
       old0[q] = ovalid[0] ? *reinterpret_cast<const float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
       old1[q] = ovalid[1] ? *reinterpret_cast<const float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    /*@LST(layer, 4)*/
     // every wave has read this layer's input activations (and this wave its old values): the buffer may be overwritten
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    /*@LST(layer, 5)*/
     {  // the partner's partial sums go into the partner's output cells
       float* pr0 = act + prow[0] * NF;
       float* pr1 = act + prow[1] * NF;
@@ -1455,6 +1461,7 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    /*@LST(layer, 6)*/
     // finish: bh 0: Y = (Z[b=0] + Z[b=1]) + Z[b=2](received);  bh 1: Y = (Z[b=1](received) - Z[b=2]) - Z[b=3];
     // then in place v = v + leaky(conv(v) + bias)  (lib/model.py:85-89); only real cells are written
 #pragma unroll
@@ -1488,6 +1495,7 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
     }
     // new activations visible to every wave; also the chunk barrier of the next layer's first chunk (this wave's share
     // of its second chunk has arrived, nobody reads this layer's last chunks any more)
+    /*@LST(layer, 7)*/
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
