@@ -70,7 +70,7 @@ struct NetParams {
   const uint4* w3;      // 3xbf16 mode: [45 taps][1536 granules] LDS image of the split residual weights, or null
   const float* ww;      // f32w mode: [5][3 dx][2 granule halves] chunks of [4 p][2 h][64 co][16] transformed residual weights (LDS image order of trunk_w), or null
   const uint32_t* wtab; // f32w mode: [128] tile of MFMA row (row tile, lane): board | ty << 8 | x << 16 | valid << 24
-  const float* ww2;     // f32w2 mode: [5][8 chunks = b * 2 + granule half][4 a][2 h][64 co][16] 2-D Winograd F(2x2,3x3) transformed residual weights (LDS image order of trunk_w2d), or null
+  const float* ww2;     // f32w2 mode: [5][8 chunks][2 b][4 a][2 h][64 co][8] 2-D Winograd F(2x2,3x3) transformed residual weights (LDS image order of trunk_w2d), or null
   int ncu, TB2, TB4;    // f32w mode: compute units; boards per workgroup of the 2- / 4-way K-split overflow tiles (0: off)
 };
 
@@ -1251,44 +1251,32 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
 //     M[a][b] = sum_ci U[a][b][co][ci] V[a][b][ci]                                                       (MFMA)
 //     Y[u][v] = sum_ab At[u][a] At[v][b] M[a][b]      At = [1 1 1 0; 0 1 -1 -1]
 // GEMM rows are the 64 tiles of a board (8 x 8 for 15 x 15: exactly two 32-row MFMA blocks, no padding rows; the row
-// form needs 120 tiles in 128 rows), 16 transformed taps of K = 64.
-// The workgroup is FOUR waves, one per SIMD, each free to use the SIMD's whole register file: wave = (row tile rt,
-// column tile ct) = 32 tiles x 32 channels, ALL sixteen taps -- the whole output transform stays in the wave's
-// registers and nothing is exchanged between waves (a first version split the taps over eight waves of 256 registers:
-// partial sums through LDS, three barriers per layer, 48.7 k cycles per layer against 32.8 k of MFMA time).
-// A wave runs the four transformed columns b = 0..3 one after another (phases of 8 operand sets: the channel
-// granules), with four accumulators M[a = 0..3][b] per phase in one of TWO accumulator sets, so that the fold of
-// phase b -- Z[u] = sum_a At[u][a] M[a][b], then Y[u][0] += Z (b = 0, 1, 2), Y[u][1] += Z, -Z, -Z (b = 1, 2, 3) -- runs on
-// the vector pipe underneath the MFMAs of phase b + 1.  The bias is the initial value of M[1][1], which enters all four
-// outputs with +1.  With a single wave per SIMD nothing else covers its latencies, so the stream is software-pipelined
-// by hand: the 12 LDS reads of set T+1 (4 tile rows x the 2 input columns b combines, 4 weight granules) are requested
-// in front of the MFMAs of set T, and its column combination + row transform (V0 = c0-c2, V1 = c1+c2, V2 = c2-c1,
-// V3 = c1-c3) are spread between the last eight of them.
-// Weight chunk = 32 KiB = one b, half the channel granules, all four a: [a][h][co][4 granules] -- the chunk format of
-// the row form, 8 chunks per layer through the same ring of three buffers, one workgroup barrier per chunk (64 MFMAs
-// of a wave) plus two per layer around the in-place epilogue.
+// form needs 120 tiles in 128 rows), 16 transformed taps of K = 64.  Work split: wave = (row tile rt, column tile ct,
+// bh) -- 32 tiles x 32 channels, and the wave's HALF of the taps: b in {1, 0} for bh = 0, b in {2, 3} for bh = 1, all
+// four a.  A wave keeps the four accumulators M[0..3][b] of ONE b at a time:
+//     phase 0  b = 1 | 2:  K loop, then Z[u] = sum_a At[u][a] M[a][b] (32 registers) stays behind
+//     phase 1  b = 0 | 3:  K loop, then the same fold
+// and FINISHES output column v = bh of its tiles:  Y[u][0] = Z[u][b=0] + Z[u][1] + Z[u][2]  (bh = 0; Z[u][2] comes from
+// the partner wave), Y[u][1] = Z[u][1] - Z[u][2] - Z[u][3]  (bh = 1; Z[u][1] from the partner).  What a wave hands to its
+// partner is exactly its phase-0 fold.  The exchange needs no extra LDS: after the "inputs read" barrier the activation
+// buffer is dead, so the partner's partial sums are written INTO THE PARTNER'S OUTPUT CELLS, read back from there behind
+// a second barrier and overwritten with the finished activations (three barriers per layer).
+// Operand stream per (b, channel granule): 8 cell reads (4 tile rows x the 2 columns b combines) + 4 weight granules
+// -> column combine, row transform (as the row form: V0 = c0-c2, V1 = c1+c2, V2 = c2-c1, V3 = c1-c3) -> 16 MFMAs.
+// Weight chunk = 32 KiB = [2 b of the phase][4 a][2 h][64 co][2 channel granules]: 8 chunks per layer (4 per phase)
+// through the same ring of three buffers, one workgroup barrier per chunk (32 MFMAs of a wave).
 // Activation rows keep the index cell = y * W + x; their granule swizzle key is akey<true> (tile coordinates), under
 // which the 16 lanes of every ds_read_b128 group -- 8 tile columns x 2 tile rows, see the lane -> tile map below --
 // read 16 different slots for any cell offset.
-constexpr int NT2 = 256;                  // threads of k_net_forward_w2
 constexpr int W2NCHUNK = NRES * 8;        // 40 chunks of WCH floats
-constexpr int W2SETS = 32;                // operand sets per layer and wave: 4 b x 8 channel granules
-
-// chunk c of the weights -> ring buffer c % WNBUF, by NTH threads
-template <int NTH>
-__device__ __forceinline__ void fetch_chunk_n(const float* ww, int c, unsigned wring, int tid) {
-  const float4* src = reinterpret_cast<const float4*>(ww + (size_t)c * WCH) + tid;
-  const unsigned dst = __builtin_amdgcn_readfirstlane(wring + (unsigned)(c % WNBUF) * (WCH * 4) + (unsigned)(tid >> 6) * 1024u);
-#pragma unroll
-  for (int m = 0; m < WCH / 4 / NTH; ++m) dma_b128(src + m * NTH, dst + m * NTH * 16);
-}
+constexpr int W2SETS = 16;                // operand sets per layer and wave: 2 phases x 8 channel granules
 
 __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float* wbuf, int tid) {
   const float slope = p.slope;
   const int H = p.H, W = p.W;
   const int wave = tid >> 6, lane = tid & 63;
   const int i = lane & 31, h = lane >> 5;
-  const int ct = wave & 1, rt = wave >> 1;
+  const int ct = wave & 1, rt = (wave >> 1) & 1, bh = wave >> 2;
   // lane -> tile.  ds_read_b128 is served in the lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} of each half
   // (MI355X_MICROARCH.md, LDS): quads 0,3,5,6 form group 0 and quads 1,2,4,7 group 1, and quad >> 1 numbers the quads
   // of either group 0..3.  Position q = 0..15 inside the group -> tile column q & 7, tile row (group * 2 + (q >> 3)).
@@ -1300,222 +1288,217 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
   // LDS byte address of input cell (r, j) of the tile, channel granule 8h (+ G, XORed in per set), swizzle key folded
   // in.  A cell outside the board reads the zero row -- any of its slots: the one the virtual cell's key selects, which
   // keeps the lanes of a group on different slots.
-  unsigned ra[4][4];
+  auto caddr = [&](int r, int j) -> unsigned {
+    const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + j;
+    const bool ok = tvalid && y >= 0 && y < H && x >= 0 && x < W;
+    const int row = ok ? y * W + x : ZROW;
+    const int key = ((tx + (j >> 1)) & 7) | (((ty + (r >> 1)) & 1) << 3);
+    return abase + (unsigned)(row * NF + (((h * 8) ^ key) << 2)) * 4u;
+  };
+  // the two input columns a phase combines, c_r = d[r][jA] + sg * d[r][jB]:
+  //   bh 0: phase 0 (b = 1)  x1 + x2      phase 1 (b = 0)  x0 - x2
+  //   bh 1: phase 0 (b = 2)  x2 - x1      phase 1 (b = 3)  x1 - x3
+  const int jA0 = bh ? 2 : 1, jB0 = bh ? 1 : 2, jA1 = bh ? 1 : 0, jB1 = bh ? 3 : 2;
+  const float sg0 = bh ? -1.f : 1.f, sg1 = -1.f;
+  unsigned ra[2][4], rb[2][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + j;
-      const bool ok = tvalid && y >= 0 && y < H && x >= 0 && x < W;
-      const int row = ok ? y * W + x : ZROW;
-      const int key = ((tx + (j >> 1)) & 7) | (((ty + (r >> 1)) & 1) << 3);
-      ra[r][j] = abase + (unsigned)(row * NF + (((h * 8) ^ key) << 2)) * 4u;
-    }
-  // this lane's weight row in ring buffer 0: [a = 0][h][co = ct*32 + i], 4 granules of 16 bytes, the granule index XORed
-  // with (co >> 2) & 3 (as trunk_w: the 16 lanes of a read group hold every residue of i mod 4 four times, with four
-  // different (i >> 2) & 3)
-  const unsigned wlane = wring + (unsigned)((h * 64 + ct * 32 + i) * 16 + (((i >> 2) & 3) << 2)) * 4u;
+  for (int r = 0; r < 4; ++r) {
+    ra[0][r] = caddr(r, jA0); rb[0][r] = caddr(r, jB0);
+    ra[1][r] = caddr(r, jA1); rb[1][r] = caddr(r, jB1);
+  }
+  // this lane's weight row in ring buffer 0: [b = bh][a = 0][h][co = ct*32 + i], 2 granules of 16 bytes, the granule
+  // index XORed with (co >> 3) & 1 (lanes i and i ^ 8.. of a read group then sit on different slots)
+  const unsigned wlane = wring + (unsigned)(bh * 16384 + (h * 64 + ct * 32 + i) * 32 + (((i >> 3) & 1) << 4));
   // output side (weights are the first MFMA operand: a lane's 16 accumulator registers are 4 groups q of 4 consecutive
-  // channels ct*32 + 8q + 4h + 0..3 of ITS tile): the four cells (2ty + u, 2tx + v) of the tile
+  // channels ct*32 + 8q + 4h + 0..3 of ITS tile): this wave finishes cells (2ty + u, 2tx + bh), its partner the
+  // cells (2ty + u, 2tx + 1 - bh)
+  const int xo = 2 * tx + bh, xp = 2 * tx + 1 - bh;
   const int g0 = ct * 8 + h;  // granule of channel group q is g0 + 2q
-  float* ocell[2][2];
-  int okey[2][2];
-  bool ovalid[2][2];
+  int orow[2], prow[2], okey[2], pkey[2];
+  bool ovalid[2], pvalid[2];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const int y = 2 * ty + u, x = 2 * tx + v;
-      ovalid[u][v] = tvalid && y < H && x < W;
-      ocell[u][v] = act + (ovalid[u][v] ? y * W + x : ZROW) * NF;
-      okey[u][v] = (((x + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
-    }
+  for (int u = 0; u < 2; ++u) {
+    const int y = 2 * ty + u;
+    ovalid[u] = tvalid && y < H && xo < W;
+    pvalid[u] = tvalid && y < H && xp < W;
+    orow[u] = y * W + xo;
+    prow[u] = y * W + xp;
+    okey[u] = (((xo + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
+    pkey[u] = (((xp + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
+  }
 
-  f4v CA0, CA1, CA2, CA3, CB0, CB1, CB2, CB3;  // the 4 x 2 input cells of the operand set being fetched
-  f4v W0, W1, W2, W3, X0, X1, X2, X3;          // weight granules: the set the MFMAs read, the set being fetched
-  f4v V0, V1, V2, V3, N0, N1, N2, N3;          // transformed inputs: the set the MFMAs read, the set being formed
-// the reads of operand set T1 of the layer: column b = T1 >> 3, channel granule G = T1 & 7 of the lane half, chunk
-// T1 >> 2 of the layer.  The two input columns b combines (c_r = d[r][jA] +- d[r][jB]):
-//   b 0: x0 - x2     b 1: x1 + x2     b 2: x2 - x1     b 3: x1 - x3
-#define W3_LOADS(B0, B1, B2, B3, T1)                                                                         \
+  f4v CA0, CA1, CA2, CA3, CB0, CB1, CB2, CB3;  // the 4 x 2 input cells of the operand set in flight
+  f4v W0, W1, W2, W3, X0, X1, X2, X3;          // its weight granules: two sets, the MFMAs read one while the other loads
+// operand set T of the layer: phase T >> 3, channel granule G = T & 7 of the lane half, chunk T >> 1 of the layer
+#define W2_ALOAD(B0, B1, B2, B3, T)                                                                          \
   {                                                                                                          \
-    constexpr int b_ = (T1) >> 3, G_ = (T1) & 7, cq_ = (T1) >> 2;                                            \
-    constexpr int jA_ = b_ == 0 ? 0 : b_ == 2 ? 2 : 1, jB_ = b_ == 2 ? 1 : b_ == 3 ? 3 : 2;                  \
-    const unsigned wa_ = (wlane + rbuf[cq_ % WNBUF]) ^ ((unsigned)(G_ & 3) << 4);                            \
-    /* (the set's addresses are formed HERE: without the fence the compiler forms all 128 of a layer up front) */ \
-    asm volatile("" : "+v"(ra[0][jA_]), "+v"(ra[1][jA_]), "+v"(ra[2][jA_]), "+v"(ra[3][jA_]),                \
-                      "+v"(ra[0][jB_]), "+v"(ra[1][jB_]), "+v"(ra[2][jB_]), "+v"(ra[3][jB_]));               \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(CA0) : "v"(ra[0][jA_] ^ (G_ << 4)));                           \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(CB0) : "v"(ra[0][jB_] ^ (G_ << 4)));                           \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(CA1) : "v"(ra[1][jA_] ^ (G_ << 4)));                           \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(CB1) : "v"(ra[1][jB_] ^ (G_ << 4)));                           \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(CA2) : "v"(ra[2][jA_] ^ (G_ << 4)));                           \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(CB2) : "v"(ra[2][jB_] ^ (G_ << 4)));                           \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(CA3) : "v"(ra[3][jA_] ^ (G_ << 4)));                           \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(CB3) : "v"(ra[3][jB_] ^ (G_ << 4)));                           \
+    constexpr int ph_ = (T) >> 3, G_ = (T) & 7, cq_ = (T) >> 1;                                              \
+    const unsigned wa_ = (wlane + rbuf[cq_ % WNBUF]) ^ ((unsigned)(G_ & 1) << 4);                            \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CA0) : "v"(ra[ph_][0] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CB0) : "v"(rb[ph_][0] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CA1) : "v"(ra[ph_][1] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CB1) : "v"(rb[ph_][1] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CA2) : "v"(ra[ph_][2] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CB2) : "v"(rb[ph_][2] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CA3) : "v"(ra[ph_][3] ^ (G_ << 4)));                           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(CB3) : "v"(rb[ph_][3] ^ (G_ << 4)));                           \
     asm volatile("ds_read_b128 %0, %1" : "=v"(B0) : "v"(wa_));                                               \
-    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(B1) : "v"(wa_));                                   \
-    asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(B2) : "v"(wa_));                                  \
-    asm volatile("ds_read_b128 %0, %1 offset:24576" : "=v"(B3) : "v"(wa_));                                  \
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(B1) : "v"(wa_));                                   \
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(B2) : "v"(wa_));                                   \
+    asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(B3) : "v"(wa_));                                  \
   }
 // every LDS read this wave has issued is complete (the compiler does not know of the reads above)
-#define W3_AWAIT(B0, B1, B2, B3)                                                                             \
+#define W2_AWAIT(B0, B1, B2, B3)                                                                             \
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                        \
                : "+v"(CA0), "+v"(CA1), "+v"(CA2), "+v"(CA3), "+v"(CB0), "+v"(CB1), "+v"(CB2), "+v"(CB3),     \
                  "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3));
-// column combination of the fetched set (T1 its index: the sign is b's), one row r at a time
-#define W3_COMB(R, CA, CB, T1) const f4v c##R##_ = (((T1) >> 3) == 1) ? (CA + CB) : (CA - CB);
-// one slice e of the fold of the PREVIOUS phase pb (accumulators P0..P3): Z[u] = sum_a At[u][a] M[a], then
-//   pb 0: Y[u][0] = Z        pb 1: Y[u][0] += Z, Y[u][1] = Z        pb 2: Y[u][0] += Z, Y[u][1] -= Z        pb 3: Y[u][1] -= Z
-#define W3_FOLD(PB, E, P0, P1, P2, P3)                                                                       \
-  {                                                                                                          \
-    const float z0_ = (P0[E] + P1[E]) + P2[E], z1_ = (P1[E] - P2[E]) - P3[E];                                \
-    if ((PB) == 0) { Y00[E] = z0_; Y10[E] = z1_; }                                                           \
-    if ((PB) == 1) { Y00[E] += z0_; Y10[E] += z1_; Y01[E] = z0_; Y11[E] = z1_; }                             \
-    if ((PB) == 2) { Y00[E] += z0_; Y10[E] += z1_; Y01[E] -= z0_; Y11[E] -= z1_; }                           \
-    if ((PB) == 3) { Y01[E] -= z0_; Y11[E] -= z1_; }                                                         \
-  }
-// MFMA k of the step (k = 4 * round + a) and the vector work placed behind it: in the second step of a phase the
-// fold slice k of the previous phase; behind MFMAs 8..11 the column combination of the next set, behind 12..15 its
-// row transform
-#define W3_MF(ACC, WV, VV, C) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.C, VV.C, ACC, 0, 0, 0);
-// The MFMAs of a step depend on nothing near them (their operands were formed a step earlier, their results are read a
-// phase later), and instruction selection is then free to collect them somewhere else -- it did: 96 MFMAs in a row
-// behind six steps of bare loads and transforms.  An empty asm that "rewrites" the accumulators keeps every round of four
-// where it is written (no instruction, no wait: the accumulators stay in the AGPRs they are in).
-#define W3_PIN(A0, A1, A2, A3) asm volatile("" : "+a"(A0), "+a"(A1), "+a"(A2), "+a"(A3));
-#define W3_HOOK(T, K, P0, P1, P2, P3)                                                                        \
-  __builtin_amdgcn_sched_barrier(0);                                                                         \
-  if ((T) % 8 == 1 && (T) > 8) W3_FOLD(((T) >> 3) - 1, K, P0, P1, P2, P3)                                    \
-  __builtin_amdgcn_sched_barrier(0);
-// One step of the layer's software pipeline: set T (V*, W*) is in registers.  At the first set of a chunk the chunk's
-// ONE workgroup barrier (this wave's share of chunk c+1 has arrived -> barrier -> chunk c+1 visible to every wave,
-// nobody reads chunk c-1 any more -> chunk c+2 goes into that buffer); request set T+1; MFMAs with the vector work of
-// set T+1 and of the previous phase's fold between them.
-#define W3_STEP(T, W0, W1, W2, W3, X0, X1, X2, X3, V0, V1, V2, V3, N0, N1, N2, N3, A0, A1, A2, A3, P0, P1, P2, P3) \
-  if ((T) % 4 == 0) {                                                                                        \
+// One step of the layer's software pipeline (the structure of trunk_w's): set T was requested a whole burst ago; wait,
+// at the first set of a chunk pass the chunk's ONE workgroup barrier (this wave's share of chunk c+1 has arrived ->
+// barrier -> chunk c+1 visible to every wave, nobody reads chunk c-1 any more -> chunk c+2 goes into that buffer),
+// combine the columns, form each transformed operand in front of its first MFMA, request set T+1 behind the first
+// round of MFMAs, issue the other twelve.
+#define W2_STEP(T, B0, B1, B2, B3, NB0, NB1, NB2, NB3)                                                       \
+  W2_AWAIT(B0, B1, B2, B3)                                                                                   \
+  if ((T) % 2 == 0) {                                                                                        \
     if ((T) != 0) {                                                                                          \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
       __syncthreads();                                                                                       \
     }                                                                                                        \
-    if (c0 + (T) / 4 + 2 < W2NCHUNK) fetch_chunk_n<NT2>(p.ww2, c0 + (T) / 4 + 2, wring, tid);                \
+    if (c0 + (T) / 2 + 2 < W2NCHUNK) fetch_chunk(p.ww2, c0 + (T) / 2 + 2, wring, tid);                       \
   }                                                                                                          \
-  if ((T) + 1 < W2SETS) W3_LOADS(X0, X1, X2, X3, ((T) + 1) % W2SETS)                                         \
-  __builtin_amdgcn_sched_barrier(0);                                                                         \
-  if ((T) % 8 == 0) {  /* a phase begins: fresh accumulators (the bias rides in M[1][1]) */                   \
-    A0 = __builtin_amdgcn_mfma_f32_32x32x2f32(W0.x, V0.x, zero16, 0, 0, 0);                                  \
-    A1 = __builtin_amdgcn_mfma_f32_32x32x2f32(W1.x, V1.x, ((T) >> 3) == 1 ? bias16 : zero16, 0, 0, 0);       \
-    A2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W2.x, V2.x, zero16, 0, 0, 0);                                  \
-    A3 = __builtin_amdgcn_mfma_f32_32x32x2f32(W3.x, V3.x, zero16, 0, 0, 0);                                  \
-  } else {                                                                                                   \
-    W3_MF(A0, W0, V0, x) W3_HOOK(T, 0, P0, P1, P2, P3)                                                       \
-    W3_MF(A1, W1, V1, x) W3_HOOK(T, 1, P0, P1, P2, P3)                                                       \
-    W3_MF(A2, W2, V2, x) W3_HOOK(T, 2, P0, P1, P2, P3)                                                       \
-    W3_MF(A3, W3, V3, x) W3_HOOK(T, 3, P0, P1, P2, P3)                                                       \
-  }                                                                                                          \
-  W3_PIN(A0, A1, A2, A3)                                                                                     \
-  W3_MF(A0, W0, V0, y) W3_HOOK(T, 4, P0, P1, P2, P3)                                                         \
-  W3_MF(A1, W1, V1, y) W3_HOOK(T, 5, P0, P1, P2, P3)                                                         \
-  W3_MF(A2, W2, V2, y) W3_HOOK(T, 6, P0, P1, P2, P3)                                                         \
-  W3_MF(A3, W3, V3, y) W3_HOOK(T, 7, P0, P1, P2, P3)                                                         \
-  W3_PIN(A0, A1, A2, A3)                                                                                     \
-  if ((T) + 1 < W2SETS) W3_AWAIT(X0, X1, X2, X3)                                                             \
-  W3_COMB(0, CA0, CB0, (T) + 1)                                                                              \
-  W3_MF(A0, W0, V0, z) W3_HOOK(T, 8, P0, P1, P2, P3)                                                         \
-  W3_COMB(1, CA1, CB1, (T) + 1)                                                                              \
-  W3_MF(A1, W1, V1, z) W3_HOOK(T, 9, P0, P1, P2, P3)                                                         \
-  W3_COMB(2, CA2, CB2, (T) + 1)                                                                              \
-  W3_MF(A2, W2, V2, z) W3_HOOK(T, 10, P0, P1, P2, P3)                                                        \
-  W3_COMB(3, CA3, CB3, (T) + 1)                                                                              \
-  W3_MF(A3, W3, V3, z) W3_HOOK(T, 11, P0, P1, P2, P3)                                                        \
-  N0 = c0_ - c2_;                                                                                            \
-  W3_MF(A0, W0, V0, w) W3_HOOK(T, 12, P0, P1, P2, P3)                                                        \
-  N1 = c1_ + c2_;                                                                                            \
-  W3_MF(A1, W1, V1, w) W3_HOOK(T, 13, P0, P1, P2, P3)                                                        \
-  N2 = c2_ - c1_;                                                                                            \
-  W3_MF(A2, W2, V2, w) W3_HOOK(T, 14, P0, P1, P2, P3)                                                        \
-  N3 = c1_ - c3_;                                                                                            \
-  W3_MF(A3, W3, V3, w) W3_HOOK(T, 15, P0, P1, P2, P3)
-// two steps: the operand sets swap roles
-#define W3_PAIR(T, A0, A1, A2, A3, P0, P1, P2, P3)                                                           \
-  { W3_STEP(T, W0, W1, W2, W3, X0, X1, X2, X3, V0, V1, V2, V3, N0, N1, N2, N3, A0, A1, A2, A3, P0, P1, P2, P3) }     \
-  { W3_STEP((T) + 1, X0, X1, X2, X3, W0, W1, W2, W3, N0, N1, N2, N3, V0, V1, V2, V3, A0, A1, A2, A3, P0, P1, P2, P3) }
-#define W3_PHASE(B, A0, A1, A2, A3, P0, P1, P2, P3)                                                          \
-  W3_PAIR(8 * (B), A0, A1, A2, A3, P0, P1, P2, P3) W3_PAIR(8 * (B) + 2, A0, A1, A2, A3, P0, P1, P2, P3)      \
-  W3_PAIR(8 * (B) + 4, A0, A1, A2, A3, P0, P1, P2, P3) W3_PAIR(8 * (B) + 6, A0, A1, A2, A3, P0, P1, P2, P3)
+  {                                                                                                          \
+    const float sg_ = ((T) >> 3) ? sg1 : sg0;                                                                \
+    const f4v c0_ = CA0 + sg_ * CB0, c1_ = CA1 + sg_ * CB1, c2_ = CA2 + sg_ * CB2, c3_ = CA3 + sg_ * CB3;    \
+    const f4v v0 = c0_ - c2_;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    /* a phase's first MFMAs start from C = 0 (an inline constant, no registers to clear) */                    \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.x, v0.x, (T) % 8 == 0 ? zero16 : accM0, 0, 0, 0);        \
+    const f4v v1 = c1_ + c2_;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.x, v1.x, (T) % 8 == 0 ? zero16 : accM1, 0, 0, 0);        \
+    const f4v v2 = c2_ - c1_;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.x, v2.x, (T) % 8 == 0 ? zero16 : accM2, 0, 0, 0);        \
+    const f4v v3 = c1_ - c3_;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.x, v3.x, (T) % 8 == 0 ? zero16 : accM3, 0, 0, 0);        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if ((T) + 1 < W2SETS) W2_ALOAD(NB0, NB1, NB2, NB3, ((T) + 1) % W2SETS)                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.y, v0.y, accM0, 0, 0, 0);                                \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.y, v1.y, accM1, 0, 0, 0);                                \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.y, v2.y, accM2, 0, 0, 0);                                \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.y, v3.y, accM3, 0, 0, 0);                                \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.z, v0.z, accM0, 0, 0, 0);                                \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.z, v1.z, accM1, 0, 0, 0);                                \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.z, v2.z, accM2, 0, 0, 0);                                \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.z, v3.z, accM3, 0, 0, 0);                                \
+    accM0 = __builtin_amdgcn_mfma_f32_32x32x2f32(B0.w, v0.w, accM0, 0, 0, 0);                                \
+    accM1 = __builtin_amdgcn_mfma_f32_32x32x2f32(B1.w, v1.w, accM1, 0, 0, 0);                                \
+    accM2 = __builtin_amdgcn_mfma_f32_32x32x2f32(B2.w, v2.w, accM2, 0, 0, 0);                                \
+    accM3 = __builtin_amdgcn_mfma_f32_32x32x2f32(B3.w, v3.w, accM3, 0, 0, 0);                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  }
+#define W2_PAIR(T)                                                                                           \
+  W2_STEP(T, W0, W1, W2, W3, X0, X1, X2, X3)                                                                 \
+  W2_STEP((T) + 1, X0, X1, X2, X3, W0, W1, W2, W3)
+// Z[u] = sum_a At[u][a] M[a]: u = 0: M0 + M1 + M2, u = 1: M1 - M2 - M3 (left to right)
+#define W2_FOLD(Z0_, Z1_)                                                                                    \
+  _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                           \
+    Z0_[e] = (accM0[e] + accM1[e]) + accM2[e];                                                               \
+    Z1_[e] = (accM1[e] - accM2[e]) - accM3[e];                                                               \
+  }
 
   for (int layer = 0; layer < NRES; ++layer) {
-    const f32x16 zero16 = {};  // (an inline constant of the MFMA, not registers)
     const int c0 = layer * 8;  // first chunk of the layer; chunk c0 + k sits in ring buffer (c0 + k) % WNBUF
     unsigned rbuf[WNBUF];
 #pragma unroll
     for (int k = 0; k < WNBUF; ++k) rbuf[k] = (unsigned)((c0 + k) % WNBUF) * (WCH * 4);
-    /*@LST(layer, 0)*/
-    f32x16 MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3, Y00, Y01, Y10, Y11;
-    f32x16 bias16 = zero16;  // assigned two steps ahead of its use (phase 1's first MFMA)
+    const f32x16 zero16 = {};
+    f32x16 accM0, accM1, accM2, accM3, Zs0, Zs1, Zt0, Zt1;
     // (the per-set addresses are re-formed in every layer: hoisted out of the layer loop they would take 128 registers)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(ra[r][0]), "+v"(ra[r][1]), "+v"(ra[r][2]), "+v"(ra[r][3]));
-    // set 0 of the layer: the one set whose reads and transform nothing covers
-    W3_LOADS(W0, W1, W2, W3, 0)
-    W3_AWAIT(W0, W1, W2, W3)
-    {
-      W3_COMB(0, CA0, CB0, 0) W3_COMB(1, CA1, CB1, 0) W3_COMB(2, CA2, CB2, 0) W3_COMB(3, CA3, CB3, 0)
-      V0 = c0_ - c2_; V1 = c1_ + c2_; V2 = c2_ - c1_; V3 = c1_ - c3_;
-    }
-    W3_PAIR(0, MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3) W3_PAIR(2, MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3)
-    W3_PAIR(4, MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3)
-    // the bias of this lane's 16 channels, in accumulator order: the initial value of M[1][1] at the next phase's first
-    // MFMA (requested two steps ahead; earlier it would sit in 16 registers through the whole phase)
-    {
-      const float* bias = p.b_res + layer * NF + ct * 32 + 4 * h;
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(ra[0][r]), "+v"(rb[0][r]), "+v"(ra[1][r]), "+v"(rb[1][r]));
+    /*@LST(layer, 0)*/
+    W2_ALOAD(W0, W1, W2, W3, 0)
+    W2_PAIR(0) W2_PAIR(2) W2_PAIR(4)
+    // the bias of this lane's 16 channels, requested two steps ahead of the fold that adds it
+    const float* bias = p.b_res + layer * NF + ct * 32 + 4 * h;
+    float4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + 8 * q);
+    W2_PAIR(6)
+    /*@LST(layer, 1)*/
+    W2_FOLD(Zs0, Zs1)   // phase 0 (b = 1 | 2): what this wave keeps AND what it hands to its partner
+    // the bias joins Z[b = 1] (the bh = 0 waves' phase 0), which enters all four outputs of a tile with +1: the bh = 1
+    // waves get it with the partial sums their partners hand over
+    if (bh == 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 bq = *reinterpret_cast<const float4*>(bias + 8 * q);
-        bias16[4 * q] = bq.x; bias16[4 * q + 1] = bq.y; bias16[4 * q + 2] = bq.z; bias16[4 * q + 3] = bq.w;
+        Zs0[4 * q] += bq[q].x; Zs0[4 * q + 1] += bq[q].y; Zs0[4 * q + 2] += bq[q].z; Zs0[4 * q + 3] += bq[q].w;
+        Zs1[4 * q] += bq[q].x; Zs1[4 * q + 1] += bq[q].y; Zs1[4 * q + 2] += bq[q].z; Zs1[4 * q + 3] += bq[q].w;
       }
     }
-    W3_PAIR(6, MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3)
-    /*@LST(layer, 1)*/
-    W3_PHASE(1, MB0, MB1, MB2, MB3, MA0, MA1, MA2, MA3)
     /*@LST(layer, 2)*/
-    W3_PHASE(2, MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3)
+    W2_PAIR(8) W2_PAIR(10) W2_PAIR(12) W2_PAIR(14)
     /*@LST(layer, 3)*/
-    W3_PHASE(3, MB0, MB1, MB2, MB3, MA0, MA1, MA2, MA3)
+    W2_FOLD(Zt0, Zt1)   // phase 1 (b = 0 | 3)
+    // ---- epilogue.  Requested in front of the barrier: the OLD values of this wave's output cells (the residual input;
+    // only this wave ever writes these cells)
+    float4 old0[4], old1[4];
+    float* own0 = act + orow[0] * NF;
+    float* own1 = act + orow[1] * NF;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      old0[q] = ovalid[0] ? *reinterpret_cast<const float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      old1[q] = ovalid[1] ? *reinterpret_cast<const float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // this wave's own share of its outputs, formed while the loads travel: bh 0: Z[b=0] + Z[b=1], bh 1: Z[b=2] + Z[b=3]
+    f32x16 S0, S1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      S0[e] = Zt0[e] + Zs0[e];
+      S1[e] = Zt1[e] + Zs1[e];
+    }
     /*@LST(layer, 4)*/
-    // ---- epilogue: the last phase's fold (nothing left to hide it under), then -- the accumulator sets are dead now
-    // -- the OLD values of this wave's output cells (the residual input; only this wave writes them), requested in
-    // front of the barrier
-#pragma unroll
-    for (int e = 0; e < 16; ++e) W3_FOLD(3, e, MB0, MB1, MB2, MB3)
-    float4 old[2][2][4];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int v = 0; v < 2; ++v)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          old[u][v][q] = *reinterpret_cast<const float4*>(ocell[u][v] + (((g0 + 2 * q) ^ okey[u][v]) << 2));
-    /*@LST(layer, 5)*/
     // every wave has read this layer's input activations (and this wave its old values): the buffer may be overwritten
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    /*@LST(layer, 5)*/
+    {  // the partner's partial sums go into the partner's output cells
+      float* pr0 = act + prow[0] * NF;
+      float* pr1 = act + prow[1] * NF;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (pvalid[0])
+          *reinterpret_cast<float4*>(pr0 + (((g0 + 2 * q) ^ pkey[0]) << 2)) = make_float4(Zs0[4 * q], Zs0[4 * q + 1], Zs0[4 * q + 2], Zs0[4 * q + 3]);
+        if (pvalid[1])
+          *reinterpret_cast<float4*>(pr1 + (((g0 + 2 * q) ^ pkey[1]) << 2)) = make_float4(Zs1[4 * q], Zs1[4 * q + 1], Zs1[4 * q + 2], Zs1[4 * q + 3]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     /*@LST(layer, 6)*/
-    // in place v = v + leaky(conv(v) + bias)  (lib/model.py:85-89; the bias is in Y already); only real cells are written
+    // finish: bh 0: Y = (Z[b=0] + Z[b=1]) + Z[b=2](received);  bh 1: Y = Z[b=1](received) - (Z[b=2] + Z[b=3])  (the bias
+    // came in with Z[b=1]); then in place v = v + leaky(conv(v) + bias)  (lib/model.py:85-89); only real cells are written
+    const float sgn = bh ? -1.f : 1.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-#define W3_FIN(U, V, YY)                                                                                     \
-      if (ovalid[U][V]) {                                                                                    \
-        float4 n_;                                                                                           \
-        n_.x = old[U][V][q].x + leaky(YY[4 * q], slope);                                                     \
-        n_.y = old[U][V][q].y + leaky(YY[4 * q + 1], slope);                                                 \
-        n_.z = old[U][V][q].z + leaky(YY[4 * q + 2], slope);                                                 \
-        n_.w = old[U][V][q].w + leaky(YY[4 * q + 3], slope);                                                 \
-        *reinterpret_cast<float4*>(ocell[U][V] + (((g0 + 2 * q) ^ okey[U][V]) << 2)) = n_;                    \
-      }
-      W3_FIN(0, 0, Y00) W3_FIN(0, 1, Y01) W3_FIN(1, 0, Y10) W3_FIN(1, 1, Y11)
-#undef W3_FIN
+      const float4 r0 = ovalid[0] ? *reinterpret_cast<const float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 r1 = ovalid[1] ? *reinterpret_cast<const float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 n0, n1;
+      n0.x = old0[q].x + leaky(fmaf(sgn, S0[4 * q], r0.x), slope);
+      n0.y = old0[q].y + leaky(fmaf(sgn, S0[4 * q + 1], r0.y), slope);
+      n0.z = old0[q].z + leaky(fmaf(sgn, S0[4 * q + 2], r0.z), slope);
+      n0.w = old0[q].w + leaky(fmaf(sgn, S0[4 * q + 3], r0.w), slope);
+      n1.x = old1[q].x + leaky(fmaf(sgn, S1[4 * q], r1.x), slope);
+      n1.y = old1[q].y + leaky(fmaf(sgn, S1[4 * q + 1], r1.y), slope);
+      n1.z = old1[q].z + leaky(fmaf(sgn, S1[4 * q + 2], r1.z), slope);
+      n1.w = old1[q].w + leaky(fmaf(sgn, S1[4 * q + 3], r1.w), slope);
+      if (ovalid[0]) *reinterpret_cast<float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) = n0;
+      if (ovalid[1]) *reinterpret_cast<float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) = n1;
     }
     // new activations visible to every wave; also the chunk barrier of the next layer's first chunk (this wave's share
     // of its second chunk has arrived, nobody reads this layer's last chunks any more)
@@ -1523,30 +1506,26 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-#undef W3_PHASE
-#undef W3_PAIR
-#undef W3_STEP
-#undef W3_HOOK
-#undef W3_MF
-#undef W3_FOLD
-#undef W3_COMB
-#undef W3_AWAIT
-#undef W3_LOADS
+#undef W2_FOLD
+#undef W2_PAIR
+#undef W2_STEP
+#undef W2_AWAIT
+#undef W2_ALOAD
 }
 
-// One board per workgroup (TB = 1), 256 threads; launch interface, prologue (slot-row map, conv_in on the matrix pipe)
-// and heads of k_net_forward_w, activation rows keyed by akey<true>.
-__global__ __launch_bounds__(NT2) void k_net_forward_w2(NetParams p0, NetParams p1,
-                                                         const float* __restrict__ planes,
-                                                         const int32_t* __restrict__ counts, int which, int row1,
-                                                         float* __restrict__ probs, float* __restrict__ values,
-                                                         unsigned long long* __restrict__ stamps,
-                                                         const int32_t* __restrict__ gpack, int gG, int gB) {
+// One board per workgroup (TB = 1); launch interface, prologue (slot-row map, conv_in on the matrix pipe) and heads of
+// k_net_forward_w, activation rows keyed by akey<true>.
+__global__ __launch_bounds__(NT, 2) void k_net_forward_w2(NetParams p0, NetParams p1,
+                                                            const float* __restrict__ planes,
+                                                            const int32_t* __restrict__ counts, int which, int row1,
+                                                            float* __restrict__ probs, float* __restrict__ values,
+                                                            unsigned long long* __restrict__ stamps,
+                                                            const int32_t* __restrict__ gpack, int gG, int gB) {
   __shared__ __attribute__((aligned(256))) float lds[LDS_FLOATS];  // trunk_w2d XORs granule bits into LDS addresses
   float* act = lds;
   float* wbuf = lds + ACT;
   // slot form: this thread's share of the games' leaf counts is requested beside the launch's totals (tile_rows_pre)
-  const int gcpt = gpack ? (gG + NT2 - 1) / NT2 : 0;
+  const int gcpt = gpack ? (gG + NT - 1) / NT : 0;
   const bool gpre = gpack && gcpt <= GP_PRE;
   int gv[GP_PRE];
 #pragma unroll
@@ -1585,20 +1564,17 @@ __global__ __launch_bounds__(NT2) void k_net_forward_w2(NetParams p0, NetParams 
   // the first two weight chunks are on their way into ring buffers 0 and 1 while conv_in runs; its scratch (the conv_in
   // weights, the row map) sits in buffer 2, which is fetched into only after the trunk's first barrier
   float* win = wbuf + 2 * WCH;
-  // conv_in's weights first ([9][2][64] = 1152 floats = 288 transfers of 16 bytes: every thread one, wave 0 a second)
-  dma_b128(reinterpret_cast<const float4*>(p.w_in) + tid,
-           __builtin_amdgcn_readfirstlane(lds_addr(win) + (unsigned)(tid >> 6) * 1024u));
-  if (tid < 64) dma_b128(reinterpret_cast<const float4*>(p.w_in) + NT2 + tid, __builtin_amdgcn_readfirstlane(lds_addr(win) + 4096u));
-  fetch_chunk_n<NT2>(p.ww2, 0, lds_addr(wbuf), tid);
-  fetch_chunk_n<NT2>(p.ww2, 1, lds_addr(wbuf), tid);
-  for (int k = tid + (R * NF) / 4; k < ACT / 4; k += NT2) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // the wait leaves this thread's 2 chunks x (WCH / 4 / NT2) transfers in flight: conv_in's weights, the oldest, have arrived
-  static_assert(2 * (WCH / 4 / NT2) == 16 && (NT2 + 64) * 4 >= 9 * 2 * NF, "s_waitcnt vmcnt(16) / the w_in transfers below");
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  if (tid < 320) dma_b128(reinterpret_cast<const float4*>(p.w_in) + tid,
+                          __builtin_amdgcn_readfirstlane(lds_addr(win) + (unsigned)(tid >> 6) * 1024u));
+  fetch_chunk(p.ww2, 0, lds_addr(wbuf), tid);
+  fetch_chunk(p.ww2, 1, lds_addr(wbuf), tid);
+  for (int k = tid + (R * NF) / 4; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  static_assert(2 * (WCH / 4 / NT) == 8, "s_waitcnt vmcnt(8) below counts 2 chunks x WCH / 4 / NT transfers per thread");
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // conv_in's weights have arrived; the 2 x 4 chunk transfers may be on their way
   int* smap = reinterpret_cast<int*>(win + 1536);
   if (gpre) tile_rows_pre(gv, gcpt, gmine, gB, second ? 1 : 0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
-  else tile_rows<NT2>(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);
-  conv_in_mfma<true, NT2>(p, planes, smap, act, win, R, tid);
+  else tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);
+  conv_in_mfma<true>(p, planes, smap, act, win, R, tid);
   const int slot_v = tid < nb ? smap[tid] : 0;
   unsigned long long t_trunk0 = 0;
   if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
@@ -1607,7 +1583,7 @@ __global__ __launch_bounds__(NT2) void k_net_forward_w2(NetParams p0, NetParams 
   trunk_w2d(p, act, wbuf, tid);
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
-  heads_f32<false, true, NT2>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
+  heads_f32<false, true>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
     stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
@@ -2222,7 +2198,7 @@ int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats
 }
 
 /* f32w2 mode (large boards): upload the 2-D Winograd F(2x2,3x3) transformed residual weights, already in the LDS image
- * order of trunk_w2d -- [5 layers][8 chunks = b * 2 + granule half][4 a][2 h][64 co][16 floats],
+ * order of trunk_w2d -- [5 layers][8 chunks = phase * 4 + granule pair][2 b of the phase][4 a][2 h][64 co][8 floats],
  * packed by caro_ai_amd/net_hip.py:pack_net_w2 -- from then on the forward calls of this net run k_net_forward_w2.
  * One board per workgroup, its 2x2-output tiles in two 32-row MFMA blocks: boards of 12x12 .. 15x15 cells. */
 int caro_net_winograd2d_size(void) { return cnet::W2NCHUNK * cnet::WCH; }
@@ -2300,7 +2276,7 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
       hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, gpack, G, B);
     else if (n0->p.ww2)
-      hipLaunchKernelGGL(cnet::k_net_forward_w2, dim3(grid), dim3(cnet::NT2), 0, st, n0->p, n1->p, planes_dev,
+      hipLaunchKernelGGL(cnet::k_net_forward_w2, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B);
     else if (n0->p.ww)
       hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,

@@ -80,33 +80,40 @@ def pack_net_w(net: Net) -> np.ndarray:
     return out.reshape(-1)
 
 
+# 2-D Winograd F(2x2,3x3): which transformed column b a (phase, b-half) pair of the kernel processes (trunk_w2d)
+W2_PHASE_B = ((1, 2), (0, 3))  # [phase][bh]
+
+
 def wino2d_weights(w: np.ndarray) -> np.ndarray:
     """U[a][b][co][ci] = sum_{ky,kx} G[a][ky] G[b][kx] w[co][ci][ky][kx], float64"""
     return np.einsum("ak,bl,oikl->aboi", _WINO_G, _WINO_G, w.astype(np.float64))
 
 
 def pack_net_w2(net: Net) -> np.ndarray:
-    """float32[5][8 chunks][4 a][2 h][64 co][16]: the transformed taps of the five residual layers in the LDS image
-    order of k_net_forward_w2 / trunk_w2d.  Chunk c = b * 2 + half holds, for transformed column b and all four a, the
-    channel granules G = 4 half + g (g = 0..3) of both lane halves: channels 32 h + 4 G + 0..3 at 16-byte slot
-    g ^ ((co >> 2) & 3) of row (a, h, co) -- the chunk format of the row form.  float64 transform, rounded once."""
+    """float32[5][8 chunks][2 bh][4 a][2 h][64 co][8]: the transformed taps of the five residual layers in the LDS image
+    order of k_net_forward_w2 / trunk_w2d.  Chunk c = phase * 4 + cq holds, for the two b of the phase (W2_PHASE_B) and
+    all four a, the channel granules G = 2 cq and 2 cq + 1 of both lane halves: channels 32 h + 4 G + 0..3 at 16-byte
+    slot (G & 1) ^ ((co >> 3) & 1) of row (bh, a, h, co).  float64 transform, rounded once."""
     net = net.eval()
-    out = np.zeros((5, 8, 4, 2, 64, 16), np.float32)
+    out = np.zeros((5, 8, 2, 4, 2, 64, 8), np.float32)
     co = np.arange(64)
     for li, blk in enumerate(net.residual_blocks()):
         w, _ = _fold(blk)
-        u = wino2d_weights(w.cpu().numpy()).astype(np.float32)   # [a, b, co, ci]
-        for b in range(4):
-            for half in range(2):
-                for g in range(4):
-                    G = 4 * half + g
-                    slot = g ^ ((co >> 2) & 3)                    # [co]
-                    for h in range(2):
-                        ch = 32 * h + 4 * G
-                        for sl in range(4):
-                            m = slot == sl
-                            # (advanced indices split by a slice: the masked axis comes first)
-                            out[li, b * 2 + half, :, h, m, sl * 4:sl * 4 + 4] = u[:, b, m, ch:ch + 4].transpose(1, 0, 2)
+        u = wino2d_weights(w.cpu().numpy())                    # [a, b, co, ci]
+        for phase in range(2):
+            for bh in range(2):
+                b = W2_PHASE_B[phase][bh]
+                for cq in range(4):
+                    for gi in range(2):
+                        G = 2 * cq + gi
+                        for h in range(2):
+                            ch = 32 * h + 4 * G
+                            blk4 = u[:, b, :, ch:ch + 4].astype(np.float32)  # [a, co, 4]
+                            slot = gi ^ ((co >> 3) & 1)                       # [co]
+                            for a in range(4):
+                                for sl in range(2):
+                                    m = slot == sl
+                                    out[li, phase * 4 + cq, bh, a, h, m, sl * 4:sl * 4 + 4] = blk4[a, m]
     return out.reshape(-1)
 
 
