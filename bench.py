@@ -419,9 +419,12 @@ class Leg:
             # hip3x issues 6 bf16 MFMA flops per algorithmic flop: priced against the dense bf16 peak / 6
             peak = MFMA_F32_PEAK_TFS if args.net != "hip3x" else MFMA_BF16_PEAK_TFS / 6.0
             kname = NET_KERNEL[args.net]
-            # What the matrix pipe EXECUTES per launch.  hipw (row-Winograd F(2,3)): 60 transformed taps x 32 MFMAs x
+            if args.net == "hipw" and self.hipnet.mode == "f32w2":
+                kname = "k_net_forward_w2"  # large boards: the 2-D Winograd form
+            # What the matrix pipe EXECUTES per launch.  hipw, row-Winograd F(2,3): 60 transformed taps x 32 MFMAs x
             # 8 waves x 4096 flop per workgroup of TB boards, tile padding and the last partial tile included -- 2/3 of
-            # the 3x3 multiplies of the direct form.  hip / hip3x: the direct form executes its algorithmic count.
+            # the 3x3 multiplies of the direct form; hipw on large boards, 2-D Winograd F(2x2,3x3): 80 taps x 4 blocks
+            # of 32 MFMAs per board -- 4/9.  hip / hip3x: the direct form executes its algorithmic count.
             executed = None
             if args.net == "hipw":
                 tb = self.hipnet.L.caro_net_boards_per_workgroup(self.hipnet.h)

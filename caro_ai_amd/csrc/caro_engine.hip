@@ -79,16 +79,17 @@ struct View {
   uint64_t* h_key;
   int32_t* h_player;
   double* h_pi;
-  // minibatch scratch
-  int32_t* path_node;
-  int32_t* path_act;
-  int32_t* path_len;
-  int32_t* d_status;
-  float* d_value;
-  int32_t* d_local;
-  int32_t* d_home;      // leaf descents: home slot of the leaf board | bit 31 if that slot was empty when the descent ended
+  // minibatch scratch: what select leaves behind for expand + backup
+  //   d_rec    [G][maxB]        per descent: x = status | path length << 8 | leaf rank << 16 | player to move << 24,
+  //                             y = terminal value (float bits), z = home slot of the leaf board | bit 31 if that slot
+  //                             was empty when the descent ended
+  //   path_rec [G][maxB][maxd]  per level of a descent: x = node slot | action << 24, y / z = the N word (visit count +
+  //                             strong flag) and the W word of the chosen edge AS SELECT SAW THEM.  Nothing touches a
+  //                             tree between a minibatch's descents and its backup, so the backup starts from these
+  //                             values instead of loading the edges again (one dependent memory round less per block)
+  uint4* d_rec;
+  uint4* path_rec;
   uint64_t* d_key;
-  int32_t* d_player;
   int32_t* g_nleaf;
   int32_t* g_off;
   int32_t* g_tree;
@@ -348,12 +349,11 @@ __device__ __forceinline__ void load_row(NodeRow<GEO>& r, const uint64_t* __rest
 
 template <class GEO, bool ROOT>
 __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, int t, const uint64_t* __restrict__ tkeys,
-                                              const uint32_t* __restrict__ tedges, int32_t* __restrict__ pn,
-                                              int32_t* __restrict__ pa, int l, int first, const double* nz,
-                                              NodeRow<GEO>& r) {
+                                              const uint32_t* __restrict__ tedges, uint4* __restrict__ prec, int l,
+                                              int first, const double* nz, NodeRow<GEO>& r) {
   using R = typename GEO::R;
   constexpr int LPD = GEO::LPD, APL = GEO::APL, KW = GEO::KW;
-  if (!ROOT) load_row<GEO, false>(r, tkeys, tedges, home_slot<R>(v, d.cur), l);  // the root's row is loaded by the caller
+  if (!ROOT) load_row<GEO, true>(r, tkeys, tedges, home_slot<R>(v, d.cur), l);  // the root's row is loaded by the caller
   uint32_t(&nraw)[APL] = r.nraw;
   uint32_t(&wraw)[APL] = r.wraw;
   float(&q)[APL] = r.q;
@@ -367,7 +367,7 @@ __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, in
     else if (r.k[0] == EMPTY_KEY) node = -1;
     else {  // collision with another board: walk the probe sequence, then reload the rows
       node = probe_from<R>(v, t, d.cur, (r.slot + 1u) & ((uint32_t)v.hcap - 1u));
-      if (node >= 0) load_row<GEO, ROOT>(r, tkeys, tedges, (uint32_t)node, l);
+      if (node >= 0) load_row<GEO, true>(r, tkeys, tedges, (uint32_t)node, l);
     }
   }
   if (node < 0) {  // not in the tree: this is the leaf (mcts.py:123)
@@ -443,9 +443,17 @@ __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, in
     const uint64_t holders = group_bits<LPD>(__ballot(u == um), first);
     besta = __shfl(ba, __ffsll((unsigned long long)holders) - 1, LPD);
   }
-  if (l == 0) {
-    pn[d.depth] = node;
-    pa[d.depth] = besta;
+  {  // the level's record, written by the lane that holds the chosen edge: node, action, and the edge's N and W words
+    const int ol = besta / APL, oj = besta - ol * APL;
+    if (l == ol) {
+      uint32_t en = nraw[0], ew = wraw[0];
+#pragma unroll
+      for (int j = 1; j < APL; ++j) {
+        en = oj == j ? nraw[j] : en;
+        ew = oj == j ? wraw[j] : ew;
+      }
+      prec[d.depth] = make_uint4((uint32_t)node | ((uint32_t)besta << 24), en, ew, 0u);
+    }
   }
   const bool won = R::template move_group<LPD>(v.gp, d.cur, d.aux, besta, d.player, l, first);  // game.move, mcts.py:138
   d.player ^= 1;
@@ -514,8 +522,7 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
   const int st_sel = v.n_stores == 2 ? player0 : 0;
   const int t = g * v.n_stores + st_sel;
   const int A = v.A;
-  int32_t* pn = v.path_node + ((size_t)g * v.maxB + b) * v.maxd;
-  int32_t* pa = v.path_act + ((size_t)g * v.maxB + b) * v.maxd;
+  uint4* prec = v.path_rec + ((size_t)g * v.maxB + b) * v.maxd;
   const int tsel = st_sel ? gr.tbl[1] : gr.tbl[0];
   const size_t tb = tbase_sel(v, t, tsel);
   const uint64_t* tkeys = v.node_key + tb * KW;
@@ -543,10 +550,10 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
   }
   if (v.dbg) st_noise = __builtin_amdgcn_s_memtime();
 
-  bool live = descend_level<GEO, true>(v, d, t, tkeys, tedges, pn, pa, l, first, nz, r);
+  bool live = descend_level<GEO, true>(v, d, t, tkeys, tedges, prec, l, first, nz, r);
   if (v.dbg) st_root = __builtin_amdgcn_s_memtime();
   while (__any(live)) {
-    if (live) live = descend_level<GEO, false>(v, d, t, tkeys, tedges, pn, pa, l, first, nullptr, r);
+    if (live) live = descend_level<GEO, false>(v, d, t, tkeys, tedges, prec, l, first, nullptr, r);
   }
   if (v.dbg) st_loop = __builtin_amdgcn_s_memtime();
 
@@ -579,12 +586,9 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
     if (v.dbg) maxdep = group_allreduce_i32<64>(d.depth, [](int x, int y) { return x > y ? x : y; });
     if (head) {
       const size_t di = (size_t)g * v.maxB + b;
-      v.d_status[di] = (st == ST_LEAF && dup) ? ST_DROPPED : st;
-      v.d_value[di] = d.value;
-      v.d_local[di] = my_rank;
-      v.d_player[di] = d.player;
-      v.path_len[di] = d.depth;
-      v.d_home[di] = (int32_t)d.home;
+      const uint32_t stw = (uint32_t)((st == ST_LEAF && dup) ? ST_DROPPED : st);
+      v.d_rec[di] = make_uint4(stw | ((uint32_t)d.depth << 8) | ((uint32_t)my_rank << 16) | ((uint32_t)d.player << 24),
+                               __float_as_uint(d.value), d.home, 0u);
       store_board<R>(v.d_key + di * KW, d.cur);
     }
     const int nleaf = __popcll(m_first);
@@ -682,12 +686,10 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
     }
     if (mine) {
       const size_t di = (size_t)g * v.maxB + bb;
-      v.d_status[di] = (st == ST_LEAF && dup) ? ST_DROPPED : st;
-      v.d_value[di] = s_value[bb];
-      v.d_local[di] = __popcll(m_first & ((1ull << bb) - 1ull));
-      v.d_player[di] = s_player[bb];
-      v.path_len[di] = dep;
-      v.d_home[di] = (int32_t)s_dhome[bb];
+      const uint32_t stw = (uint32_t)((st == ST_LEAF && dup) ? ST_DROPPED : st);
+      const uint32_t rank = (uint32_t)__popcll(m_first & ((1ull << bb) - 1ull));
+      v.d_rec[di] = make_uint4(stw | ((uint32_t)dep << 8) | (rank << 16) | ((uint32_t)s_player[bb] << 24),
+                               __float_as_uint(s_value[bb]), s_dhome[bb], 0u);
       store_board<R>(v.d_key + di * KW, key);
       s_first[bb] = first_seen;
     }
@@ -777,10 +779,11 @@ __global__ void k_encode(View v, int B, float* __restrict__ planes, uint64_t* __
   const int HW = v.HW;
   for (int b = 0; b < B; ++b) {
     const size_t di = (size_t)g * v.maxB + b;
-    if (v.d_status[di] != ST_LEAF) continue;
-    const int rowi = off + v.d_local[di];
+    const uint32_t rx = v.d_rec[di].x;
+    if ((int)(rx & 0xFFu) != ST_LEAF) continue;
+    const int rowi = off + (int)((rx >> 16) & 0xFFu);
     const typename R::Board brd = load_board<R>(v.d_key + di * KW);
-    const int who = v.d_player[di];
+    const int who = (int)(rx >> 24);
     float* dst = planes + (size_t)rowi * 2 * HW;
     for (int i = tid; i < 2 * HW; i += blockDim.x) dst[i] = R::plane(v.gp, brd, who, i / HW, i % HW);
     if (leaf_keys && tid < KW) leaf_keys[(size_t)rowi * KW + tid] = v.d_key[di * KW + tid];
@@ -806,20 +809,89 @@ __device__ __forceinline__ void backup_path(const View& v, int t, float value, b
     cur = -cur;
   }
 }
+// the same from the path records of a descent (reads the edges afresh: the sequential fallback of expand_body)
+template <int AP>
+__device__ __forceinline__ void backup_path_rec(const View& v, int t, float value, bool strong_val, const uint4* rec,
+                                                int len) {
+  float cur = -value;
+  for (int i = len - 1; i >= 0; --i) {
+    const uint32_t na = rec[i].x;
+    uint32_t* row = v.edges + (ebase(v, t) + (na & 0xFFFFFFu)) * 4 * AP;
+    const int a = (int)(na >> 24);
+    const uint32_t nraw = row[a];
+    const int n = (int)(nraw & NMASK) + 1;
+    const uint32_t strong = (nraw & NSTRONG) | (strong_val ? NSTRONG : 0u);
+    const float w = __uint_as_float(row[AP + a]) + cur;
+    row[a] = (uint32_t)n | strong;
+    row[AP + a] = __float_as_uint(w);
+    row[2 * AP + a] = __float_as_uint(w / (float)n);
+    cur = -cur;
+  }
+}
+
+// Everything expand_body needs from memory, requested in ONE round of independent loads -- they depend on the game
+// index and the lane only, so the fused kernels issue them at the very top, beside the game's scalars (load_game),
+// and the whole expand + backup of a block costs that one memory round: the descent records (with the home slot of
+// each leaf and whether it was free, as the descent saw it), the leaf boards, the net's value and prior rows of the
+// game's slot rows, and the first 16 levels of every path WITH the N and W words of their edges as select saw them
+// (nothing touches the tree in between), so the backup only WRITES edges.
+template <class GEO>
+struct ExpandPre {
+  static constexpr int NPR = (MAXB * 0 + 64 * GEO::APL + 63) / 64;  // prior values per lane (B x AP <= 64 x APL in the one-wave forms)
+  uint4 rec;                       // lane < B: the descent's record
+  typename GEO::R::Board brd;      // lane < B: its leaf board
+  float row_val;                   // lane < B: values[off + lane]
+  uint4 p0, p1;                    // lane = descent * 8 + level: path records of levels (lane & 7) and 8 + (lane & 7)
+  float pr[NPR];                   // priors of the slot rows: index lane + 64 k over (leaf rank, action)
+  int nleaf;
+};
+template <class GEO, bool ONE>
+__device__ __forceinline__ ExpandPre<GEO> expand_preload(const View& v, int g, int B, int off, const float* __restrict__ probs,
+                                                         const float* __restrict__ values) {
+  using R = typename GEO::R;
+  constexpr int KW = GEO::KW, AP = GEO::AP;
+  ExpandPre<GEO> e;
+  const int lane = threadIdx.x;
+  e.nleaf = v.g_nleaf[g];
+  e.rec = make_uint4(ST_DROPPED, 0u, 0u, 0u);
+  e.row_val = 0.f;
+#pragma unroll
+  for (int w = 0; w < KW; ++w) e.brd.w[w] = 0;
+  if (lane < B) {
+    const size_t di = (size_t)g * v.maxB + lane;
+    e.rec = v.d_rec[di];
+    e.brd = load_board<R>(v.d_key + di * KW);
+    if ((long long)off + lane < (long long)v.G * v.maxB) e.row_val = values[off + lane];  // leaf rows off .. off + nleaf - 1
+  }
+  e.p0 = e.p1 = make_uint4(0u, 0u, 0u, 0u);
+  if (B <= 8 && lane < 64 && (lane >> 3) < B) {
+    const uint4* pr = v.path_rec + ((size_t)g * v.maxB + (lane >> 3)) * v.maxd;
+    if ((lane & 7) < v.maxd) e.p0 = pr[lane & 7];
+    if (8 + (lane & 7) < v.maxd) e.p1 = pr[8 + (lane & 7)];
+  }
+#pragma unroll
+  for (int k = 0; k < ExpandPre<GEO>::NPR; ++k) {
+    e.pr[k] = 0.f;
+    if (ONE) {  // slot rows: leaf rank b of the game sits at row off + b whatever the other games found
+      const int idx = lane + 64 * k, b = idx / AP, a = idx - b * AP;
+      if (idx < B * AP && a < v.A && lane < 64) e.pr[k] = probs[(size_t)(off + b) * v.A + a];
+    }
+  }
+  return e;
+}
 
 // _create_node (mcts.py:178-190) for every unique leaf, then the queued _backup calls (mcts.py:225-246,
 // 286-287).  The reference applies the backups one after another; contributions to DIFFERENT edges commute,
 // contributions to the SAME edge must keep queue order because W is a float32 running sum.  So the queue is
 // flattened into (edge, +-value) entries in reference order (terminals by sim index, then new leaves first
 // seen; inside a path from the leaf upwards), the first entry of every distinct edge becomes its owner and
-// applies all entries of that edge in order, and the owners' read-modify-writes proceed in parallel.
-// The block is latency bound, so the code is laid out as four rounds of independent loads:
-//   1  per descent: status, path length, leaf rank, terminal value, leaf board
-//   2  per leaf: the key in its home slot, its net value;  3  the path entries (and the priors, off the chain)
-//   4  the edges the owners update.
+// applies all entries of that edge in order, and the owners' writes proceed in parallel.
+// Memory: one round of loads (ExpandPre, issued by the caller -- in the fused kernels at the top of the kernel), then
+// only stores: keys and rows of the new nodes, the owners' edges (their old N / W words travel in the path records).
+// Rare cases take extra rounds: a leaf whose home slot is taken (probe sequence), paths deeper than 16 levels.
 template <class GEO, bool ONE = false>
-__device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, int B, const float* __restrict__ probs,
-                                            const float* __restrict__ values) {
+__device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, int B, const ExpandPre<GEO>& pre, int off,
+                                            const float* __restrict__ probs) {
   using R = typename GEO::R;
   using Board = typename R::Board;
   constexpr int AP = GEO::AP, KW = GEO::KW;
@@ -828,6 +900,7 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
   __shared__ short e_act[MAXE];
   __shared__ float e_val[MAXE];
   __shared__ unsigned char e_strong[MAXE];
+  __shared__ uint32_t e_n[MAXE], e_w[MAXE];  // the edge's N and W words as select saw them
   __shared__ int s_total;
   __shared__ uint64_t s_brd[MAXB][KW];
   __shared__ int s_node[MAXB], s_row[MAXB];
@@ -837,6 +910,8 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
   __shared__ float q_val[MAXB];
   __shared__ unsigned char q_strong[MAXB];
   __shared__ int s_nq;
+  __shared__ uint4 s_p0[64], s_p1[64];   // the preloaded path records: [descent * 8 + level], levels 0..7 and 8..15
+  __shared__ float s_rowval[MAXB];
   const int g = blockIdx.x;
   if (gr.done) return;
   const int lane = threadIdx.x;
@@ -847,50 +922,26 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
   // the tree the pending minibatch was selected on: the mover's (the ply comes after the backup)
   const int st_sel = v.n_stores == 2 ? gr.player : 0;
   const int t = g * v.n_stores + st_sel;
-  const int nleaf = v.g_nleaf[g];
-  const int off = ONE ? g * B : v.g_off[g];  // the fused kernels use slot rows: no load in front of the value loads
+  const int nleaf = pre.nleaf;
   const int base = st_sel ? gr.nn[1] : gr.nn[0];
   const bool overflow = base + nleaf > v.cap;
   const int A = v.A;
   const int tsel = st_sel ? gr.tbl[1] : gr.tbl[0];
   const size_t tb = tbase_sel(v, t, tsel);
   const size_t eb = ebase_sel(v, t, tsel);
-  // ---- round 1: everything select left behind, in ONE round of independent loads (they depend on g and the lane
-  // only): the record of descent `lane` -- with the home slot of its leaf and whether that slot was empty, as the
-  // descent saw it --, the net value of every leaf row of the game, and the first 8 levels of every path
-  // (lane = descent * 8 + level; deeper levels are fetched later, by the few entries that need them)
-  int my_st = ST_DROPPED, my_len = 0, my_local = 0;
-  uint32_t my_home = 0u;
-  float my_val = 0.f, row_val = 0.f;
-  Board brd;
-#pragma unroll
-  for (int w = 0; w < KW; ++w) brd.w[w] = 0;
+  const int my_st = (int)(pre.rec.x & 0xFFu), my_len = (int)((pre.rec.x >> 8) & 0xFFu);
+  const int my_local = (int)((pre.rec.x >> 16) & 0xFFu);
+  const uint32_t my_home = pre.rec.z;
+  float my_val = __uint_as_float(pre.rec.y);  // meaningful for terminals
+  const Board& brd = pre.brd;
   const bool pre_paths = B <= 8 && block_threads<ONE>() >= 64;
-  __shared__ int s_pn[64], s_pa[64];
-  int pre_n = 0, pre_a = 0;
-  if (pre_paths && lane < 64 && (lane >> 3) < B && (lane & 7) < v.maxd) {
-    const size_t di = (size_t)g * v.maxB + (lane >> 3);
-    pre_n = v.path_node[di * v.maxd + (lane & 7)];
-    pre_a = v.path_act[di * v.maxd + (lane & 7)];
-  }
-  if (lane < B) {
-    const size_t di = (size_t)g * v.maxB + lane;
-    my_st = v.d_status[di];
-    my_len = v.path_len[di];
-    my_local = v.d_local[di];
-    my_val = v.d_value[di];   // meaningful for terminals
-    my_home = (uint32_t)v.d_home[di];
-    brd = load_board<R>(v.d_key + di * KW);
-    if ((long long)off + lane < (long long)v.G * v.maxB) row_val = values[off + lane];  // leaf rows off .. off + nleaf - 1
-  }
   if (pre_paths && lane < 64) {
-    s_pn[lane] = pre_n;
-    s_pa[lane] = pre_a;
+    s_p0[lane] = pre.p0;
+    s_p1[lane] = pre.p1;
   }
   const bool is_leaf = lane < B && my_st == ST_LEAF && !overflow;
   // the value of this descent's leaf: row off + my_local, held by lane my_local
-  __shared__ float s_rowval[MAXB];
-  if (lane < B) s_rowval[lane] = row_val;
+  if (lane < B) s_rowval[lane] = pre.row_val;
   block_sync<ONE>();
   if (lane < B) {
     s_node[lane] = -2;  // not a leaf
@@ -905,7 +956,7 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
     }
   }
   block_sync<ONE>();
-  CARO_XS(1)  // round 1 has arrived, leaves published
+  CARO_XS(1)  // the preloaded round has arrived, leaves published
   const bool single_wave = ONE || blockDim.x == 64;
   if (!overflow) {
     // _create_node.  The reference inserts the leaves one after another (first-seen order): a leaf whose home slot is
@@ -988,21 +1039,21 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
   block_sync<ONE>();
   CARO_XS(3)  // queue flattened
   const int total = s_total;
-  // ---- round 3: the path entries; next to them (off the dependent chain) the rows of the new nodes
+  // the path entries (levels beyond the preloaded 16 are fetched here, by the few entries that need them)
   if (total <= MAXE)
     for (int j = lane; j < total; j += block_threads<ONE>()) {
       int k = 0;
       while (k + 1 < nq && q_off[k + 1] <= j) ++k;  // queue item of entry j
       const int r = j - q_off[k];                    // r-th entry of that backup, counted from the leaf
       const int i = q_len[k] - 1 - r;
-      const size_t di = (size_t)g * v.maxB + q_b[k];
-      if (pre_paths && i < 8) {  // preloaded in round 1
-        e_node[j] = s_pn[q_b[k] * 8 + i];
-        e_act[j] = (short)s_pa[q_b[k] * 8 + i];
-      } else {
-        e_node[j] = v.path_node[di * v.maxd + i];
-        e_act[j] = (short)v.path_act[di * v.maxd + i];
-      }
+      uint4 rec;
+      if (pre_paths && i < 8) rec = s_p0[q_b[k] * 8 + i];
+      else if (pre_paths && i < 16) rec = s_p1[q_b[k] * 8 + i - 8];
+      else rec = v.path_rec[((size_t)g * v.maxB + q_b[k]) * v.maxd + i];
+      e_node[j] = (int)(rec.x & 0xFFFFFFu);
+      e_act[j] = (short)(rec.x >> 24);
+      e_n[j] = rec.y;
+      e_w[j] = rec.z;
       e_val[j] = (r & 1) ? q_val[k] : -q_val[k];     // cur = -value at the leaf's parent, sign flips each ply (mcts.py:238,246)
       e_strong[j] = q_strong[k];
     }
@@ -1011,24 +1062,39 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
     for (int idx = lane; idx < B * AP; idx += block_threads<ONE>()) {  // lanes over (leaf, action)
       const int b = idx / AP, a = idx - b * AP;
       const int node = s_node[b];
+      // the leaf's prior row.  Slot rows (ONE) were preloaded by (leaf rank, action): the value sits in lane src & 63,
+      // slot src >> 6 -- fetched by EVERY lane (B * AP is a multiple of 64 there: the loop's trip count is uniform and a
+      // shuffle needs its source lane active), used by the lanes of leaves
+      float pv = 0.f;
+      if (ONE) {
+        const int src = node >= 0 ? (s_row[b] - off) * AP + a : lane;
+#pragma unroll
+        for (int k = 0; k < ExpandPre<GEO>::NPR; ++k) {
+          const float x = __shfl(pre.pr[k], src & 63, 64);
+          pv = (src >> 6) == k ? x : pv;
+        }
+      } else if (node >= 0 && a < A) {
+        pv = probs[(size_t)s_row[b] * A + a];
+      }
       if (node < 0) continue;  // not a leaf (a failed insert cannot happen while n_nodes <= cap < hcap)
       uint32_t* row = v.edges + (eb + node) * 4 * AP;
+      if (a >= A) pv = 0.f;
       row[a] = 0u;
       row[AP + a] = 0u;
       row[2 * AP + a] = 0u;
-      row[3 * AP + a] = a < A ? __float_as_uint(probs[(size_t)s_row[b] * A + a]) : 0u;
+      row[3 * AP + a] = __float_as_uint(pv);
     }
   if (total > MAXE) {  // queue does not fit the LDS list: apply sequentially, in order (never at B*depth <= 512)
     if (lane == 0)
       for (int k = 0; k < nq; ++k) {
         const size_t di = (size_t)g * v.maxB + q_b[k];
-        backup_path<AP>(v, t, q_val[k], q_strong[k] != 0, v.path_node + di * v.maxd, v.path_act + di * v.maxd, q_len[k]);
+        backup_path_rec<AP>(v, t, q_val[k], q_strong[k] != 0, v.path_rec + di * v.maxd, q_len[k]);
       }
     return;
   }
   block_sync<ONE>();
   CARO_XS(5)  // rows of the new nodes written
-  // ---- round 4: the owners' read-modify-writes
+  // ---- the owners' writes
   const int n = total;
   if (single_wave && n <= 128) {
     // One wavefront, at most two entries per lane (j0 = lane, j1 = lane + 64).  The entries of one edge are found by
@@ -1055,17 +1121,16 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
       todo0 &= ~m0;
       todo1 &= ~m1;
     }
-    // the owners' rows are requested together, then each owner adds its entries in queue order (ascending index)
+    // every owner starts from the edge's words in its own entry (all entries of an edge carry the same ones) and adds
+    // its entries in queue order (ascending index)
     uint32_t* row0 = own0 ? v.edges + (eb + (key0 >> 8)) * 4 * AP : nullptr;
     uint32_t* row1 = own1 ? v.edges + (eb + (key1 >> 8)) * 4 * AP : nullptr;
     const int a0 = key0 & 0xff, a1 = key1 & 0xff;
-    uint32_t n0 = 0u, n1 = 0u, w0 = 0u, w1 = 0u;
-    if (own0) { n0 = row0[a0]; w0 = row0[AP + a0]; }
-    if (own1) { n1 = row1[a1]; w1 = row1[AP + a1]; }
     if (own0) {
+      const uint32_t n0 = e_n[j0];
       int cnt = (int)(n0 & NMASK);
       uint32_t strong = n0 & NSTRONG;
-      float w = __uint_as_float(w0);
+      float w = __uint_as_float(e_w[j0]);
       for (unsigned long long m = g0m0; m; m &= m - 1ull) {
         const int e = __ffsll(m) - 1;
         cnt += 1;
@@ -1083,9 +1148,10 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
       row0[2 * AP + a0] = __float_as_uint(w / (float)cnt);
     }
     if (own1) {
+      const uint32_t n1 = e_n[j1];
       int cnt = (int)(n1 & NMASK);
       uint32_t strong = n1 & NSTRONG;
-      float w = __uint_as_float(w1);
+      float w = __uint_as_float(e_w[j1]);
       for (unsigned long long m = g1m1; m; m &= m - 1ull) {
         const int e = 64 + __ffsll(m) - 1;
         cnt += 1;
@@ -1103,10 +1169,10 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
     for (int k = 0; k < j; ++k) owner = owner && !(e_node[k] == node && e_act[k] == a);
     if (!owner) continue;
     uint32_t* row = v.edges + (eb + node) * 4 * AP;
-    const uint32_t nraw = row[a];
+    const uint32_t nraw = e_n[j];
     int cnt = (int)(nraw & NMASK);
     uint32_t strong = nraw & NSTRONG;
-    float w = __uint_as_float(row[AP + a]);
+    float w = __uint_as_float(e_w[j]);
     for (int k = j; k < n; ++k) {
       if (e_node[k] == node && e_act[k] == a) {
         cnt += 1;                 // visit_count += 1
@@ -1126,7 +1192,9 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
 template <class GEO>
 __global__ void k_expand_backup(View v, const float* __restrict__ probs, const float* __restrict__ values) {
   GameRegs<GEO> gr = load_game<GEO>(v, blockIdx.x);
-  expand_body<GEO>(v, gr, v.leaf_count[2], probs, values);
+  const int B = v.leaf_count[2], off = v.g_off[blockIdx.x];  // dense rows: the game's first row comes from k_encode
+  const ExpandPre<GEO> pre = expand_preload<GEO, false>(v, blockIdx.x, B, off, probs, values);
+  expand_body<GEO>(v, gr, B, pre, off, probs);
 }
 
 // The block's NOISE WAVE (fused kernels: 128 threads, wave 1): the Dirichlet rows of this minibatch's descents --
@@ -1181,8 +1249,9 @@ __global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ n
   unsigned long long t0 = 0;
   if (v.dbg) t0 = __builtin_amdgcn_s_memtime();
   GameRegs<GEO> gr = load_game<GEO>(v, blockIdx.x);
+  const ExpandPre<GEO> pre = expand_preload<GEO, true>(v, blockIdx.x, B, blockIdx.x * B, probs, values);  // one round with load_game
   if (do_expand) {
-    expand_body<GEO, true>(v, gr, B, probs, values);
+    expand_body<GEO, true>(v, gr, B, pre, blockIdx.x * B, probs);
     block_sync<true>();  // the block's own tree updates are visible to its descents
   }
   const unsigned long long t1 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -1605,6 +1674,10 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
   int lm = v.lm[g];
   const int pend = v.pend[g];
   GameRegs<GEO> gr = load_game<GEO>(v, g);
+  // ... and, in the same round, everything the pending minibatch's expand + backup reads (tree wave; the addresses depend
+  // on g and the lane only, so the loads are issued whether or not a minibatch is pending)
+  ExpandPre<GEO> pre;
+  if (threadIdx.x < 64) pre = expand_preload<GEO, true>(v, g, B, g * B, probs, values);
   __syncthreads();  // also: the flag is clear before the noise wave can set it
   if (threadIdx.x >= 64) {
     // the noise wave: rows of the minibatch the tree wave is about to select.  A game whose ply is due moves first:
@@ -1645,7 +1718,7 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
     return;
   }
   if (pend) {
-    expand_body<GEO, true>(v, gr, B, probs, values);
+    expand_body<GEO, true>(v, gr, B, pre, g * B, probs);
     block_sync<true>();  // the block's own tree updates are visible to what follows
   }
   const unsigned long long t1 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -1932,20 +2005,21 @@ __global__ void k_get_descent(View v, int game, int b, int32_t* info, float* val
                               uint64_t* path_keys, int32_t* path_actions) {
   constexpr int KW = GEO::KW;
   const size_t di = (size_t)game * v.maxB + b;
-  const int len = v.path_len[di];
+  const uint4 rec = v.d_rec[di];
+  const int len = (int)((rec.x >> 8) & 0xFFu);
   const int t = v.g_tree[game];
   if (threadIdx.x == 0) {
-    info[0] = v.d_status[di];
+    info[0] = (int)(rec.x & 0xFFu);
     info[1] = len;
-    info[2] = v.d_player[di];
-    info[3] = v.d_local[di];
-    *value = v.d_value[di];
+    info[2] = (int)(rec.x >> 24);
+    info[3] = (int)((rec.x >> 16) & 0xFFu);
+    *value = __uint_as_float(rec.y);
     for (int w = 0; w < KW; ++w) leaf_key[w] = v.d_key[di * KW + w];
   }
   for (int i = threadIdx.x; i < len; i += blockDim.x) {
-    const int node = v.path_node[di * v.maxd + i];
-    path_actions[i] = v.path_act[di * v.maxd + i];
-    for (int w = 0; w < KW; ++w) path_keys[(size_t)i * KW + w] = v.node_key[(tbase(v, t) + node) * KW + w];
+    const uint32_t na = v.path_rec[di * v.maxd + i].x;
+    path_actions[i] = (int)(na >> 24);
+    for (int w = 0; w < KW; ++w) path_keys[(size_t)i * KW + w] = v.node_key[(tbase(v, t) + (na & 0xFFFFFFu)) * KW + w];
   }
 }
 
@@ -2250,10 +2324,8 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   DA(v.h_key, G * v.maxply * KW);
   DA(v.h_player, G * v.maxply);
   DA(v.h_pi, G * v.maxply * v.A);
-  DA(v.path_node, G * v.maxB * v.maxd);
-  DA(v.path_act, G * v.maxB * v.maxd);
-  DA(v.path_len, G * v.maxB);
-  DA(v.d_status, G * v.maxB); DA(v.d_value, G * v.maxB); DA(v.d_local, G * v.maxB); DA(v.d_home, G * v.maxB); DA(v.d_player, G * v.maxB);
+  DA(v.path_rec, G * v.maxB * v.maxd);
+  DA(v.d_rec, G * v.maxB);
   DA(v.d_key, G * v.maxB * KW);
   DA(v.g_nleaf, G); DA(v.g_off, G); DA(v.g_tree, G); DA(v.g_class, G); DA(v.g_pack, G);
   DA(v.leaf_count, 4);
