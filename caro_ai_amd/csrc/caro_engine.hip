@@ -619,6 +619,11 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
       // player to move come from the first lane of the leaf's group
       const int HW = v.HW;
       int local = 0;
+      // what a lane's elements of a plane row are (plane, cell) does not depend on the leaf: formed once.  (Per leaf
+      // and element the index arithmetic -- two divisions by a run-time HW -- cost a block with 5..8 leaves 5-10 k cycles.)
+      typename R::PlaneAt pat[R::PLANE_ITEMS];
+#pragma unroll
+      for (int k = 0; k < R::PLANE_ITEMS; ++k) pat[k] = R::plane_at(v.gp, tid + 64 * k < 2 * HW ? tid + 64 * k : 0);
       for (unsigned long long m = m_first; m; m &= m - 1ull) {
         const int src = __ffsll(m) - 1;
         Board brd;
@@ -631,7 +636,9 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
         const int who = __builtin_amdgcn_readlane(d.player, src);
         const int rowi = g * B + local++;
         float* dst = planes + (size_t)rowi * 2 * HW;
-        for (int i = tid; i < 2 * HW; i += 64) dst[i] = R::plane(v.gp, brd, who, i / HW, i % HW);
+#pragma unroll
+        for (int k = 0; k < R::PLANE_ITEMS; ++k)
+          if (tid + 64 * k < 2 * HW) dst[tid + 64 * k] = R::plane_val(brd, who, pat[k]);
         if (leaf_keys && tid < KW) {
           uint64_t kw = brd.w[0];
 #pragma unroll

@@ -154,6 +154,20 @@ struct C4Rules {
   }
 #endif
 
+  // the same in two steps for a loop over many boards: what depends on the element index alone (plane, the cell's
+  // bit, its column's counter, its row) is formed once, the per-board part is a handful of shifts
+  static constexpr int PLANE_ITEMS = 2;  // ceil(2 * HW / 64): elements a lane of a 64-lane wave writes per board
+  struct PlaneAt { int p, bit, cshift, r; };
+  static CR_HD PlaneAt plane_at(const GameParams&, int idx) {
+    const int p = idx / 42, i = idx - p * 42, row_idx = i / 7, c = i - row_idx * 7, r = 5 - row_idx;
+    return PlaneAt{p, 62 - (6 * c + r), 3 * (6 - c), r};
+  }
+  static CR_HD float plane_val(const Board& b, int who_move, const PlaneAt& at) {
+    const uint64_t s = b.w[0];
+    const int h = 6 - (int)((s >> at.cshift) & 7ULL);
+    const int mine = (int)((s >> at.bit) & 1ULL) == who_move;
+    return (at.r < h && (at.p == 0 ? mine : !mine)) ? 1.0f : 0.0f;
+  }
   // value (0/1) of plane `p` at flat index i = row_idx*7 + c: connect_four.py:175-204
   static CR_HD float plane(const GameParams&, const Board& b, int who_move, int p, int i) {
     const int row_idx = i / 7, c = i % 7;
@@ -288,6 +302,16 @@ struct MnkRules {
   // tictactoe.py:164-176: plane 0 = who_move's tokens, plane 1 = the other token; no row flip
   static CR_HD float plane(const GameParams&, const Board& b, int who_move, int p, int i) {
     return bit(b, p == 0 ? who_move : 1 - who_move, i) ? 1.0f : 0.0f;
+  }
+  // (two-step form, as C4Rules)
+  static constexpr int PLANE_ITEMS = 2 * W64;  // 2 * HW <= 2 * 64 * W64 elements over 64 lanes
+  struct PlaneAt { int p, i; };
+  static CR_HD PlaneAt plane_at(const GameParams& gp, int idx) {
+    const int hw = gp.rows * gp.cols, p = idx / hw;
+    return PlaneAt{p, idx - p * hw};
+  }
+  static CR_HD float plane_val(const Board& b, int who_move, const PlaneAt& at) {
+    return bit(b, at.p == 0 ? who_move : 1 - who_move, at.i) ? 1.0f : 0.0f;
   }
   static CR_HD bool contains(const GameParams&, const Board& node, const Board& root) {
     bool ok = true;
