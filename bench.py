@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
 MFMA_BF16_PEAK_TFS = 2500.0 # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
-PMC_FILE = os.path.join("profiles", "pmc_r03.json")
+PMC_FILE = os.path.join("profiles", "pmc_r04.json")
 CPU_RATIO_FILE = os.path.join("profiles", "cpu_ratio_r03.json")
 NET_KERNEL = {"hip": "k_net_forward", "hipw": "k_net_forward_w", "hip3x": "k_net_forward_3x"}
 
@@ -65,7 +65,7 @@ def host_cores():
 
 def load_pmc(section=None):
     """HBM bytes per launch and MFMA-busy fraction from the committed PMC passes (separate rocprofv3 --pmc runs of
-    this command, tools/profile_r03.sh), by kernel; section = None (headline) | "config5" | "config4" """
+    this command, tools/profile_r04.sh), by kernel; section = None (headline) | "config5" | "config4" """
     try:
         d = json.load(open(os.path.join(ROOT, PMC_FILE)))
         d = d[section] if section else d
@@ -390,7 +390,7 @@ class Leg:
         # FLOPs of one leaf through lib/model.py Net (2 x MAC): conv_in, 5 residual 3x3 convs, 1x1 heads, FC heads
         flops_per_leaf = 2.0 * (HW * 64 * 18 + 5 * HW * 64 * 576 + HW * 3 * 64 + 20 * HW + 20 + 2 * HW * A)
         traffic_note = ("HBM bytes per launch from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                        "configuration, tools/profile_r03.sh, corrected as MI355X_MICROARCH.md prescribes: read side "
+                        "configuration, tools/profile_r04.sh, corrected as MI355X_MICROARCH.md prescribes: read side "
                         "x2); not measured in this run" % PMC_FILE)
         kernel_us = 0.0
         roofline = roofline_tree = None
