@@ -37,6 +37,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/caro_hip.h"
@@ -406,14 +407,29 @@ __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, in
         besta = a;
       }
     }
+    // np.argmax: first maximum (mcts.py:136) -- an all-reduce of (score, action) under "greater score, then lower action",
+    // which is commutative and associative: the quad / mirror steps of group_allreduce_i32 serve (DPP moves of the three
+    // words instead of nine trips through the LDS crossbar), the wider steps stay shuffles
+    {
+      auto step = [&](double ob, int oa) {
+        if (ob > best || (ob == best && oa < besta)) {
+          best = ob;
+          besta = oa;
+        }
+      };
+      auto dpp64 = [&](auto ctrl_tag) {
+        constexpr int CTRL = decltype(ctrl_tag)::value;
+        const long long bits = __double_as_longlong(best);
+        const int lo = dpp_i32<CTRL>((int)(uint32_t)bits), hi = dpp_i32<CTRL>((int)(uint32_t)((unsigned long long)bits >> 32));
+        const int oa = dpp_i32<CTRL>(besta);
+        step(__longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo)), oa);
+      };
+      if constexpr (LPD >= 2) dpp64(std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+      if constexpr (LPD >= 4) dpp64(std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+      if constexpr (LPD >= 8) dpp64(std::integral_constant<int, 0x141>{});   // row_half_mirror
+      if constexpr (LPD >= 16) dpp64(std::integral_constant<int, 0x140>{});  // row_mirror
 #pragma unroll
-    for (int m = 1; m < LPD; m <<= 1) {  // np.argmax: first maximum (mcts.py:136)
-      const double ob = __shfl_xor(best, m, LPD);
-      const int oa = __shfl_xor(besta, m, LPD);
-      if (ob > best || (ob == best && oa < besta)) {
-        best = ob;
-        besta = oa;
-      }
+      for (int m = 16; m < LPD; m <<= 1) step(__shfl_xor(best, m, LPD), __shfl_xor(besta, m, LPD));
     }
   } else {
     // Q + ((c * P) * sqrt(sum N)) / (1 + N) in float32, no contraction (mcts.py:79-84 under numpy >= 2).
@@ -441,7 +457,9 @@ __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, in
     const uint32_t u = orderable(bs + 0.0f);
     const uint32_t um = group_max_u32<LPD>(u);
     const uint64_t holders = group_bits<LPD>(__ballot(u == um), first);
-    besta = __shfl(ba, __ffsll((unsigned long long)holders) - 1, LPD);
+    // (one action per lane: the first holder's lane index IS its action -- no trip through the LDS crossbar)
+    if constexpr (APL == 1) besta = __ffsll((unsigned long long)holders) - 1;
+    else besta = __shfl(ba, __ffsll((unsigned long long)holders) - 1, LPD);
   }
   {  // the level's record, written by the lane that holds the chosen edge: node, action, and the edge's N and W words
     const int ol = besta / APL, oj = besta - ol * APL;
