@@ -43,8 +43,10 @@ def build(n):
     obj = os.path.join(OUT, "caro_net_exp%d.o" % n)
     subprocess.check_call([HIPCC] + FLAGS + ["-DCARO_EXP=%d" % n, "-I", HERE, "-I", CSRC, "-c", src, "-o", obj])
     eng = os.path.join(CSRC, "caro_engine.hip.o")
-    if not os.path.exists(eng):
-        subprocess.check_call([sys.executable, "-m", "caro_ai_amd.build"], cwd=ROOT)
+    if not os.path.exists(eng):  # the object does not travel to the GPU box (.gpurunignore): compile it here, as build.py does
+        eng = os.path.join(OUT, "caro_engine.hip.o")
+        if not os.path.exists(eng):
+            subprocess.check_call([HIPCC] + FLAGS + ["-ffp-contract=off", "-c", os.path.join(CSRC, "caro_engine.hip"), "-o", eng])
     so = os.path.join(OUT, "libcaro_exp%d.so" % n)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", eng, obj, "-o", so])
     return so
