@@ -271,3 +271,31 @@ def test_debug_stamps_leave_the_outputs_alone(rows):
     assert len(wg) >= (rows + 5) // 6            # every workgroup with boards left its stamps
     assert (wg[:, 3] > wg[:, 2]).all() and (wg[:, 0] > wg[:, 3]).all()   # trunk start < trunk end < total
     hn.close()
+
+
+def test_winograd_2d_c_abi_refuses_what_it_cannot_do():
+    """caro_net_enable_winograd2d: boards outside one-board-per-workgroup x 8 x 8 tiles, a wrong image size, a net already
+    in another arithmetic mode -> CARO_E_INVAL / CARO_E_STATE with a message, never a launch"""
+    import numpy as np
+    from caro_ai_amd import _lib
+    from caro_ai_amd.net_hip import HipNet, pack_net_w2
+    L = _lib.load()
+    assert L.caro_net_winograd2d_supported(15, 15) and L.caro_net_winograd2d_supported(12, 12)
+    assert not L.caro_net_winograd2d_supported(6, 7) and not L.caro_net_winograd2d_supported(11, 11)
+    small = _net((2, 6, 7), 7, "best_026_12000.dat")
+    with pytest.raises(_lib.CaroError, match="-22"):
+        HipNet(small, "cuda:0", mode="f32w2")
+    big = _net((2, 15, 15), 225, None)
+    hn = HipNet(big, "cuda:0", mode="f32")
+    w2 = pack_net_w2(big)
+    assert L.caro_net_enable_winograd2d(hn.h, w2.ctypes.data, w2.size - 1) == -22   # wrong size
+    assert L.caro_net_enable_winograd2d(hn.h, w2.ctypes.data, w2.size) == 0
+    assert L.caro_net_enable_winograd2d(hn.h, None, w2.size) == -22
+    hw = HipNet(big, "cuda:0", mode="f32w1")
+    assert L.caro_net_enable_winograd2d(hw.h, w2.ctypes.data, w2.size) == -71           # already the row form
+    x = _boards(3, (2, 15, 15), 5).to("cuda:0")
+    p2, _ = hn(x)
+    p1, _ = hw(x)
+    torch.cuda.synchronize()
+    assert (p1 - p2).abs().max().item() < 1e-5 and not np.array_equal(p1.cpu().numpy(), np.zeros_like(p1.cpu().numpy()))
+    hn.close(); hw.close()

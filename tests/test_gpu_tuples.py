@@ -222,3 +222,33 @@ def test_same_seed_same_bits_at_1024_games(inference, stagger):
     assert ca["expansions"] / (passes * 25) > 1536 * (0.85 if stagger else 0.9)
     for x, y in zip(a, b):
         assert x == y
+
+
+def test_same_seed_same_bits_15x15_conv_net_in_the_engine():
+    """config 4's launches (2-D Winograd net kernel on slot... dense rows of the step-wise tree kernels, eviction on) are
+    deterministic: two runs of 64 games x 3 moves at 50 x 8 give the same root rows, pi and counters bit for bit"""
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.lib.model import Net
+    game = TicTacToe(15, 5)
+    torch.manual_seed(0)
+    net = Net(game.obs_shape, game.action_space).to(DEV).eval()
+
+    def run():
+        eng = SelfPlayEngine(game, 64, net1=net, max_batch=8, seed=5, device=DEV, searches_hint=50, node_cap=4096,
+                             evict=True, inference="hipw")
+        assert eng.evaluators[0].mode == "f32w2"
+        out = []
+        for _ in range(3):
+            eng.search(50, 8)
+            pi, counts = eng.policy()
+            out.append((pi.cpu().numpy().tobytes(), counts.cpu().numpy().tobytes()))
+            eng.step()
+        c = eng.counters()
+        eng.close()
+        return out, c
+
+    a, ca = run()
+    b, cb = run()
+    assert ca == cb and ca["overflows"] == 0 and ca["expansions"] > 0.8 * ca["sims"]
+    assert a == b
