@@ -709,14 +709,6 @@ __device__ __forceinline__ void fetch_chunk(const float* ww, int c, unsigned wri
   for (int m = 0; m < WCH / 4 / NT; ++m) dma_b128(src + m * NT, dst + m * NT * 16);
 }
 
-// chunk c of a weight image -> ring buffer `buf` (the 2-D Winograd trunk keeps its own ring order)
-__device__ __forceinline__ void fetch_chunk_to(const float* ww, int c, int buf, unsigned wring, int tid) {
-  const float4* src = reinterpret_cast<const float4*>(ww + (size_t)c * WCH) + tid;
-  const unsigned dst = __builtin_amdgcn_readfirstlane(wring + (unsigned)buf * (WCH * 4) + (unsigned)(tid >> 6) * 1024u);
-#pragma unroll
-  for (int m = 0; m < WCH / 4 / NT; ++m) dma_b128(src + m * NT, dst + m * NT * 16);
-}
-
 // the head parameters (heads_f32<true>) -> ring buffer 0 + HEAD_STAGE_AT, issued when that buffer has seen its last
 // chunk; over-reads up to 8 KiB past the block (the packed buffer is padded by a whole tap chunk)
 __device__ __forceinline__ void fetch_heads(const float* hp, int hspan, unsigned wring, int tid) {
@@ -1283,9 +1275,9 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w(NetParams p0, NetParams
 //     phase 1  b = 0 | 3:  K loop, then the same fold
 // and FINISHES output column v = bh of its tiles:  Y[u][0] = Z[u][b=0] + Z[u][1] + Z[u][2]  (bh = 0; Z[u][2] comes from
 // the partner wave), Y[u][1] = Z[u][1] - Z[u][2] - Z[u][3]  (bh = 1; Z[u][1] from the partner).  What a wave hands to its
-// partner is exactly its phase-0 fold.  The exchange needs no extra LDS: it goes through the two ring buffers the layer's
-// chunks 5 and 6 have left (the next layer's first two chunks are fetched behind the epilogue's barriers instead of
-// during the last sets), written with no barrier in front; the "inputs read" barrier publishes it (two barriers per layer).
+// partner is exactly its phase-0 fold.  The exchange needs no extra LDS: after the "inputs read" barrier the activation
+// buffer is dead, so the partner's partial sums are written INTO THE PARTNER'S OUTPUT CELLS, read back from there behind
+// a second barrier and overwritten with the finished activations (three barriers per layer).
 // Operand stream per (b, channel granule): 8 cell reads (4 tile rows x the 2 columns b combines) + 4 weight granules
 // -> column combine, row transform (as the row form: V0 = c0-c2, V1 = c1+c2, V2 = c2-c1, V3 = c1-c3) -> 16 MFMAs.
 // Weight chunk = 32 KiB = [2 b of the phase][4 a][2 h][64 co][2 channel granules]: 8 chunks per layer (4 per phase)
@@ -1335,18 +1327,21 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
   // index XORed with (co >> 3) & 1 (lanes i and i ^ 8.. of a read group then sit on different slots)
   const unsigned wlane = wring + (unsigned)(bh * 16384 + (h * 64 + ct * 32 + i) * 32 + (((i >> 3) & 1) << 4));
   // output side (weights are the first MFMA operand: a lane's 16 accumulator registers are 4 groups q of 4 consecutive
-  // channels ct*32 + 8q + 4h + 0..3 of ITS tile): this wave finishes cells (2ty + u, 2tx + bh), its partner (wave ^ 4) the
+  // channels ct*32 + 8q + 4h + 0..3 of ITS tile): this wave finishes cells (2ty + u, 2tx + bh), its partner the
   // cells (2ty + u, 2tx + 1 - bh)
-  const int xo = 2 * tx + bh;
+  const int xo = 2 * tx + bh, xp = 2 * tx + 1 - bh;
   const int g0 = ct * 8 + h;  // granule of channel group q is g0 + 2q
-  int orow[2], okey[2];
-  bool ovalid[2];
+  int orow[2], prow[2], okey[2], pkey[2];
+  bool ovalid[2], pvalid[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int y = 2 * ty + u;
     ovalid[u] = tvalid && y < H && xo < W;
+    pvalid[u] = tvalid && y < H && xp < W;
     orow[u] = y * W + xo;
+    prow[u] = y * W + xp;
     okey[u] = (((xo + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
+    pkey[u] = (((xp + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
   }
 
   f4v CA0, CA1, CA2, CA3, CB0, CB1, CB2, CB3;  // the 4 x 2 input cells of the operand set in flight
@@ -1386,9 +1381,7 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
       /*@CHUNK_BARRIER*/ __syncthreads();                                                                    \
     }                                                                                                        \
-    /* chunks 2..7 of the layer are fetched two chunks ahead; the buffers chunks 5 and 6 leave stay FREE: they carry \
-       the partner exchange of the epilogue, and the next layer's first two chunks are fetched from there */          \
-    if (/*@FETCH_ON*/ (T) / 2 + 2 < 8) fetch_chunk_to(p.ww2, c0 + (T) / 2 + 2, (base + (T) / 2 + 2) % WNBUF, wring, tid); \
+    if (/*@FETCH_ON*/ c0 + (T) / 2 + 2 < W2NCHUNK) fetch_chunk(p.ww2, c0 + (T) / 2 + 2, wring, tid);         \
   }                                                                                                          \
   {                                                                                                          \
     const float sg_ = ((T) >> 3) ? sg1 : sg0;                                                                \
@@ -1434,12 +1427,10 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
   }
 
   for (int layer = 0; layer < NRES; ++layer) {
-    // chunk k of the layer sits in ring buffer (base + k) % WNBUF.  The ring skips one position per layer (8 chunks, but
-    // the next layer's chunk 0 goes where chunk 7 was: see the epilogue), so base = 7 * layer % 3 = layer % 3
-    const int c0 = layer * 8, base = layer % WNBUF;
+    const int c0 = layer * 8;  // first chunk of the layer; chunk c0 + k sits in ring buffer (c0 + k) % WNBUF
     unsigned rbuf[WNBUF];
 #pragma unroll
-    for (int k = 0; k < WNBUF; ++k) rbuf[k] = (unsigned)((base + k) % WNBUF) * (WCH * 4);
+    for (int k = 0; k < WNBUF; ++k) rbuf[k] = (unsigned)((c0 + k) % WNBUF) * (WCH * 4);
     const f32x16 zero16 = {};
     f32x16 accM0, accM1, accM2, accM3, Zs0, Zs1, Zt0, Zt1;
     // (the per-set addresses are re-formed in every layer: hoisted out of the layer loop they would take 128 registers)
@@ -1487,33 +1478,33 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
       S1[e] = Zt1[e] + Zs1[e];
     }
     /*@LST(layer, 4)*/
-    // The partner's partial sums travel through the ring buffers that chunks 5 and 6 of this layer have left (nobody
-    // reads them since the chunk barriers of sets 12 and 14, and nothing was fetched into them): written here, with no
-    // barrier in front, while slower waves finish their main loop.  Wave w's area: buffer of chunk 5 (w < 4) or 6,
-    // 8 KiB each, [u][q][lane] float4.
-    float* xmine = wbuf + ((base + 5 + (wave >> 2)) % WNBUF) * WCH + (wave & 3) * 2048 + lane * 4;
-    const float* xpart = wbuf + ((base + 5 + ((wave >> 2) ^ 1)) % WNBUF) * WCH + (wave & 3) * 2048 + lane * 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      *reinterpret_cast<float4*>(xmine + q * 256) = make_float4(Zs0[4 * q], Zs0[4 * q + 1], Zs0[4 * q + 2], Zs0[4 * q + 3]);
-      *reinterpret_cast<float4*>(xmine + 1024 + q * 256) = make_float4(Zs1[4 * q], Zs1[4 * q + 1], Zs1[4 * q + 2], Zs1[4 * q + 3]);
-    }
-    // every wave has read this layer's input activations (and this wave its old values), and the exchange is written:
-    // ONE barrier publishes both
+    // every wave has read this layer's input activations (and this wave its old values): the buffer may be overwritten
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     /*@LST(layer, 5)*/
-    // chunk 7's buffer is free now: the next layer's chunk 0 goes there (it arrives under the finish below)
-    if (layer + 1 < NRES) fetch_chunk_to(p.ww2, c0 + 8, (base + 7) % WNBUF, wring, tid);
+    {  // the partner's partial sums go into the partner's output cells
+      float* pr0 = act + prow[0] * NF;
+      float* pr1 = act + prow[1] * NF;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (pvalid[0])
+          *reinterpret_cast<float4*>(pr0 + (((g0 + 2 * q) ^ pkey[0]) << 2)) = make_float4(Zs0[4 * q], Zs0[4 * q + 1], Zs0[4 * q + 2], Zs0[4 * q + 3]);
+        if (pvalid[1])
+          *reinterpret_cast<float4*>(pr1 + (((g0 + 2 * q) ^ pkey[1]) << 2)) = make_float4(Zs1[4 * q], Zs1[4 * q + 1], Zs1[4 * q + 2], Zs1[4 * q + 3]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     /*@LST(layer, 6)*/
     // finish: bh 0: Y = (Z[b=0] + Z[b=1]) + Z[b=2](received);  bh 1: Y = Z[b=1](received) - (Z[b=2] + Z[b=3])  (the bias
     // came in with Z[b=1]); then in place v = v + leaky(conv(v) + bias)  (lib/model.py:85-89); only real cells are written
     const float sgn = bh ? -1.f : 1.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 r0 = *reinterpret_cast<const float4*>(xpart + q * 256);
-      const float4 r1 = *reinterpret_cast<const float4*>(xpart + 1024 + q * 256);
+      const float4 r0 = ovalid[0] ? *reinterpret_cast<const float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 r1 = ovalid[1] ? *reinterpret_cast<const float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 n0, n1;
       n0.x = old0[q].x + leaky(fmaf(sgn, S0[4 * q], r0.x), slope);
       n0.y = old0[q].y + leaky(fmaf(sgn, S0[4 * q + 1], r0.y), slope);
@@ -1526,12 +1517,11 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
       if (ovalid[0]) *reinterpret_cast<float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) = n0;
       if (ovalid[1]) *reinterpret_cast<float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) = n1;
     }
-    // new activations visible to every wave, the next layer's chunk 0 has arrived, the exchange has been read: its
-    // buffers take the next layer's chunks 1 (here) and 2 (at the layer's first set)
+    // new activations visible to every wave; also the chunk barrier of the next layer's first chunk (this wave's share
+    // of its second chunk has arrived, nobody reads this layer's last chunks any more)
     /*@LST(layer, 7)*/
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (layer + 1 < NRES) fetch_chunk_to(p.ww2, c0 + 9, (base + 8) % WNBUF, wring, tid);
   }
 #undef W2_FOLD
 #undef W2_PAIR

@@ -11,8 +11,8 @@ L.caro_exp_read_lst.argtypes = [C.c_void_p]
 torch.manual_seed(0)
 net = Net((2, 15, 15), 225).eval()
 hn = HipNet(net, "cuda:0", mode=(sys.argv[1] if len(sys.argv) > 1 else "f32w2"))
-names = ["phase 0 main loop", "fold (+ bias)", "phase 1 main loop", "fold + own share + old-value requests",
-         "exchange write + barrier (inputs read)", "next layer's chunk 0 requested", "partner read + finish + write"]
+names = ["phase 0 main loop", "fold + zero", "phase 1 main loop", "fold + old/bias requests", "barrier A (inputs read)",
+         "exchange write + barrier B", "finish + write"]
 rows = 7600
 x = (torch.rand((rows, 2, 15, 15), device="cuda") < 0.3).float()
 counts = torch.tensor([rows, 0], dtype=torch.int32, device="cuda")
