@@ -23,11 +23,10 @@
 // the node store: open addressing with linear probing over hcap = 2^k >= 2*cap slots, node id = slot,
 // so one descent level costs ONE memory latency (key and action rows of the home slot load together).
 //   node_key u64 [T][hcap][KW]      board of the node in the slot (the key); word 0 == ~0 marks an empty slot
-//   edges    u32 [T][hcap][4][AP]   per node four action rows N | W | Q | P,
-//                                   adjacent in memory (connect four: one
-//                                   128-byte line per node); N carries the
-//                                   "strong" flag in bit 30 (W has absorbed a
-//                                   float32 value).
+//   edges    u32x4 [T][hcap][AP]    per node and action one 16-byte record {N, W, Q, P} (array of structs, round 4: a lane
+//                                   loads its action with ONE 16-byte load and an edge update dirties one cache line;
+//                                   connect four: 128 bytes per node); N carries the "strong" flag in bit 30 (W has
+//                                   absorbed a float32 value).
 // Arithmetic: non-root PUCT in float32, root PUCT in float64, no FMA
 // contraction (compiled with -ffp-contract=off), exactly the order of
 // lib/mcts.py:79-84 under numpy>=2 scalar promotion.
@@ -333,15 +332,15 @@ template <class GEO, bool WITH_W>
 __device__ __forceinline__ void load_row(NodeRow<GEO>& r, const uint64_t* __restrict__ tkeys,
                                          const uint32_t* __restrict__ tedges, uint32_t slot, int l) {
   constexpr int APL = GEO::APL, AP = GEO::AP, KW = GEO::KW;
-  const uint32_t* row = tedges + (size_t)slot * 4 * AP;
+  const uint4* row = reinterpret_cast<const uint4*>(tedges + (size_t)slot * 4 * AP);
   r.slot = slot;
 #pragma unroll
   for (int j = 0; j < APL; ++j) {
-    const int a = l * APL + j;
-    r.nraw[j] = row[a];
-    r.wraw[j] = WITH_W ? row[AP + a] : 0u;
-    r.q[j] = __uint_as_float(row[2 * AP + a]);
-    r.p[j] = __uint_as_float(row[3 * AP + a]);
+    const uint4 e = row[l * APL + j];  // {N, W, Q, P} of the lane's action: one 16-byte load
+    r.nraw[j] = e.x;
+    r.wraw[j] = e.y;
+    r.q[j] = __uint_as_float(e.z);
+    r.p[j] = __uint_as_float(e.w);
   }
   const uint64_t* k = tkeys + (size_t)slot * KW;
 #pragma unroll
@@ -823,14 +822,14 @@ __device__ __forceinline__ void backup_path(const View& v, int t, float value, b
   for (int i = len - 1; i >= 0; --i) {
     uint32_t* row = v.edges + (ebase(v, t) + pn[i]) * 4 * AP;
     const int a = pa[i];
-    const uint32_t nraw = row[a];
+    const uint32_t nraw = row[4 * a];
     const int n = (int)(nraw & NMASK) + 1;
     const uint32_t strong = (nraw & NSTRONG) | (strong_val ? NSTRONG : 0u);
-    const float w = __uint_as_float(row[AP + a]) + cur;
+    const float w = __uint_as_float(row[4 * a + 1]) + cur;
     const float q = w / (float)n;
-    row[a] = (uint32_t)n | strong;
-    row[AP + a] = __float_as_uint(w);
-    row[2 * AP + a] = __float_as_uint(q);
+    row[4 * a] = (uint32_t)n | strong;
+    row[4 * a + 1] = __float_as_uint(w);
+    row[4 * a + 2] = __float_as_uint(q);
     cur = -cur;
   }
 }
@@ -843,13 +842,13 @@ __device__ __forceinline__ void backup_path_rec(const View& v, int t, float valu
     const uint32_t na = rec[i].x;
     uint32_t* row = v.edges + (ebase(v, t) + (na & 0xFFFFFFu)) * 4 * AP;
     const int a = (int)(na >> 24);
-    const uint32_t nraw = row[a];
+    const uint32_t nraw = row[4 * a];
     const int n = (int)(nraw & NMASK) + 1;
     const uint32_t strong = (nraw & NSTRONG) | (strong_val ? NSTRONG : 0u);
-    const float w = __uint_as_float(row[AP + a]) + cur;
-    row[a] = (uint32_t)n | strong;
-    row[AP + a] = __float_as_uint(w);
-    row[2 * AP + a] = __float_as_uint(w / (float)n);
+    const float w = __uint_as_float(row[4 * a + 1]) + cur;
+    row[4 * a] = (uint32_t)n | strong;
+    row[4 * a + 1] = __float_as_uint(w);
+    row[4 * a + 2] = __float_as_uint(w / (float)n);
     cur = -cur;
   }
 }
@@ -1104,10 +1103,7 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
       if (node < 0) continue;  // not a leaf (a failed insert cannot happen while n_nodes <= cap < hcap)
       uint32_t* row = v.edges + (eb + node) * 4 * AP;
       if (a >= A) pv = 0.f;
-      row[a] = 0u;
-      row[AP + a] = 0u;
-      row[2 * AP + a] = 0u;
-      row[3 * AP + a] = __float_as_uint(pv);
+      reinterpret_cast<uint4*>(row)[a] = make_uint4(0u, 0u, 0u, __float_as_uint(pv));  // N = W = Q = 0, P
     }
   if (total > MAXE) {  // queue does not fit the LDS list: apply sequentially, in order (never at B*depth <= 512)
     if (lane == 0)
@@ -1168,9 +1164,9 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
         w = w + e_val[e];
         if (e_strong[e]) strong = NSTRONG;
       }
-      row0[a0] = (uint32_t)cnt | strong;
-      row0[AP + a0] = __float_as_uint(w);
-      row0[2 * AP + a0] = __float_as_uint(w / (float)cnt);
+      row0[4 * a0] = (uint32_t)cnt | strong;  // N, W, Q: twelve adjacent bytes (P stays)
+      row0[4 * a0 + 1] = __float_as_uint(w);
+      row0[4 * a0 + 2] = __float_as_uint(w / (float)cnt);
     }
     if (own1) {
       const uint32_t n1 = e_n[j1];
@@ -1183,9 +1179,9 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
         w = w + e_val[e];
         if (e_strong[e]) strong = NSTRONG;
       }
-      row1[a1] = (uint32_t)cnt | strong;
-      row1[AP + a1] = __float_as_uint(w);
-      row1[2 * AP + a1] = __float_as_uint(w / (float)cnt);
+      row1[4 * a1] = (uint32_t)cnt | strong;
+      row1[4 * a1 + 1] = __float_as_uint(w);
+      row1[4 * a1 + 2] = __float_as_uint(w / (float)cnt);
     }
   } else
   for (int j = lane; j < n; j += block_threads<ONE>()) {
@@ -1205,9 +1201,9 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
         if (e_strong[k]) strong = NSTRONG;
       }
     }
-    row[a] = (uint32_t)cnt | strong;
-    row[AP + a] = __float_as_uint(w);
-    row[2 * AP + a] = __float_as_uint(w / (float)cnt);  // value_avg = value / visit_count
+    row[4 * a] = (uint32_t)cnt | strong;
+    row[4 * a + 1] = __float_as_uint(w);
+    row[4 * a + 2] = __float_as_uint(w / (float)cnt);  // value_avg = value / visit_count
   }
   CARO_XS(6)  // backups applied
   if (xs && lane == 0) xs[7] = (unsigned long long)total;
@@ -1296,7 +1292,7 @@ __device__ __forceinline__ void root_policy(const View& v, int g, int t, const t
   constexpr int AP = GEO::AP;
   const int node = probe<R>(v, t, root);
   for (int a = threadIdx.x; a < AP; a += blockDim.x)
-    s_n[a] = (node >= 0 && a < v.A) ? (int)(v.edges[(ebase(v, t) + node) * 4 * AP + a] & NMASK) : 0;
+    s_n[a] = (node >= 0 && a < v.A) ? (int)(v.edges[((ebase(v, t) + node) * AP + a) * 4] & NMASK) : 0;
   __syncthreads();
   __shared__ int s_best;
   __shared__ double s_total;
@@ -1365,7 +1361,7 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
 #pragma unroll
     for (int j = 0; j < (AP + 63) / 64; ++j) {
       const int a = threadIdx.x + j * 64;
-      nraw[j] = a < AP && threadIdx.x < 64 ? erow[(size_t)hs * 4 * AP + a] : 0u;
+      nraw[j] = a < AP && threadIdx.x < 64 ? erow[((size_t)hs * AP + a) * 4] : 0u;
     }
     bool eq = true;
 #pragma unroll
@@ -1376,7 +1372,7 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
 #pragma unroll
       for (int j = 0; j < (AP + 63) / 64; ++j) {
         const int a = threadIdx.x + j * 64;
-        nraw[j] = node >= 0 && a < AP && threadIdx.x < 64 ? erow[(size_t)node * 4 * AP + a] : 0u;
+        nraw[j] = node >= 0 && a < AP && threadIdx.x < 64 ? erow[((size_t)node * AP + a) * 4] : 0u;
       }
     }
 #pragma unroll
@@ -1938,11 +1934,11 @@ __global__ void k_lookup(View v, long long M, const int32_t* __restrict__ game, 
   const uint32_t* row = v.edges + (ebase(v, t) + node) * 4 * AP;
   for (int a = threadIdx.x; a < v.A; a += blockDim.x) {
     const size_t o = (size_t)m * v.A + a;
-    N[o] = (int)(row[a] & NMASK);
-    strong[o] = (row[a] & NSTRONG) ? 1 : 0;
-    W[o] = __uint_as_float(row[AP + a]);
-    Q[o] = __uint_as_float(row[2 * AP + a]);
-    P[o] = __uint_as_float(row[3 * AP + a]);
+    N[o] = (int)(row[4 * a] & NMASK);
+    strong[o] = (row[4 * a] & NSTRONG) ? 1 : 0;
+    W[o] = __uint_as_float(row[4 * a + 1]);
+    Q[o] = __uint_as_float(row[4 * a + 2]);
+    P[o] = __uint_as_float(row[4 * a + 3]);
   }
 }
 
@@ -1975,10 +1971,10 @@ __global__ void k_poke(View v, long long M, const int32_t* __restrict__ game, co
       for (int a = threadIdx.x; a < AP; a += blockDim.x) {
         const size_t o = (size_t)m * v.A + a;
         const bool in = a < v.A;
-        row[a] = in ? ((uint32_t)N[o] | (strong[o] ? NSTRONG : 0u)) : 0u;
-        row[AP + a] = in ? __float_as_uint(W[o]) : 0u;
-        row[2 * AP + a] = in ? __float_as_uint(Q[o]) : 0u;
-        row[3 * AP + a] = in ? __float_as_uint(P[o]) : 0u;
+        row[4 * a] = in ? ((uint32_t)N[o] | (strong[o] ? NSTRONG : 0u)) : 0u;
+        row[4 * a + 1] = in ? __float_as_uint(W[o]) : 0u;
+        row[4 * a + 2] = in ? __float_as_uint(Q[o]) : 0u;
+        row[4 * a + 3] = in ? __float_as_uint(P[o]) : 0u;
       }
     }
     __syncthreads();
@@ -2015,11 +2011,11 @@ __global__ void k_dump(View v, int game, int store, long long cap, uint64_t* key
   const uint32_t* row = v.edges + (ebase(v, t) + slot) * 4 * AP;
   for (int a = threadIdx.x; a < v.A; a += blockDim.x) {
     const size_t o = (size_t)node * v.A + a;
-    N[o] = (int)(row[a] & NMASK);
-    strong[o] = (row[a] & NSTRONG) ? 1 : 0;
-    W[o] = __uint_as_float(row[AP + a]);
-    Q[o] = __uint_as_float(row[2 * AP + a]);
-    P[o] = __uint_as_float(row[3 * AP + a]);
+    N[o] = (int)(row[4 * a] & NMASK);
+    strong[o] = (row[4 * a] & NSTRONG) ? 1 : 0;
+    W[o] = __uint_as_float(row[4 * a + 1]);
+    Q[o] = __uint_as_float(row[4 * a + 2]);
+    P[o] = __uint_as_float(row[4 * a + 3]);
   }
   if (threadIdx.x < KW) keys[(size_t)node * KW + threadIdx.x] = k[threadIdx.x];
 }
