@@ -91,6 +91,7 @@ _SIGNATURES = {
     "caro_pending_leaves": (C.c_int, [_P, _P, _P]),
     "caro_debug_stamps": (C.c_int, [_P, C.c_int]),
     "caro_debug_read": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "caro_debug_sqrt_check": (C.c_int, [C.c_uint32, _P]),
     "caro_profile_enable": (C.c_int, [_P, C.c_int]),
     "caro_profile_read": (C.c_int, [_P, _P, _P, C.c_int]),
     "caro_profile_begin": (C.c_int, [_P, C.c_int, _P]),

@@ -279,6 +279,23 @@ __device__ __forceinline__ uint32_t group_max_u32(uint32_t x) {
   return (uint32_t)group_allreduce_i32<LPD>((int)x, [](int a, int b) { return (int)max((uint32_t)a, (uint32_t)b); });
 }
 // float -> uint32 with the same order (-inf lowest); -0.0 must not reach it (callers add +0.0f first)
+// sqrtf of a visit count: x is an integer in [0, 2^24].  v_sqrt_f32 is within one ulp; the two residuals pick the
+// correctly rounded neighbour -- the fix-up sqrtf itself expands to, without its scaling of tiny / huge arguments and
+// its zero / infinity class test (x = 0: both residual tests fail on NaN / zero and 0 stays).  Equal to sqrtf on every
+// such x (caro_debug_sqrt_check compares them all; tests/test_gpu_engine.py).
+__device__ __forceinline__ float sqrt_count(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+  s = rd <= 0.0f ? sd : s;
+  s = ru > 0.0f ? su : s;
+  return s;
+}
+__global__ void k_sqrt_check(uint32_t n, unsigned long long* bad) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x)
+    if (__float_as_uint(sqrt_count((float)i)) != __float_as_uint(sqrtf((float)i))) atomicAdd(bad, 1ull);
+}
+
 __device__ __forceinline__ uint32_t orderable(float f) {
   const uint32_t u = __float_as_uint(f);
   return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
@@ -313,6 +330,7 @@ struct Descent {
   int player, depth, status;
   float value;
   uint32_t home;  // where the descent ended outside the tree: home slot of that board | bit 31 if the slot is empty
+  typename GEO::R::LaneK lk;  // the lane's constants of the win test (move_group)
 };
 
 // One level of find_leaf (lib/mcts.py:123-147) for the descents of a wave.  ROOT: the level at the game's root
@@ -349,8 +367,8 @@ __device__ __forceinline__ void load_row(NodeRow<GEO>& r, const uint64_t* __rest
 
 template <class GEO, bool ROOT>
 __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, int t, const uint64_t* __restrict__ tkeys,
-                                              const uint32_t* __restrict__ tedges, uint4* __restrict__ prec, int l,
-                                              int first, const double* nz, NodeRow<GEO>& r) {
+                                              const uint32_t* __restrict__ tedges, uint4* __restrict__ prec,
+                                              uint4* lprec, int l, int first, const double* nz, NodeRow<GEO>& r) {
   using R = typename GEO::R;
   constexpr int LPD = GEO::LPD, APL = GEO::APL, KW = GEO::KW;
   if (!ROOT) load_row<GEO, true>(r, tkeys, tedges, home_slot<R>(v, d.cur), l);  // the root's row is loaded by the caller
@@ -434,7 +452,7 @@ __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, in
     // Q + ((c * P) * sqrt(sum N)) / (1 + N) in float32, no contraction (mcts.py:79-84 under numpy >= 2).
     // float32(sqrt(float64(n))) == sqrtf(float32(n)) for n < 2^24: rounding a correctly rounded 53-bit root
     // again to 24 bits is innocuous (53 >= 2 * 24 + 2), so the float64 root is not needed here.
-    const float sqf = sqrtf((float)nsum);  // IEEE correctly rounded (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
+    const float sqf = sqrt_count((float)nsum);  // = sqrtf: IEEE correctly rounded
     const float c32 = v.c_puct;
     float bs = -__builtin_huge_valf();
     int ba = l * APL;
@@ -469,10 +487,14 @@ __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, in
         en = oj == j ? nraw[j] : en;
         ew = oj == j ? wraw[j] : ew;
       }
-      prec[d.depth] = make_uint4((uint32_t)node | ((uint32_t)besta << 24), en, ew, 0u);
+      // (staged in LDS when the block's records fit: a store to memory here sits in front of the next level's loads in
+      // the wave's in-order memory counter, and the level would wait for its acknowledgement)
+      const uint4 rec = make_uint4((uint32_t)node | ((uint32_t)besta << 24), en, ew, 0u);
+      if (lprec) lprec[d.depth] = rec;
+      else prec[d.depth] = rec;
     }
   }
-  const bool won = R::template move_group<LPD>(v.gp, d.cur, d.aux, besta, d.player, l, first);  // game.move, mcts.py:138
+  const bool won = R::template move_group<LPD>(v.gp, d.cur, d.aux, besta, d.player, d.lk, first);  // game.move, mcts.py:138
   d.player ^= 1;
   ++d.depth;
   if (won) {  // mcts.py:140-142
@@ -530,6 +552,7 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
   Descent<GEO> d;
   d.cur = gr.root;
   d.aux = R::aux_of(v.gp, d.cur);
+  d.lk = R::lane_k(v.gp, l);
   const int player0 = gr.player;
   d.player = player0;
   d.depth = 0;
@@ -567,10 +590,18 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
   }
   if (v.dbg) st_noise = __builtin_amdgcn_s_memtime();
 
-  bool live = descend_level<GEO, true>(v, d, t, tkeys, tedges, prec, l, first, nz, r);
+  // the descents' path records are collected in LDS and written out after the last level
+  constexpr int PREC_LDS = 512;
+  __shared__ uint4 s_prec[PREC_LDS];
+  const bool stage = B * v.maxd <= PREC_LDS;
+  uint4* lprec = stage ? s_prec + b * v.maxd : nullptr;
+  bool live = descend_level<GEO, true>(v, d, t, tkeys, tedges, prec, lprec, l, first, nz, r);
   if (v.dbg) st_root = __builtin_amdgcn_s_memtime();
-  while (__any(live)) {
-    if (live) live = descend_level<GEO, false>(v, d, t, tkeys, tedges, prec, l, first, nullptr, r);
+  // (a group's lanes leave the loop together: everything a level exchanges stays inside the group)
+  while (live) live = descend_level<GEO, false>(v, d, t, tkeys, tedges, prec, lprec, l, first, nullptr, r);
+  if (stage) {  // a group's lanes share a wavefront: its LDS writes are in order with these reads
+    __builtin_amdgcn_wave_barrier();
+    for (int i = l; i < d.depth; i += LPD) prec[i] = s_prec[b * v.maxd + i];
   }
   if (v.dbg) st_loop = __builtin_amdgcn_s_memtime();
 
@@ -2696,6 +2727,20 @@ int caro_debug_read(caro_engine* h, uint64_t* out_host, int64_t n_u64, void* str
   if (n_u64 > (int64_t)h->v.G * 16) n_u64 = (int64_t)h->v.G * 16;
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   HIPCHK(hipMemcpy(out_host, h->v.dbg, n_u64 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* diagnostic: the tree kernels' square root of a visit count against sqrtf on every integer 0..n_max (<= 2^24); the
+   number of differing results goes to *bad_host (0 is the only acceptable answer) */
+int caro_debug_sqrt_check(uint32_t n_max, uint64_t* bad_host) {
+  if (!bad_host || n_max > (1u << 24)) return fail(CARO_E_INVAL, "bad argument");
+  unsigned long long* bad = nullptr;
+  HIPCHK(hipMalloc(&bad, sizeof(unsigned long long)));
+  HIPCHK(hipMemset(bad, 0, sizeof(unsigned long long)));
+  hipLaunchKernelGGL(k_sqrt_check, dim3(1024), dim3(256), 0, (hipStream_t) nullptr, n_max, bad);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(bad_host, bad, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipFree(bad));
   return 0;
 }
 

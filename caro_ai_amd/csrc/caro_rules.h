@@ -146,10 +146,19 @@ struct C4Rules {
 #if defined(__HIPCC__)
   // the same move made by the LPD lanes of one descent (all hold the same board): lane l tests direction l & 3,
   // one ballot joins the four.  `first` = the group's first lane in the wave.
+  // What lane l contributes does not change along a descent (its direction's stride and start-row mask): formed once
+  // per descent (lane_k) instead of by selects on the dependent chain of every level.
+  struct LaneK { int s; uint64_t m; };
+  static CR_D LaneK lane_k(const GameParams&, int l) {
+    const int dir = l & 3;
+    LaneK k{dir == 0 ? 1 : dir == 1 ? 6 : dir == 2 ? 7 : 5, dir == 1 ? ~0ULL : dir == 3 ? ROWS345 : ROWS012};
+    asm volatile("" : "+v"(k.s), "+v"(k.m));  // keep them in registers: not re-formed inside the loop
+    return k;
+  }
   template <int LPD>
-  static CR_D bool move_group(const GameParams&, Board& b, Aux& aux, int col, int player, int l, int first) {
+  static CR_D bool move_group(const GameParams&, Board& b, Aux& aux, int col, int player, const LaneK& k, int first) {
     const uint64_t nb = drop(b, aux, col, player);
-    const uint64_t hit = wins_dir(stones(b, aux, player), nb, l & 3);
+    const uint64_t hit = four(stones(b, aux, player), k.s) & k.m & span(nb, k.s);
     return group_bits<LPD>(__ballot(hit != 0), first) != 0;
   }
 #endif
@@ -285,9 +294,12 @@ struct MnkRules {
   // element l % NL of line l / NL (NL = LPD / 4 >= n for every geometry: n <= 4 | 16 lanes, 5 | 32, <= 15 | 64),
   // the group's ballot bits are the four line words side by side, and a run of k is found in all four at once;
   // `starts` keeps a run from straddling two lines when n == NL.
+  struct LaneK { int l; };
+  static CR_D LaneK lane_k(const GameParams&, int l) { return LaneK{l}; }
   template <int LPD>
-  static CR_D bool move_group(const GameParams& gp, Board& b, Aux&, int mv, int player, int l, int first) {
+  static CR_D bool move_group(const GameParams& gp, Board& b, Aux&, int mv, int player, const LaneK& lk, int first) {
     constexpr int NL = LPD / 4;
+    const int l = lk.l;
     put(b, mv, player);
     const int n = gp.n, row = mv / n, col = mv % n;
     const int i = line_cell(n, row, col, l / NL, l % NL);

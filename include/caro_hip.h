@@ -190,6 +190,9 @@ int caro_profile_read(caro_engine* h, double ms[8], int64_t launches[8], int res
 /* diagnostics (tools/probe_select.py): per-game cycle stamps of k_select's phases; off unless enabled */
 int caro_debug_stamps(caro_engine* h, int on);
 int caro_debug_read(caro_engine* h, uint64_t* out_host, int64_t n_u64, void* stream);
+/* diagnostic: the device's square root of a visit count (float32, `m.sqrt(sum(counts))` of lib/mcts.py:79 rounded as
+   numpy does) compared with sqrtf on every integer 0..n_max (n_max <= 2^24); *bad_host = differing results (must be 0) */
+int caro_debug_sqrt_check(uint32_t n_max, uint64_t* bad_host);
 /* number of live (unfinished) games; synchronises */
 int caro_live_games(caro_engine* h, int32_t* live, void* stream);
 /* unique leaves that have been selected but not yet booked as expansions (between caro_select and

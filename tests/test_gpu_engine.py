@@ -79,6 +79,16 @@ def test_noise_device_equals_host_bits(A):
     assert np.all(got > 0) and np.allclose(got.sum(1), 1.0, atol=1e-12)
 
 
+def test_visit_count_square_root_is_sqrtf_on_every_count():
+    """the descent's sqrt(sum N) (lib/mcts.py:79, float32 as numpy rounds it) is a trimmed form of sqrtf: equal on every
+    integer a visit count can be, 0 .. 2^24"""
+    import ctypes as C
+    from caro_ai_amd import _lib
+    bad = C.c_uint64(12345)
+    _lib.check(_lib.load().caro_debug_sqrt_check(1 << 24, C.byref(bad)))
+    assert bad.value == 0
+
+
 # ------------------------------------------------------------------ batched rules vs the reference's vectors
 @pytest.mark.parametrize("name", ["rules_c4.json.gz", "rules_ttt3.json.gz", "rules_mnk5.json.gz",
                                   "rules_mnk15.json.gz"])
