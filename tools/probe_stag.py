@@ -9,8 +9,9 @@ from caro_ai_amd.lib.model import Net
 from caro_ai_amd.net_hip import HipNet
 g = ConnectFour()
 net = Net(g.obs_shape, 7); net.load_state_dict(torch.load("tests/golden/weights/best_026_12000.dat", map_location="cpu"))
-G, S, B = 1024, 25, 8
-eng = SelfPlayEngine(g, G, evaluators=[HipNet(net, "cuda:0")], max_batch=B, seed=0, stagger=True, searches_hint=S)
+G, S, B = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), 25, 8
+CAP = int(sys.argv[2]) if len(sys.argv) > 2 else None
+eng = SelfPlayEngine(g, G, evaluators=[HipNet(net, "cuda:0")], max_batch=B, seed=0, stagger=True, searches_hint=S, node_cap=CAP)
 for _ in range(20):
     eng.search(S, B); eng.drain()
 L = _lib.load()
