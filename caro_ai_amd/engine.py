@@ -234,40 +234,45 @@ class SelfPlayEngine:
         return actions, done, result
 
     def _staging(self, cap):
+        """fresh output buffers for one drain, carved from ONE allocation (the caching allocator hands back a block a
+        dropped drain released: no GPU work): the rows a drain returns are views of them, so no copy kernels follow the
+        drain kernels on the stream and tuples kept across moves never alias a later drain"""
         cap = int(cap or self.G * self.maxply)
-        if not hasattr(self, "_dr") or self._dr[0].shape[0] < cap:
-            dev = self.device
-            self._dr = (torch.empty((cap, self.KW), dtype=torch.int64, device=dev),
-                        torch.empty(cap, dtype=torch.int32, device=dev),
-                        torch.empty((cap, self.A), dtype=torch.float64, device=dev),
-                        torch.empty(cap, dtype=torch.int32, device=dev),
-                        torch.empty((self.G, 4), dtype=torch.int64, device=dev))
-        return cap
+        KW, A, G = self.KW, self.A, self.G
+        sizes = (cap * KW * 8, cap * A * 8, G * 4 * 8, cap * 4, cap * 4)  # states, pi, games (8-byte types first), players, z
+        buf = torch.empty(sum(sizes), dtype=torch.uint8, device=self.device)
+        o = [0]
+        for n in sizes:
+            o.append(o[-1] + n)
+        return cap, (buf[o[0]:o[1]].view(torch.int64).view(cap, KW),
+                     buf[o[3]:o[4]].view(torch.int32),
+                     buf[o[1]:o[2]].view(torch.float64).view(cap, A),
+                     buf[o[4]:o[5]].view(torch.int32),
+                     buf[o[2]:o[3]].view(torch.int64).view(G, 4))
 
     def drain_begin(self, recycle=True, cap=None):
         """first half of drain(): the kernels are enqueued, nothing waits (see caro_drain_tuples_begin)"""
-        cap = self._staging(cap)
-        s, p, pi, z, games = self._dr
+        cap, bufs = self._staging(cap)
+        s, p, pi, z, games = bufs
         if self.stagger:  # the parked games; their slots have restarted already (or not: stagger_recycle)
             assert bool(recycle) == self.stagger_recycle, \
                 "staggered mode restarts slots in-kernel: recycle is fixed by stagger_recycle at construction"
             _lib.check(self.L.caro_drain_parked_begin(self.h, cap, _ptr(s), _ptr(p), _ptr(pi), _ptr(z), _ptr(games),
                                                       self._stream()))
-            return
-        _lib.check(self.L.caro_drain_tuples_begin(self.h, cap, _ptr(s), _ptr(p), _ptr(pi), _ptr(z), _ptr(games),
-                                                  1 if recycle else 0, self._stream()))
+        else:
+            _lib.check(self.L.caro_drain_tuples_begin(self.h, cap, _ptr(s), _ptr(p), _ptr(pi), _ptr(z), _ptr(games),
+                                                      1 if recycle else 0, self._stream()))
+        self._dr = bufs  # (only once the call was accepted: a refused begin leaves the open drain's buffers in place)
 
     def drain_end(self):
-        """second half: waits for the totals, hands out the rows as tensors of their own (the staging buffer is
-        reused from row 0 by the next drain; the copies are ordered before it on the stream)"""
+        """second half: waits for the totals, hands out the rows (views of this drain's own buffers, see _staging)"""
         s, p, pi, z, games = self._dr
         nt, ng = C.c_int64(0), C.c_int64(0)
         _lib.check(self.L.caro_drain_tuples_end(self.h, C.addressof(nt), C.addressof(ng)))
         nt, ng = nt.value, ng.value
         if nt == 0 and ng == 0:
             return {"states": s[:0], "players": p[:0], "pi": pi[:0], "z": z[:0], "games": games[:0]}
-        return {"states": s[:nt].clone(), "players": p[:nt].clone(), "pi": pi[:nt].clone(), "z": z[:nt].clone(),
-                "games": games[:ng].clone()}
+        return {"states": s[:nt], "players": p[:nt], "pi": pi[:nt], "z": z[:nt], "games": games[:ng]}
 
     def drain(self, recycle=True, cap=None):
         """Finished games -> tuples (device tensors of their own: later drains do not touch them), in the
