@@ -456,7 +456,13 @@ class Leg:
                                           "this configuration (%s)" % PMC_FILE
                         if pmc.get(kname, {}).get("mfma_busy") else None,
                         "avg_launch_us": avg_s * 1e6, "launches_timed": n, "leaves_per_launch": leaves_per_launch,
-                        "flops_per_leaf": flops_per_leaf}
+                        "flops_per_leaf": flops_per_leaf,
+                        "clock_note": "peak is the guide's figure at 2.4 GHz. Workgroup clocks stamped inside the engine's "
+                                      "own launches (tools/probe_engine_net.py, profiles/r04_engine_launch_pair_timeline"
+                                      ".txt; not measured in this run) put the shader clock under this kernel at "
+                                      "2.08-2.11 GHz in steady state (2.36 GHz in a first launch): a workgroup's 312 k "
+                                      "cycles are the whole launch, there is no dispatch tail. At that clock the matrix "
+                                      "pipe's peak is 137.6 TFLOP/s"}
             kernel_us += S * avg_s * 1e6
         if roofline is None:  # torch evaluators: the net is not our kernel; the tree walk is the dominant own kernel
             roofline = roofline_tree
