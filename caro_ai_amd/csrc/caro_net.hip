@@ -205,7 +205,8 @@ static inline int head_span_host(int HW, int A) { return 3 * NF + 3 + 20 * HW + 
 template <bool STAGED, bool K2D = false, int NTH = NT>
 __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, float* scratch,
                                           float* __restrict__ probs, float* __restrict__ values, int slot_v, int nb,
-                                          int R, int tid) {
+                                          int R, int tid, float* __restrict__ featbuf = nullptr,
+                                          int32_t* __restrict__ rowlist = nullptr, int dense0 = 0) {
   const int HW = p.HW, A = p.A;
   const float slope = p.slope;
   // !STAGED (boards from 7x7 up): the parameters up to b_v2 (at most 4 740 floats) are copied to the place of the staged
@@ -213,7 +214,7 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
   // memory (225 dependent batches of loads at 15x15)
   constexpr int NSM = (3 * NF + 3 + 20 * 225 + 20 + 20 + 1 + NTH - 1) / NTH;  // floats per thread at the largest board
   const int nsmall = 3 * NF + 3 + 20 * HW + 20 + 20 + 1;
-  if (!STAGED) {
+  if (!STAGED && !featbuf) {
     float tmp[NSM];
 #pragma unroll
     for (int u = 0; u < NSM; ++u) tmp[u] = tid + u * NTH < nsmall ? p.w_head[tid + u * NTH] : 0.f;
@@ -222,7 +223,8 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
       if (tid + u * NTH < nsmall) scratch[HEAD_STAGE_AT + tid + u * NTH] = tmp[u];
     __syncthreads();
   }
-  const float* hp = scratch + HEAD_STAGE_AT;
+  // (featbuf: only the 1x1 convolutions are computed here -- their 195 parameters come straight from the packed buffer)
+  const float* hp = featbuf ? p.w_head : scratch + HEAD_STAGE_AT;
   const float* w_head = hp;
   const float* b_head = w_head + 3 * NF;
   const float* w_v1 = b_head + 3;
@@ -256,6 +258,20 @@ __device__ __forceinline__ void heads_f32(const NetParams& p, const float* act, 
     feat[o * 256 + r] = leaky(s0, slope);
   }
   __syncthreads();
+  if (featbuf) {
+    // Batched heads (k_net_heads: large boards, one board per workgroup): the board's three feature planes go to row
+    // `dense` of the launch's feature buffer, its output row to the row list; the two FC heads, tanh and the softmax
+    // of 32 boards at a time follow in their own launch, which reads the policy matrix once per 32 boards instead of
+    // once per board (405 KB at 15x15: this stage was 10 k cycles of every workgroup's 275 k, streaming at the compute
+    // unit's L2 bandwidth).
+    for (int q = tid; q < 3 * R; q += NTH) {
+      const int o = q / R, r = q - o * R;
+      const int bi = r / HW, c = r - bi * HW;
+      featbuf[((size_t)(dense0 + bi) * 3 + o) * HW + c] = feat[o * 256 + r];
+    }
+    if (tid < nb) rowlist[dense0 + tid] = slot_v;
+    return;
+  }
   /*@HST(1)*/
   /*@PST(9)*/
   // value head: Linear(HW,20) + LeakyReLU -- threads from 0 up
@@ -1537,7 +1553,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w2(NetParams p0, NetParam
                                                             const int32_t* __restrict__ counts, int which, int row1,
                                                             float* __restrict__ probs, float* __restrict__ values,
                                                             unsigned long long* __restrict__ stamps,
-                                                            const int32_t* __restrict__ gpack, int gG, int gB) {
+                                                            const int32_t* __restrict__ gpack, int gG, int gB,
+                                                            float* __restrict__ featbuf, int32_t* __restrict__ rowlist) {
   __shared__ __attribute__((aligned(256))) float lds[LDS_FLOATS];  // trunk_w2d XORs granule bits into LDS addresses
   float* act = lds;
   float* wbuf = lds + ACT;
@@ -1600,12 +1617,181 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w2(NetParams p0, NetParam
   trunk_w2d(p, act, wbuf, tid);
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
-  heads_f32<false, true>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
+  // featbuf != null: the FC heads of the whole launch follow in k_net_heads (row0 + board0 = this board's dense index)
+  heads_f32<false, true>(p, act, wbuf, probs, values, slot_v, nb, R, tid, featbuf, rowlist, row0 + board0);
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
     stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
     stamps[4 * blockIdx.x + 2] = t_trunk0 - t_c0;
     stamps[4 * blockIdx.x + 3] = t_trunk1 - t_c0;
+  }
+}
+
+// The two FC heads, tanh and the softmax (lib/model.py:50-67, lib/mcts.py:216) of a k_net_forward_w2 launch, 32 boards
+// per workgroup: logits[32 boards][A] = features[32][2 HW] x w_p^T on the matrix pipe (wave w takes the 32 actions from
+// 32 w; K runs over the (plane, cell) order of the reference's flatten, four cells per lane and load: the A operand from
+// the staged features, the B operand from the quad-transposed policy matrix w_pT, whose 16-byte granules are
+// consecutive in the action), the value head Linear(HW,20) + LeakyReLU + Linear(20,1) + tanh as fma chains in the
+// reference's order, the softmax with sixteen threads per board.  One read of the policy matrix serves 32 boards.
+constexpr int HB = 32;               // boards per workgroup
+constexpr int HPL = 228;             // floats per staged feature plane (225 cells, rows 16-byte aligned)
+constexpr int HFS = 3 * HPL + 8;     // floats per staged board (692 = 52 mod 64: the 32 rows of an operand read spread over the banks)
+constexpr int HLG = 256;             // floats per logit row (A <= 255)
+__global__ __launch_bounds__(NT, 1) void k_net_heads(NetParams p0, NetParams p1, const int32_t* __restrict__ counts,
+                                                       int which, int row1, const float* __restrict__ featbuf,
+                                                       const int32_t* __restrict__ rowlist, float* __restrict__ probs,
+                                                       float* __restrict__ values) {
+  __shared__ __attribute__((aligned(16))) float F[HB * HFS];
+  __shared__ __attribute__((aligned(16))) float logit[HB * HLG];
+  __shared__ float wv1[20 * 225];
+  __shared__ float hid[HB * 20];
+  __shared__ float part[HB * 16];
+  __shared__ float rsum[HB];
+  __shared__ int orow[HB];
+  int L, base, blk;
+  bool second = false;
+  if (which < 2) {
+    L = counts[which];
+    base = which ? counts[0] : 0;
+    blk = blockIdx.x;
+  } else {
+    const int L0 = counts[0], nb0 = (L0 + HB - 1) / HB;
+    second = (int)blockIdx.x >= nb0;
+    L = second ? counts[1] : L0;
+    base = second ? (row1 >= 0 ? row1 : L0) : 0;
+    blk = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x;
+  }
+  const int i0 = blk * HB;
+  if (i0 >= L) return;
+  const int nbrd = L - i0 < HB ? L - i0 : HB;
+  const NetParams p = second ? p1 : p0;
+  const int HW = p.HW, A = p.A, tid = threadIdx.x;
+  const float slope = p.slope;
+  // the boards' features and the value head's first matrix (rows behind the last board stay as they are: a row of the
+  // product depends on its own board only, and those rows are never written out)
+  {
+    // (the dense boards of a workgroup are consecutive rows of the feature buffer: one flat copy, eight requests per
+    // thread in flight)
+    const float* src = featbuf + (size_t)(base + i0) * 3 * HW;
+    const int total = nbrd * 3 * HW;
+    for (int j0 = tid; j0 < total; j0 += 8 * NT) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = j0 + u * NT < total ? src[j0 + u * NT] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u * NT;
+        if (j < total) {
+          const int i = j / (3 * HW), r = j - i * 3 * HW, o = (r >= HW) + (r >= 2 * HW);
+          F[i * HFS + o * HPL + (r - o * HW)] = t[u];
+        }
+      }
+    }
+    float tw[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) tw[u] = tid + u * NT < 20 * HW ? p.w_v1[tid + u * NT] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 9; ++u)
+      if (tid + u * NT < 20 * HW) wv1[tid + u * NT] = tw[u];
+  }
+  if (tid < HB) orow[tid] = tid < nbrd ? rowlist[base + i0 + tid] : 0;
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  // ---- policy logits: wave -> 32 actions, lane -> (board lane & 31 of the A operand | action lane & 31 of the B operand, k half)
+  if (wave * 32 < A) {
+    const int i = lane & 31, h = lane >> 5, a = wave * 32 + i;
+    const bool av = a < A;
+    const int nq = HW >> 2, rem = HW & 3;
+    const int npair = (nq + 1) / 2;  // steps of two quads (one per k half)
+    const size_t half = ((size_t)HW * A + 3) & ~(size_t)3;
+    constexpr int U = 4;  // pairs per group: the next group's operands are requested under the current group's 16 MFMAs
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int pl = 0; pl < 2; ++pl) {
+      const float* frow = F + i * HFS + (1 + pl) * HPL;
+      const float* wh = p.w_pT + pl * half;
+      const float4* wq = reinterpret_cast<const float4*>(wh) + (av ? a : 0);
+      float4 bw[U], fa[U], bn[U], fn[U];
+      auto fetch = [&](int g, float4* b_, float4* f_) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int q = 2 * (g * U + u) + h;  // this k half's quad of cells
+          const bool qv = q < nq && g * U + u < npair;
+          b_[u] = (qv && av) ? wq[(size_t)q * A] : make_float4(0.f, 0.f, 0.f, 0.f);
+          f_[u] = qv ? *reinterpret_cast<const float4*>(frow + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+      const int ngrp = (npair + U - 1) / U;
+      fetch(0, bn, fn);
+      for (int g = 0; g < ngrp; ++g) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { bw[u] = bn[u]; fa[u] = fn[u]; }
+        if (g + 1 < ngrp) fetch(g + 1, bn, fn);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].x, bw[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].y, bw[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].z, bw[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u].w, bw[u].w, acc, 0, 0, 0);
+        }
+      }
+      const float* wr = wh + (size_t)nq * A * 4;
+      for (int r = 0; r < rem; ++r) {  // the last HW % 4 cells: the lower k half carries them, the upper one zeros
+        const float fr = h == 0 ? frow[4 * nq + r] : 0.f;
+        const float br = (h == 0 && av) ? wr[(size_t)r * A + a] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr, br, acc, 0, 0, 0);
+      }
+    }
+    // C[board 8 (r >> 2) + 4 h + (r & 3)][action lane & 31]
+    if (av) {
+      const float bias = p.b_p[a];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) logit[(8 * (r >> 2) + 4 * h + (r & 3)) * HLG + a] = acc[r] + bias;
+    }
+  }
+  // ---- value head, first layer: Linear(HW,20) + LeakyReLU, one (board, unit) per thread, the chain in cell order
+  for (int k = tid; k < nbrd * 20; k += NT) {
+    const int bi = k / 20, u = k - bi * 20;
+    float s = p.b_v1[u];
+    const float* w = wv1 + u * HW;
+    const float* f = F + bi * HFS;
+#pragma unroll 8
+    for (int c = 0; c < HW; ++c) s = fmaf(f[c], w[c], s);
+    hid[k] = leaky(s, slope);
+  }
+  __syncthreads();
+  // ---- Linear(20,1) + tanh; the softmax: sixteen threads per board
+  if (tid < nbrd) {
+    float s = p.b_v2[0];
+    for (int u = 0; u < 20; ++u) s = fmaf(hid[tid * 20 + u], p.w_v2[u], s);
+    values[orow[tid]] = tanhf(s);
+  }
+  const int bi = tid >> 4, j = tid & 15;
+  float* lg = logit + bi * HLG;
+  float mx = -3.4e38f;
+  for (int a = j; a < A; a += 16) mx = fmaxf(mx, lg[a]);
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 16));
+  float ps = 0.f;
+  for (int a = j; a < A; a += 16) {  // exp(logit - max) in place, the thread's strided share summed in action order
+    const float e = expf(lg[a] - mx);
+    lg[a] = e;
+    ps += e;
+  }
+  part[tid] = ps;
+  __syncthreads();
+  if (j == 0) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum += part[bi * 16 + q];
+    rsum[bi] = sum;
+  }
+  __syncthreads();
+  if (bi < nbrd) {
+    const float sum = rsum[bi];
+    float* out = probs + (size_t)orow[bi] * A;
+    for (int a = j; a < A; a += 16) out[a] = lg[a] / sum;
   }
 }
 
@@ -1984,6 +2170,9 @@ struct caro_net {
   uint32_t* wtab_dev;  // tile table (f32w mode), or null
   float* ww2_dev;      // 2-D Winograd transformed residual weights (f32w2 mode), or null
   float* wpT_dev;      // policy matrix transposed, or null
+  float* feat_dev;     // f32w2 mode: the launch's feature rows [rows][3][HW] between k_net_forward_w2 and k_net_heads
+  int32_t* rowl_dev;   //             and the output row of every dense board
+  int64_t feat_rows;   //             rows both hold
   int device;
   unsigned long long* dbg_stamps;  // diagnostic (caro_net_debug_stamps): per-workgroup stamps of the slot launches too
 };
@@ -2043,6 +2232,9 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   n->wtab_dev = nullptr;
   n->ww2_dev = nullptr;
   n->wpT_dev = nullptr;
+  n->feat_dev = nullptr;
+  n->rowl_dev = nullptr;
+  n->feat_rows = 0;
   const size_t pad = (size_t)cnet::TPC * cnet::WCHUNK;  // k_net_forward reads one chunk past the last tap
   if (hipMalloc((void**)&n->dev, (n_floats + pad) * sizeof(float)) != hipSuccess) {
     delete n;
@@ -2230,6 +2422,7 @@ int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_flo
     return nfail(CARO_E_INVAL, "2-D Winograd form: boards of one per workgroup with at most 8 x 8 tiles (12x12 .. 15x15)");
   const int64_t want = (int64_t)cnet::W2NCHUNK * cnet::WCH;
   if (n_floats != want) return nfail(CARO_E_INVAL, "transformed weight image has the wrong size");
+  if (!n->p.w_pT) return nfail(CARO_E_STATE, "2-D Winograd form: the batched heads need the transposed policy matrix");
   if (hipSetDevice(n->device) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
   if (!n->ww2_dev && hipMalloc((void**)&n->ww2_dev, want * sizeof(float)) != hipSuccess)
     return nfail(CARO_E_NOMEM, "hipMalloc failed");
@@ -2247,6 +2440,8 @@ void caro_net_destroy(caro_net* n) {
   if (n->wtab_dev) (void)hipFree(n->wtab_dev);
   if (n->ww2_dev) (void)hipFree(n->ww2_dev);
   if (n->wpT_dev) (void)hipFree(n->wpT_dev);
+  if (n->feat_dev) (void)hipFree(n->feat_dev);
+  if (n->rowl_dev) (void)hipFree(n->rowl_dev);
   if (n->dev) (void)hipFree(n->dev);
   delete n;
 }
@@ -2270,6 +2465,9 @@ int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro
   n->wtab_dev = nullptr;
   n->ww2_dev = nullptr;
   n->wpT_dev = nullptr;
+  n->feat_dev = nullptr;
+  n->rowl_dev = nullptr;
+  n->feat_rows = 0;
   n->p.H = H; n->p.W = W; n->p.HW = H * W; n->p.A = A; n->p.TB = 4;
   *out = n;
   return 0;
@@ -2292,9 +2490,27 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
     if (n0->p.w3)
       hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, gpack, G, B);
-    else if (n0->p.ww2)
+    else if (n0->p.ww2) {
+      // the trunk launch leaves every board's three feature planes in n0's feature buffer; the FC heads of the whole
+      // launch follow, 32 boards per workgroup (k_net_heads).  The buffer grows to the largest launch seen (first call).
+      const int64_t need = max_rows + (row1 > 0 ? row1 : 0) + 64;
+      if (n0->feat_rows < need) {
+        if (n0->feat_dev) (void)hipFree(n0->feat_dev);
+        if (n0->rowl_dev) (void)hipFree(n0->rowl_dev);
+        n0->feat_dev = nullptr; n0->rowl_dev = nullptr; n0->feat_rows = 0;
+        if (hipMalloc((void**)&n0->feat_dev, (size_t)need * 3 * n0->p.HW * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&n0->rowl_dev, (size_t)need * sizeof(int32_t)) != hipSuccess)
+          return nfail(CARO_E_NOMEM, "hipMalloc of the head feature rows failed");
+        n0->feat_rows = need;
+      }
       hipLaunchKernelGGL(cnet::k_net_forward_w2, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
-                         counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B);
+                         counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B,
+                         n0->feat_dev, n0->rowl_dev);
+      if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "net kernel launch failed");
+      const unsigned hgrid = (unsigned)((max_rows + cnet::HB - 1) / cnet::HB) + (which == 2 ? 1u : 0u);
+      hipLaunchKernelGGL(cnet::k_net_heads, dim3(hgrid), dim3(cnet::NT), 0, st, n0->p, n1->p, counts_dev, which, row1,
+                         n0->feat_dev, n0->rowl_dev, probs_dev, values_dev);
+    }
     else if (n0->p.ww)
       hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B);
