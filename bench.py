@@ -441,7 +441,10 @@ class Leg:
                                 "than the direct convolution; tile padding included) / launch time measured with HIP "
                                 "events in this run; algorithmic_* prices SURVEY 8(d)'s direct-convolution flops per "
                                 "leaf over the same time and can exceed 1 for a Winograd kernel; mfma_busy_pmc is the "
-                                "hardware's own count from the committed --pmc pass",
+                                "hardware's own count from the committed --pmc pass"
+                                + ("; a launch here = k_net_forward_w2 (trunk, 1x1 convolutions) + k_net_heads (the FC "
+                                   "heads of the launch, 32 boards per workgroup): avg_launch_us spans both"
+                                   if kname == "k_net_forward_w2" else ""),
                         "traffic": pmc.get(kname, {}).get("hbm"),
                         "traffic_source": (traffic_note + "; the net's algorithmic bytes per launch are planes + "
                                            "priors + the weights once (%.2f MB): the measured figure is higher because "
