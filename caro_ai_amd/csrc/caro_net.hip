@@ -2170,9 +2170,10 @@ struct caro_net {
   uint32_t* wtab_dev;  // tile table (f32w mode), or null
   float* ww2_dev;      // 2-D Winograd transformed residual weights (f32w2 mode), or null
   float* wpT_dev;      // policy matrix transposed, or null
-  float* feat_dev;     // f32w2 mode: the launch's feature rows [rows][3][HW] between k_net_forward_w2 and k_net_heads
-  int32_t* rowl_dev;   //             and the output row of every dense board
-  int64_t feat_rows;   //             rows both hold
+  // f32w2 mode: the feature rows [rows][3][HW] that travel from k_net_forward_w2 to k_net_heads and the output row of
+  // every dense board -- one set per stream the handle is launched on (launches on different streams may overlap)
+  struct HeadRows { void* stream; float* feat; int32_t* rowl; int64_t rows; } hrows[8];
+  int n_hrows;
   int device;
   unsigned long long* dbg_stamps;  // diagnostic (caro_net_debug_stamps): per-workgroup stamps of the slot launches too
 };
@@ -2232,9 +2233,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   n->wtab_dev = nullptr;
   n->ww2_dev = nullptr;
   n->wpT_dev = nullptr;
-  n->feat_dev = nullptr;
-  n->rowl_dev = nullptr;
-  n->feat_rows = 0;
+  n->n_hrows = 0;
   const size_t pad = (size_t)cnet::TPC * cnet::WCHUNK;  // k_net_forward reads one chunk past the last tap
   if (hipMalloc((void**)&n->dev, (n_floats + pad) * sizeof(float)) != hipSuccess) {
     delete n;
@@ -2440,8 +2439,10 @@ void caro_net_destroy(caro_net* n) {
   if (n->wtab_dev) (void)hipFree(n->wtab_dev);
   if (n->ww2_dev) (void)hipFree(n->ww2_dev);
   if (n->wpT_dev) (void)hipFree(n->wpT_dev);
-  if (n->feat_dev) (void)hipFree(n->feat_dev);
-  if (n->rowl_dev) (void)hipFree(n->rowl_dev);
+  for (int k = 0; k < n->n_hrows; ++k) {
+    if (n->hrows[k].feat) (void)hipFree(n->hrows[k].feat);
+    if (n->hrows[k].rowl) (void)hipFree(n->hrows[k].rowl);
+  }
   if (n->dev) (void)hipFree(n->dev);
   delete n;
 }
@@ -2465,9 +2466,7 @@ int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro
   n->wtab_dev = nullptr;
   n->ww2_dev = nullptr;
   n->wpT_dev = nullptr;
-  n->feat_dev = nullptr;
-  n->rowl_dev = nullptr;
-  n->feat_rows = 0;
+  n->n_hrows = 0;
   n->p.H = H; n->p.W = W; n->p.HW = H * W; n->p.A = A; n->p.TB = 4;
   *out = n;
   return 0;
@@ -2494,22 +2493,30 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
       // the trunk launch leaves every board's three feature planes in n0's feature buffer; the FC heads of the whole
       // launch follow, 32 boards per workgroup (k_net_heads).  The buffer grows to the largest launch seen (first call).
       const int64_t need = max_rows + (row1 > 0 ? row1 : 0) + 64;
-      if (n0->feat_rows < need) {
-        if (n0->feat_dev) (void)hipFree(n0->feat_dev);
-        if (n0->rowl_dev) (void)hipFree(n0->rowl_dev);
-        n0->feat_dev = nullptr; n0->rowl_dev = nullptr; n0->feat_rows = 0;
-        if (hipMalloc((void**)&n0->feat_dev, (size_t)need * 3 * n0->p.HW * sizeof(float)) != hipSuccess ||
-            hipMalloc((void**)&n0->rowl_dev, (size_t)need * sizeof(int32_t)) != hipSuccess)
+      caro_net::HeadRows* hr = nullptr;
+      for (int k = 0; k < n0->n_hrows; ++k)
+        if (n0->hrows[k].stream == stream) hr = &n0->hrows[k];
+      if (!hr) {
+        if (n0->n_hrows == 8) return nfail(CARO_E_STATE, "a large-board net handle serves at most 8 streams");
+        hr = &n0->hrows[n0->n_hrows++];
+        hr->stream = stream; hr->feat = nullptr; hr->rowl = nullptr; hr->rows = 0;
+      }
+      if (hr->rows < need) {
+        if (hr->feat) (void)hipFree(hr->feat);
+        if (hr->rowl) (void)hipFree(hr->rowl);
+        hr->feat = nullptr; hr->rowl = nullptr; hr->rows = 0;
+        if (hipMalloc((void**)&hr->feat, (size_t)need * 3 * n0->p.HW * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&hr->rowl, (size_t)need * sizeof(int32_t)) != hipSuccess)
           return nfail(CARO_E_NOMEM, "hipMalloc of the head feature rows failed");
-        n0->feat_rows = need;
+        hr->rows = need;
       }
       hipLaunchKernelGGL(cnet::k_net_forward_w2, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B,
-                         n0->feat_dev, n0->rowl_dev);
+                         hr->feat, hr->rowl);
       if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "net kernel launch failed");
       const unsigned hgrid = (unsigned)((max_rows + cnet::HB - 1) / cnet::HB) + (which == 2 ? 1u : 0u);
       hipLaunchKernelGGL(cnet::k_net_heads, dim3(hgrid), dim3(cnet::NT), 0, st, n0->p, n1->p, counts_dev, which, row1,
-                         n0->feat_dev, n0->rowl_dev, probs_dev, values_dev);
+                         hr->feat, hr->rowl, probs_dev, values_dev);
     }
     else if (n0->p.ww)
       hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,

@@ -252,8 +252,8 @@ int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats
  * with the other arithmetic modes of a net.  A forward call of such a net is TWO launches on the caller's stream: the
  * trunk (one board per workgroup) and the FC heads + softmax of the whole call, 32 boards per workgroup; the first call
  * allocates the feature rows that travel between them (3 * H * W floats per row of the largest launch seen).  The rows
- * belong to the net handle (the first net of a pair): forward calls of ONE such handle must not overlap on different
- * streams -- give every stream its own handle, as caro_ai_amd.engine.StreamedSelfPlay does. */
+ * are kept per (net handle, stream) -- the first net's, for a pair -- so launches of one handle on different streams may
+ * overlap; a handle serves at most 8 streams, and host calls on one handle are not thread-safe. */
 int caro_net_winograd2d_size(void);
 int caro_net_winograd2d_supported(int H, int W);
 int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_floats);
