@@ -461,11 +461,12 @@ class Leg:
                         "avg_launch_us": avg_s * 1e6, "launches_timed": n, "leaves_per_launch": leaves_per_launch,
                         "flops_per_leaf": flops_per_leaf,
                         "clock_note": "peak is the guide's figure at 2.4 GHz. Workgroup clocks stamped inside the engine's "
-                                      "own launches (tools/probe_engine_net.py, profiles/r04_engine_launch_pair_timeline"
-                                      ".txt; not measured in this run) put the shader clock under this kernel at "
-                                      "2.08-2.11 GHz in steady state (2.36 GHz in a first launch): a workgroup's 312 k "
-                                      "cycles are the whole launch, there is no dispatch tail. At that clock the matrix "
-                                      "pipe's peak is 137.6 TFLOP/s"}
+                                      "own launches (profiles/r04_net_launch_clock.txt; not measured in this run): in steady "
+                                      "state a workgroup's 312 k cycles take 132 us at 2.36-2.37 GHz; the first milliseconds "
+                                      "after an idle gap (a host synchronisation) run at 2.1 GHz and climb. avg_launch_us is "
+                                      "above that because it averages in the 7.5 % of launches whose leaf count exceeds one "
+                                      "round of full tiles (1 536) and pay a second, short round (mean 190 us), and the event "
+                                      "pair's own gap"}
             kernel_us += S * avg_s * 1e6
         if roofline is None:  # torch evaluators: the net is not our kernel; the tree walk is the dominant own kernel
             roofline = roofline_tree
