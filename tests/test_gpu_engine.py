@@ -123,6 +123,49 @@ def test_rules_kernels_vs_reference(name):
         assert np.packbits(planes[i].astype(np.uint8)).tobytes().hex() == r["planes"]
 
 
+@pytest.mark.parametrize("name", ["c4", "ttt3", "mnk15"])
+def test_rules_kernels_vs_reference_digests(name):
+    """SURVEY 8(c) G1 at its stated size (tests/golden/make_golden_r5.py: 10^5 random connect-four plies, 10^4 each for
+    3x3 and 15x15 k=5 played through the REFERENCE's game classes, one SHA-256 per 1000-ply block over next state, won,
+    legal mask, planes).  The blocks are walked through this package's BaseGame shim (the host helpers of
+    caro_rules.h); everything the digest absorbs comes from the batched rule KERNELS on all plies of the set at once."""
+    import hashlib
+    from caro_ai_amd import _lib
+    from tests import rules_digest as rd
+    L = _lib.load()
+    d = load_golden("rules_digest.json.gz")
+    s = d["sets"][name]
+    game = _game_of(s)
+    A, HW, nb, bl = game.action_space, game.obs_shape[1] * game.obs_shape[2], len(s["blocks"]), d["block"]
+    recs, tallies = [], []
+    for b in range(nb):
+        tallies.append(rd.playout_block(game, d["seed"], b, bl, A, lambda s_, lg, m, p, s2, won: recs.append((s_, m, p))))
+    M = len(recs)
+    assert M == nb * bl == (100000 if name == "c4" else 10000)
+    keys = torch.from_numpy(game.to_keys([r[0] for r in recs]).view(np.int64)).to(DEV)
+    moves = torch.tensor([r[1] for r in recs], dtype=torch.int32, device=DEV)
+    players = torch.tensor([r[2] for r in recs], dtype=torch.int32, device=DEV)
+    legal = torch.zeros((M, A), dtype=torch.uint8, device=DEV)
+    _lib.check(L.caro_rules_legal_batch(game.kind, game.n, game.k, M, keys.data_ptr(), legal.data_ptr(), None))
+    won = torch.zeros(M, dtype=torch.int32, device=DEV)
+    full = torch.zeros(M, dtype=torch.int32, device=DEV)
+    _lib.check(L.caro_rules_move_batch(game.kind, game.n, game.k, M, keys.data_ptr(), moves.data_ptr(),
+                                       players.data_ptr(), won.data_ptr(), full.data_ptr(), None))
+    who = (1 - players).contiguous()
+    planes = torch.zeros((M, 2 * HW), dtype=torch.float32, device=DEV)
+    _lib.check(L.caro_rules_encode_batch(game.kind, game.n, game.k, M, keys.data_ptr(), who.data_ptr(),
+                                         planes.data_ptr(), None))
+    torch.cuda.synchronize()
+    legal, won = legal.cpu().numpy(), won.cpu().numpy()
+    planes = planes.cpu().numpy().astype(np.uint8)
+    new_states = game.from_keys(keys.cpu().numpy().view(np.uint64))
+    for b, want in enumerate(s["blocks"]):
+        h = hashlib.sha256()
+        for i in range(b * bl, (b + 1) * bl):
+            rd.absorb(h, new_states[i], bool(won[i]), np.flatnonzero(legal[i]), A, planes[i])
+        assert {"sha256": h.hexdigest(), "wins": tallies[b][0], "draws": tallies[b][1]} == want, (name, b)
+
+
 # ------------------------------------------------------------------ engine vs recorded reference games
 def _play_and_check_golden(d, g, form, explicit_noise=False, **engine_kw):
     from oracle.oracle import noise_row
@@ -181,6 +224,16 @@ def test_engine_replays_reference_games(name, form):
     (synthetic table net, noise generated on device from the spec)."""
     d = load_golden(name)
     for g in d["games"]:
+        _play_and_check_golden(d, g, form)
+
+
+def test_engine_replays_reference_drawn_games(form):
+    """whole games recorded from the reference that end in a DRAW (tests/golden/make_golden_r5.py; ref
+    lib/utils.py:86-96, lib/mcts.py:144-146), one store and one store per player: root N / W / Q / nodes / pi / z"""
+    d = load_golden("draws_ttt3.json.gz")
+    assert len(d["games"]) >= 3
+    for g in d["games"]:
+        assert g["result"] == 0 and set(g["z"]) == {0}
         _play_and_check_golden(d, g, form)
 
 

@@ -424,6 +424,66 @@ def test_real_weights_gpu_net_arena_800_sims(inference):
     assert followed >= 6
 
 
+@pytest.mark.parametrize("name,inference", [("arena_c4_320_x16.json.gz", "hipw"), ("arena_c4_800_x16.json.gz", "hipw"),
+                                            ("arena_c4_800_x16.json.gz", "hip")])
+def test_arena_32_recorded_games_gpu_net(name, inference):
+    """SURVEY 8(c) G5 (tests/golden/make_golden_r5.py): 16 + 16 seeded tau = 0 arena games best_026 vs best_025 recorded
+    from the reference at play.py's 40 x 8 and config 5's 100 x 8 sims/move, all 16 of a set in one engine, both nets
+    in one launch.  Stated tolerance as above; and the W / L / D tally is the reference's whenever every game
+    followed the recorded moves."""
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    d = load_golden(name)
+    g = ConnectFour()
+    n1, n2 = _real_nets(g, d["weights"])
+    gm0 = d["games"][0]
+    assert [gm["uid"] for gm in d["games"]] == list(range(gm0["uid"], gm0["uid"] + 16))
+    eng = SelfPlayEngine(g, 16, net1=n1, net2=n2, n_stores=2, max_batch=8, inference=inference, seed=gm0["seed"],
+                         steps_before_tau_0=0, uid_base=gm0["uid"], first_player_mode=2, searches_hint=gm0["searches"])
+    total, same, max_dpi, followed, log = _compare_with_recorded_games(d, eng, g, max(gm["plies"] for gm in d["games"]))
+    eng.close()
+    print("\n".join(log))
+    print("%s %s: identical root-N plies %d / %d, max |dpi| elsewhere %.4f, %d / 16 games followed to the end"
+          % (name, inference, same, total, max_dpi, followed))
+    assert total >= 200 and same / total >= 0.99 and max_dpi <= 0.15
+    assert followed >= 14
+
+
+def test_arena_32_recorded_games_exact_with_reference_net_arithmetic():
+    """the same 32 games, the first four of each set EXACTLY: HIP tree walk (two stores, two evaluators) + the
+    reference's net arithmetic (torch CPU forward on the same leaf batches) -- root N, pi, z, result, steps"""
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    torch.set_num_threads(1)
+    g = ConnectFour()
+    for name in ("arena_c4_320_x16.json.gz", "arena_c4_800_x16.json.gz"):
+        d = load_golden(name)
+        nets = []
+        for w in d["weights"]:
+            n = Net(g.obs_shape, g.action_space)
+            n.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", w), map_location="cpu"))
+            nets.append(n)
+        res = []
+        for gm in d["games"][:4]:
+            eng = SelfPlayEngine(g, 1, evaluators=[_cpu_torch_evaluator(n) for n in nets], n_stores=2,
+                                 max_batch=gm["batch"], steps_before_tau_0=0, seed=gm["seed"], uid_base=gm["uid"],
+                                 node_cap=gm["searches"] * gm["batch"] * gm["plies"] + 64)
+            eng.reset([gm["first_player"]])
+            for ply in range(gm["plies"]):
+                assert str(g.from_key(eng.roots()[0][0])) == gm["states"][ply]
+                eng.search(gm["searches"], gm["batch"])
+                pi, counts = eng.policy()
+                assert counts[0].cpu().tolist() == gm["trace"][ply]["N"], (gm["uid"], ply)
+                assert pi[0].cpu().numpy().tolist() == gm["pi"][ply]
+                eng.step()
+            dr = eng.drain(recycle=False)
+            uid, first, result, steps = dr["games"][0].cpu().tolist()
+            assert (result, steps) == (gm["result"], gm["steps"])
+            assert dr["z"].cpu().tolist() == gm["z"][::-1]
+            eng.close()
+
+
 # ------------------------------------------------------------------ BASELINE config 4: 15 x 15, k = 5, 50 x 8 sims/move
 def _seeded_net_15(d):
     """the repo's own Net under the committed seed -- the state_dict the reference's Net was

@@ -397,3 +397,62 @@ def test_evaluate_pair_of_stores_across_rounds_vs_reference():
     _replay_on_persistent_stores(o, d["rounds"], d["steps_before_tau_0"], d["searches"], d["batch"], True)
     res = [g["result"] for g in d["rounds"]]
     assert d["win_ratio"] == res.count(1) / len(res)
+
+
+# --------------------------------------------------------------- round 5: draws, G1 at SURVEY's size, G5 (make_golden_r5.py)
+def test_drawn_games_vs_reference():
+    """ref lib/utils.py:86-96 (no legal move left => result 0, every z 0) and lib/mcts.py:144-146 (a full board met
+    inside the tree backs up 0.0): whole TicTacToe(3,3) games recorded from the reference that END IN A DRAW -- 25x1,
+    10x8, 25x4 on one store, 10x8 and 20x16 on one store per player -- root N / nodes / pi / z bit exact"""
+    d = load_golden("draws_ttt3.json.gz")
+    assert len(d["games"]) >= 3
+    shapes = set()
+    for g in d["games"]:
+        assert g["result"] == 0 and g["plies"] == 9 and g["steps"] == 8 and set(g["z"]) == {0}
+        shapes.add((g["searches"], g["batch"], g["n_stores"]))
+        o = make_oracle(d, g["n_stores"])
+        res = _check_game(o, g, lambda oo: oo.use_synth_net())
+        assert res["result"] == 0 and not res["z"].any()
+    assert len(shapes) >= 3 and any(s[2] == 2 for s in shapes)
+
+
+@pytest.mark.parametrize("name", ["c4", "ttt3", "mnk15"])
+def test_rules_digest_vs_reference(name):
+    """SURVEY 8(c) G1 at its stated size -- 10^5 random connect-four plies, 10^4 each for 3x3 and 15x15 k=5, played
+    through the reference's game classes and kept as one SHA-256 per 1000-ply block over (next state, won, legal mask,
+    planes): the oracle walks the same blocks and must produce the same digests"""
+    from tests import rules_digest as rd
+    d = load_golden("rules_digest.json.gz")
+    s = d["sets"][name]
+    o = make_oracle(s)
+    assert len(s["blocks"]) * d["block"] == (100000 if name == "c4" else 10000)
+    for b, want in enumerate(s["blocks"]):
+        assert rd.block_digest(o, d["seed"], b, d["block"], o.A) == want, (name, b)
+
+
+@pytest.mark.parametrize("name", ["arena_c4_320_x16.json.gz", "arena_c4_800_x16.json.gz"])
+def test_arena_32_games_vs_reference(name):
+    """32 seeded tau = 0 arena games best_026 vs best_025, one store per player, recorded from the
+    reference -- 16 at play.py's 40 x 8 sims/move (ref play.py:47-52, config.py:18-19), 16 at BASELINE config 5's
+    100 x 8: the oracle driving the same torch CPU forward reproduces every ply's root N (= the argmax move), pi, z,
+    and the W / L / D tally"""
+    d = load_golden(name)
+    assert len(d["games"]) == 16
+    res = []
+    nets = None
+    for g in d["games"]:
+        assert g["steps_before_tau_0"] == 0 and g["n_stores"] == 2 and g["first_player"] == g["uid"] & 1
+        o = make_oracle(d, 2)
+        if nets is None:
+            nets = [_torch_net(w, (2, o.rows, o.cols), o.A) for w in d["weights"]]
+
+        def setup(oo):
+            oo.set_net(0, nets[0])
+            oo.set_net(1, nets[1])
+
+        r = _check_game(o, g, setup)
+        for ply in range(g["plies"]):  # tau = 0: pi is the one-hot of the first maximum of N
+            n = g["trace"][ply]["N"]
+            assert g["pi"][ply].index(1.0) == n.index(max(n)) and sum(g["pi"][ply]) == 1.0
+        res.append(r["result"])
+    assert {"wins": res.count(1), "losses": res.count(-1), "draws": res.count(0)} == d["tally"]
