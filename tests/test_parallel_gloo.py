@@ -122,6 +122,53 @@ def test_two_rank_gloo():
     assert res[0]["wld"] == res[1]["wld"] == (allr.count(1), allr.count(-1), allr.count(0))
 
 
+def test_eight_rank_gloo():
+    """BASELINE config 3's world size (8 ranks): uid sharding over three recycle generations, the
+    variable-length gather and the batched exchange with ranks that have no rows in a flush, ONE-buffer weight
+    broadcast, counter all-reduces, round shares with an idle rank (7 rounds over 8 ranks)"""
+    world = 8
+    counts = [(5, 3, 0, 2, 7, 1, 0, 4), (0, 4, 1, 0, 0, 3, 2, 0), (0,) * 8]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, counts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # uids: slot g of rank r plays r*G + g + k * world*G -- the 8 ranks' sets are disjoint and tile [0, 3 * 8 * 4)
+    alluids = [u for r in range(world) for u in res[r]["uids"]]
+    assert len(set(alluids)) == len(alluids) == 96 and sorted(alluids) == list(range(96))
+    for r in range(world):
+        assert min(res[r]["uids"]) == 4 * r and all((u % 32) // 4 == r for u in res[r]["uids"])
+    cat = lambda rows: torch.cat(rows) if rows else None
+    for rnd, cnt in enumerate(counts):
+        exp = [_fake_tuples(r * 10 + rnd, cnt[r]) for r in range(world)]
+        for rank in range(world):
+            got = res[rank]["gather%d" % rnd]
+            assert got["z"].shape[0] == sum(cnt)
+            for k in ("states", "players", "z"):  # rank-major concatenation of the ranks' rows
+                np.testing.assert_array_equal(got[k], cat([e[k] for e in exp]).numpy())
+            np.testing.assert_array_equal(got["pi"], cat([e["pi"] for e in exp]).float().numpy())
+    # batched exchange (every 2nd move): moves 0+1 in one message -- rank 2 contributes 0+1 rows, rank 6 0+2, rank 3
+    # 2+0 --, move 2 is empty on every rank and the closing flush returns nothing
+    for rank in range(world):
+        got = res[rank]["batched"]
+        assert len(got) == 1 and got[0]["z"].shape[0] == sum(counts[0]) + sum(counts[1])
+        for k in ("states", "players", "z", "pi"):
+            e = torch.cat([torch.cat([_fake_tuples(r * 10 + rnd, counts[rnd][r])[k] for rnd in (0, 1)])
+                           for r in range(world)])
+            np.testing.assert_array_equal(got[0][k], (e.float() if k == "pi" else e).numpy())
+    assert len({res[r]["wsum"] for r in range(world)}) == 1
+    for r in range(world):
+        assert res[r]["sum"] == [36, 360, 24] and res[r]["max"] == [8, 80, 3]
+    assert sum((res[r]["rounds"] for r in range(world)), []) == list(range(7)) and res[7]["rounds"] == []
+    allr = [(-1, 0, 1)[u % 3] for u in range(7)]
+    assert all(res[r]["wld"] == (allr.count(1), allr.count(-1), allr.count(0)) for r in range(world))
+
+
 def test_single_process_paths_are_noops():
     from caro_ai_amd import parallel
     assert not parallel.is_dist()
