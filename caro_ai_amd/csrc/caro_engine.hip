@@ -56,6 +56,9 @@ enum Counter { C_SIMS, C_LEVELS, C_EXPANSIONS, C_TERMINALS, C_DROPPED, C_OVERFLO
 struct View {
   GameParams gp;
   int G, n_stores, n_nets, cap, hcap, A, HW, maxply, maxd, maxB, sbt0, first_mode, ntab, etab;
+  int tstride;        // slots from one key / row table to the next: hcap + a skew (tables are not 2^k apart in memory)
+  uint32_t slot_rot;  // tree t's home slots are rotated by t * slot_rot (0: off): the same board sits in a different
+                      // slot -- another L2 set / channel -- of every tree.  Slot ids carry no meaning: result-neutral
   float c_puct;
   double alpha, explore;
   uint64_t seed, uid_base, uid_stride;
@@ -135,19 +138,19 @@ __device__ __forceinline__ void store_board(uint64_t* p, const typename R::Board
 
 // first slot of tree t's live table
 __device__ __forceinline__ size_t tbase(const View& v, int t) {
-  return (size_t)(t * v.ntab + (v.ntab == 2 ? v.tbl[t] : 0)) * (size_t)v.hcap;
+  return (size_t)(t * v.ntab + (v.ntab == 2 ? v.tbl[t] : 0)) * (size_t)v.tstride;
 }
 // first row of tree t's action rows: they follow the key table only where a second copy exists (etab == 2:
 // eviction moves the survivors' rows; a staggered restart needs a clean KEY table, the rows are rewritten anyway)
 __device__ __forceinline__ size_t ebase(const View& v, int t) {
-  return (size_t)(t * v.etab + (v.etab == 2 ? v.tbl[t] : 0)) * (size_t)v.hcap;
+  return (size_t)(t * v.etab + (v.etab == 2 ? v.tbl[t] : 0)) * (size_t)v.tstride;
 }
 
 constexpr uint64_t EMPTY_KEY = ~0ULL;  // no board has bit 63 set (C4) / overlapping planes (m,n,k)
 
 template <class R>
-__device__ __forceinline__ uint32_t home_slot(const View& v, const typename R::Board& b) {
-  return (uint32_t)R::hash(b) & ((uint32_t)v.hcap - 1u);
+__device__ __forceinline__ uint32_t home_slot(const View& v, int t, const typename R::Board& b) {
+  return ((uint32_t)R::hash(b) + (uint32_t)t * v.slot_rot) & ((uint32_t)v.hcap - 1u);
 }
 
 // Everything the per-game kernels need to know about game g that depends on g alone, loaded in ONE round of
@@ -181,10 +184,10 @@ __device__ __forceinline__ GameRegs<GEO> load_game(const View& v, int g) {
 }
 // tbase / ebase with the table selector in hand
 __device__ __forceinline__ size_t tbase_sel(const View& v, int t, int sel) {
-  return (size_t)(t * v.ntab + sel) * (size_t)v.hcap;
+  return (size_t)(t * v.ntab + sel) * (size_t)v.tstride;
 }
 __device__ __forceinline__ size_t ebase_sel(const View& v, int t, int sel) {
-  return (size_t)(t * v.etab + (v.etab == 2 ? sel : 0)) * (size_t)v.hcap;
+  return (size_t)(t * v.etab + (v.etab == 2 ? sel : 0)) * (size_t)v.tstride;
 }
 
 // Synchronisation inside a per-game block.  ONE = the block's tree work is done by ONE wavefront (the fused kernels):
@@ -224,14 +227,14 @@ __device__ __forceinline__ int probe_from(const View& v, int t, const typename R
 }
 template <class R>
 __device__ __forceinline__ int probe(const View& v, int t, const typename R::Board& b) {
-  return probe_from<R>(v, t, b, home_slot<R>(v, b));
+  return probe_from<R>(v, t, b, home_slot<R>(v, t, b));
 }
 
 // first free slot from the board's home slot; writes the key; returns the slot (-1: table full)
 template <class R>
 __device__ __forceinline__ int insert_key(const View& v, int t, const typename R::Board& b) {
   const uint32_t mask = (uint32_t)v.hcap - 1u;
-  uint32_t i = home_slot<R>(v, b);
+  uint32_t i = home_slot<R>(v, t, b);
   uint64_t* keys = v.node_key + tbase(v, t) * R::KW;
   for (int it = 0; it < v.hcap; ++it) {
     uint64_t* k = keys + (size_t)i * R::KW;
@@ -371,7 +374,7 @@ __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, in
                                               uint4* lprec, int l, int first, const double* nz, NodeRow<GEO>& r) {
   using R = typename GEO::R;
   constexpr int LPD = GEO::LPD, APL = GEO::APL, KW = GEO::KW;
-  if (!ROOT) load_row<GEO, true>(r, tkeys, tedges, home_slot<R>(v, d.cur), l);  // the root's row is loaded by the caller
+  if (!ROOT) load_row<GEO, true>(r, tkeys, tedges, home_slot<R>(v, t, d.cur), l);  // the root's row is loaded by the caller
   uint32_t(&nraw)[APL] = r.nraw;
   uint32_t(&wraw)[APL] = r.wraw;
   float(&q)[APL] = r.q;
@@ -571,7 +574,7 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
   // the root's row is requested first; the descent's Dirichlet row (only used if the root is in the tree) is
   // generated while it is on its way
   NodeRow<GEO> r;
-  load_row<GEO, true>(r, tkeys, tedges, home_slot<R>(v, d.cur), l);
+  load_row<GEO, true>(r, tkeys, tedges, home_slot<R>(v, t, d.cur), l);
   double nz[APL];
   if (noise) {
 #pragma unroll
@@ -1385,7 +1388,7 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
   // get_policy_value (mcts.py:289-313): the root's visit counts -- its key and its N row are requested together from
   // the home slot (one latency); a collision falls back to the probe sequence
   {
-    const uint32_t hs = home_slot<R>(v, root);
+    const uint32_t hs = home_slot<R>(v, t, root);
     const uint64_t* kp = v.node_key + (tbase_sel(v, t, tsel) + hs) * KW;
     const uint32_t* erow = v.edges + ebase_sel(v, t, tsel) * 4 * AP;
     uint32_t nraw[(AP + 63) / 64];
@@ -1550,7 +1553,7 @@ __global__ void k_evict(View v) {
   for (int st = 0; st < v.n_stores; ++st) {
     const int t = g * v.n_stores + st;
     const int live = v.tbl[t];
-    const size_t ob = (size_t)(t * 2 + live) * v.hcap, nb = (size_t)(t * 2 + (1 - live)) * v.hcap;
+    const size_t ob = (size_t)(t * 2 + live) * v.tstride, nb = (size_t)(t * 2 + (1 - live)) * v.tstride;
     uint64_t* okeys = v.node_key + ob * KW;
     uint64_t* nkeys = v.node_key + nb * KW;
     const uint32_t mask = (uint32_t)v.hcap - 1u;
@@ -1563,7 +1566,7 @@ __global__ void k_evict(View v) {
       const Board b = load_board<R>(k);
       k[0] = EMPTY_KEY;  // the old table ends up empty
       if (!v.done[g] && R::contains(v.gp, b, root)) {
-        uint32_t j = (uint32_t)R::hash(b) & mask;
+        uint32_t j = home_slot<R>(v, t, b);
         for (int it = 0; it < v.hcap; ++it) {  // claim a slot: all inserted keys are distinct
           unsigned long long* w0 = (unsigned long long*)(nkeys + (size_t)j * KW);
           if (atomicCAS(w0, (unsigned long long)EMPTY_KEY, (unsigned long long)b.w[0]) == (unsigned long long)EMPTY_KEY) break;
@@ -1593,8 +1596,10 @@ __device__ __forceinline__ void reset_game(const View& v, int g, uint64_t uid, i
   constexpr int KW = GEO::KW;
   for (int s = 0; s < v.n_stores; ++s) {
     const int t = g * v.n_stores + s;
-    uint64_t* keys = v.node_key + (size_t)t * v.ntab * v.hcap * KW;
-    for (int i = threadIdx.x; i < v.ntab * v.hcap * KW; i += blockDim.x) keys[i] = EMPTY_KEY;
+    for (int tb = 0; tb < v.ntab; ++tb) {
+      uint64_t* keys = v.node_key + (size_t)(t * v.ntab + tb) * v.tstride * KW;
+      for (int i = threadIdx.x; i < v.hcap * KW; i += blockDim.x) keys[i] = EMPTY_KEY;
+    }
     if (threadIdx.x == 0) {
       v.n_nodes[t] = 0;
       v.n_created[t] = 0;
@@ -1814,7 +1819,7 @@ __global__ void k_stag_clean(View v) {
   constexpr int KW = GEO::KW;
   const int t = blockIdx.x;
   if (!v.dirty[t]) return;
-  uint64_t* keys = v.node_key + (size_t)(t * 2 + (1 - v.tbl[t])) * v.hcap * KW;
+  uint64_t* keys = v.node_key + (size_t)(t * 2 + (1 - v.tbl[t])) * v.tstride * KW;
   for (int i = threadIdx.x; i < v.hcap * KW; i += blockDim.x) keys[i] = EMPTY_KEY;
   if (threadIdx.x == 0) v.dirty[t] = 0;
 }
@@ -2361,13 +2366,19 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   int hc = 64;
   while (hc < 2 * v.cap) hc <<= 1;
   v.hcap = hc;
+  {
+    const char* e = getenv("CARO_TREE_SKEW");
+    v.tstride = hc + (e ? atoi(e) : 0);
+    e = getenv("CARO_SLOT_ROT");
+    v.slot_rot = e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
+  }
   const int KW = variant_kw(var), AP = variant_ap(var);
   const size_t T = (size_t)v.G * v.n_stores, G = (size_t)v.G;
   int rc = 0;
 #define DA(p, n) if ((rc = dalloc(h, &p, (n))) != 0) { caro_engine_destroy(h); return rc; }
   DA(v.tbl, T);
-  DA(v.node_key, T * v.ntab * v.hcap * KW);
-  DA(v.edges, T * v.etab * v.hcap * 4 * AP);
+  DA(v.node_key, T * v.ntab * v.tstride * KW);
+  DA(v.edges, T * v.etab * v.tstride * 4 * AP);
   DA(v.n_nodes, T);
   DA(v.n_created, T);
   DA(v.root, G * KW);

@@ -52,6 +52,8 @@ def torch_evaluator(net, form="gemm"):
 
 
 class SelfPlayEngine:
+    VIEW_LIMIT_BYTES = 16 << 20  # drains whose staging block is larger hand out copies of the finished rows (drain_end)
+
     def __init__(self, game, n_games, net1=None, net2=None, evaluators=None, n_stores=1, max_batch=None,
                  node_cap=None, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, first_player_mode=2,
                  c_puct=cfg.C_PUCT, alpha=cfg.ALPHA, explore=cfg.EXPLORE, seed=0, uid_base=0, uid_stride=None,
@@ -120,6 +122,7 @@ class SelfPlayEngine:
         _lib.check(self.L.caro_leaf_counts_dev(self.h, C.byref(cd)))
         self._counts_dev = cd
         self.maxply = self.HW
+        self._row_bytes = 8 * self.KW + 8 * self.A + 8  # one drained tuple: state words, float64 pi, player, z
         self.net_rows = 0
         self.net_calls = 0
         self._prof = False
@@ -272,7 +275,15 @@ class SelfPlayEngine:
         nt, ng = nt.value, ng.value
         if nt == 0 and ng == 0:
             return {"states": s[:0], "players": p[:0], "pi": pi[:0], "z": z[:0], "games": games[:0]}
-        return {"states": s[:nt], "players": p[:nt], "pi": pi[:nt], "z": z[:nt], "games": games[:ng]}
+        out = {"states": s[:nt], "players": p[:nt], "pi": pi[:nt], "z": z[:nt], "games": games[:ng]}
+        # A view keeps the WHOLE staging allocation alive.  Connect four: 3 MB, nothing.  15 x 15: G * 225 rows of
+        # 1.8 KB = 106 MB per drain at 256 games, of which a move's finished games fill a few percent -- a consumer
+        # that keeps its tuples (TupleGatherer, a replay buffer) would pin gigabytes.  There the rows are copied out
+        # (a move of that board takes > 100 ms: five small copies do not show) and the staging block goes back.
+        if s.shape[0] * self._row_bytes > self.VIEW_LIMIT_BYTES and 4 * nt < s.shape[0]:
+            out = {k: v.clone() for k, v in out.items()}
+            self._dr = None
+        return out
 
     def drain(self, recycle=True, cap=None):
         """Finished games -> tuples (device tensors of their own: later drains do not touch them), in the

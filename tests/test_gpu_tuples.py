@@ -252,3 +252,49 @@ def test_same_seed_same_bits_15x15_conv_net_in_the_engine():
     b, cb = run()
     assert ca == cb and ca["overflows"] == 0 and ca["expansions"] > 0.8 * ca["sims"]
     assert a == b
+
+
+def test_kept_drains_do_not_pin_the_staging_block_on_large_boards(monkeypatch):
+    """a drain's rows are views of a staging block sized for every game finishing at its longest
+    (G * H*W rows); on 15 x 15 that is 1.8 KB x 225 x G per drain, and whoever keeps the tuples of every move
+    (TupleGatherer, a replay buffer) would pin all of it.  Above `VIEW_LIMIT_BYTES` a drain hands out copies of the
+    finished rows: kept drains own what they hold, memory stays bounded, and the rows are the plain path's."""
+    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.net_hip import HashNet
+    game = TicTacToe(15, 5)
+    G, S, B = 64, 1, 8
+
+    def run(limit):
+        if limit is not None:
+            monkeypatch.setattr(SelfPlayEngine, "VIEW_LIMIT_BYTES", limit)
+        eng = SelfPlayEngine(game, G, evaluators=[HashNet(game, device=DEV)], max_batch=B, steps_before_tau_0=400,
+                             seed=5, device=DEV, node_cap=2048)
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        kept, peak = [], 0
+        for _ in range(260):
+            eng.search(S, B)
+            eng.step()
+            kept.append(eng.drain(recycle=True))
+            peak = max(peak, torch.cuda.memory_allocated() - base)
+        rows = sum(int(d["z"].shape[0]) for d in kept)
+        held = sum(v.untyped_storage().nbytes() for v in {id(v.untyped_storage()): v for d in kept
+                                                           for v in d.values()}.values())
+        out = [_host(d) for d in kept]
+        eng.close()
+        return rows, held, peak, out
+
+    staging = G * 225 * (8 * game.key_words + 8 * 225 + 8)
+    assert staging > SelfPlayEngine.VIEW_LIMIT_BYTES
+    rows, held, peak, out = run(None)
+    assert rows > 300 and sum(d["z"].shape[0] > 0 for d in out) >= 5
+    payload = rows * (8 * game.key_words + 8 * 225 + 8)
+    assert held < 2 * payload + (1 << 20), (held, payload)          # kept drains own their rows, not 260 staging blocks
+    assert peak < 3 * staging + 2 * payload, (peak, staging, payload)
+    rows_v, held_v, _, out_v = run(1 << 40)                            # the view form, for comparison: same rows ...
+    assert rows_v == rows
+    for a, b in zip(out, out_v):
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert held_v > 10 * held                                         # ... and every non-empty drain pins its block
