@@ -279,8 +279,8 @@ def test_kept_drains_do_not_pin_the_staging_block_on_large_boards(monkeypatch):
             kept.append(eng.drain(recycle=True))
             peak = max(peak, torch.cuda.memory_allocated() - base)
         rows = sum(int(d["z"].shape[0]) for d in kept)
-        held = sum(v.untyped_storage().nbytes() for v in {id(v.untyped_storage()): v for d in kept
-                                                           for v in d.values()}.values())
+        held = sum({v.untyped_storage().data_ptr(): v.untyped_storage().nbytes()
+                    for d in kept for v in d.values() if v.numel()}.values())
         out = [_host(d) for d in kept]
         eng.close()
         return rows, held, peak, out
