@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
 MFMA_BF16_PEAK_TFS = 2500.0 # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
-PMC_FILE = os.path.join("profiles", "pmc_r04.json")
+PMC_FILE = os.path.join("profiles", "pmc_r05.json")
 CPU_RATIO_FILE = os.path.join("profiles", "cpu_ratio_r03.json")
 NET_KERNEL = {"hip": "k_net_forward", "hipw": "k_net_forward_w", "hip3x": "k_net_forward_3x"}
 
@@ -63,9 +63,32 @@ def host_cores():
     return n
 
 
+def pmc_status():
+    """(commit the PMC passes were taken on, None | why the counters may not be quoted).  The committed PMC file
+    carries the SHA-256 of the kernel sources it was measured on (tools/profile_r05.sh); counters of other sources
+    are not quoted: a kernel change without a new PMC pass must not carry stale numbers."""
+    try:
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
+    except Exception as e:
+        return None, "no PMC file (%s)" % e
+    want = d.get("source_sha256")
+    if not want:
+        return d.get("pmc_source_head"), "the PMC file does not say which sources it was taken on"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_sha import source_sha256
+    have = source_sha256(ROOT)
+    changed = sorted(f for f in set(want) | set(have) if want.get(f) != have.get(f))
+    if changed:
+        return d.get("pmc_source_head"), "kernel sources changed since the PMC pass (%s): counters not quoted" % ", ".join(changed)
+    return d.get("pmc_source_head"), None
+
+
 def load_pmc(section=None):
     """HBM bytes per launch and MFMA-busy fraction from the committed PMC passes (separate rocprofv3 --pmc runs of
-    this command, tools/profile_r04.sh), by kernel; section = None (headline) | "config5" | "config4" """
+    this command, tools/profile_r05.sh), by kernel; section = None (headline) | "config5" | "config4".  Empty when
+    the kernel sources are not the ones the passes were taken on (pmc_status)."""
+    if pmc_status()[1] is not None:
+        return {}
     try:
         d = json.load(open(os.path.join(ROOT, PMC_FILE)))
         d = d[section] if section else d
@@ -249,7 +272,8 @@ def dist_record(world, device, value_local, want_world):
 class Leg:
     """One BASELINE.json configuration: engine + nets + the move loop."""
 
-    def __init__(self, args, game_name, G, S, B, arena, rank, world, device, evict=None, node_cap=0):
+    def __init__(self, args, game_name, G, S, B, arena, rank, world, device, evict=None, node_cap=0, streams=None,
+                 stream_mask=None):
         from caro_ai_amd import parallel
         from caro_ai_amd.engine import SelfPlayEngine, StreamedSelfPlay, torch_evaluator
         from caro_ai_amd.lib.game.connect_four import ConnectFour
@@ -286,7 +310,8 @@ class Leg:
         else:
             fnet = {"gemm": GemmNet, "folded": FoldedNet, "net": lambda n: n}[args.net](net).to(device).eval()
             make_evaluators = lambda: [torch_evaluator(fnet, form="net")]
-        self.n_streams = args.streams if self.is_hip else 1
+        self.n_streams = (args.streams if streams is None else streams) if self.is_hip else 1
+        stream_mask = args.stream_mask if stream_mask is None else stream_mask
         common = dict(max_batch=B, steps_before_tau_0=self.sbt0, seed=0, device=str(device), searches_hint=S)
         # staggered mode (every game on its own minibatch clock: even leaf counts per launch, include/caro_hip.h):
         # wherever one wavefront serves a game and nothing needs the second key table
@@ -297,7 +322,7 @@ class Leg:
                                     **{**common, **extra, "searches_hint": 2})
         if self.n_streams > 1:
             self.eng = StreamedSelfPlay(self.game, G, make_evaluators, n_streams=self.n_streams,
-                                        partition_cus=bool(args.stream_mask), stagger=self.stagger, **common, **extra,
+                                        partition_cus=bool(stream_mask), stagger=self.stagger, **common, **extra,
                                         **parallel.shard(G, rank, world))
         else:
             self.eng = SelfPlayEngine(self.game, G, evaluators=make_evaluators(), stagger=self.stagger, **common,
@@ -390,30 +415,43 @@ class Leg:
         # FLOPs of one leaf through lib/model.py Net (2 x MAC): conv_in, 5 residual 3x3 convs, 1x1 heads, FC heads
         flops_per_leaf = 2.0 * (HW * 64 * 18 + 5 * HW * 64 * 576 + HW * 3 * 64 + 20 * HW + 20 + 2 * HW * A)
         traffic_note = ("HBM bytes per launch from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                        "configuration, tools/profile_r04.sh, corrected as MI355X_MICROARCH.md prescribes: read side "
+                        "configuration, tools/profile_r05.sh, corrected as MI355X_MICROARCH.md prescribes: read side "
                         "x2); not measured in this run" % PMC_FILE)
         kernel_us = 0.0
         roofline = roofline_tree = None
+        pmc_head, pmc_stale = pmc_status()
+        # An event pair by itself: the engine records a pair with NOTHING between its two records right behind every
+        # sampled net launch (kind "empty").  Its mean elapsed time is what bracketing adds to every sampled launch
+        # (~3 us: rocprofv3 saw 141.0 / 25.65 us where the pairs said 143.9 / 28.8) and is subtracted below.
+        gap_s = 0.0
+        if prof is not None and prof.get("empty", (0, 0))[1] > 0:
+            gap_s = prof["empty"][0] * 1e-3 / prof["empty"][1]
+        timing_note = ("HIP-event pairs on the launch stream around a sample of the launches (every 12th minibatch), "
+                       "minus the mean of the EMPTY pairs recorded beside them (%.2f us, %d pairs)"
+                       % (gap_s * 1e6, prof["empty"][1] if prof and "empty" in prof else 0))
         if prof is not None and prof["select"][1] > 0:
             ms, n = prof["select"]
-            avg_s = ms * 1e-3 / n        # timed on a sample of the launches (every 12th minibatch, all indices equally)
+            avg_s = max(ms * 1e-3 / n - gap_s, 1e-9)  # timed on a sample of the launches (every 12th minibatch, all indices equally)
             n_launches = steps * S * n_streams
             levels_per_launch = delta["levels"] / n_launches
             achieved = levels_per_launch * bytes_per_level / avg_s / 1e9
             fused = prof.get("compact", (0, 0))[1] == 0
             tname = ("k_tree_stag" if self.stagger else "k_tree") if fused else "k_select"
-            others = {k: (v[0] * 1e3 / v[1] if v[1] else None) for k, v in prof.items() if k not in ("select", "net")}
+            others = {k: (max(v[0] * 1e3 / v[1] - gap_s * 1e6, 0.0) if v[1] else None) for k, v in prof.items()
+                      if k not in ("select", "net", "empty")}
             roofline_tree = {"bound": "hbm", "kernel": tname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(tname, {}).get("hbm"),
                              "traffic_source": traffic_note if pmc.get(tname) else None,
                              "algorithmic_bytes_per_launch": levels_per_launch * bytes_per_level,
                              "avg_launch_us": avg_s * 1e6, "launches": n_launches, "launches_timed": n,
+                             "event_pair_gap_us": gap_s * 1e6, "timing": timing_note,
+                             "pmc_source_head": pmc_head, "pmc_stale": pmc_stale,
                              "levels_per_launch": levels_per_launch, "bytes_per_level": bytes_per_level,
                              "other_kernels_us": others}
             kernel_us += S * avg_s * 1e6 + sum(v for v in others.values() if v)
         if prof is not None and prof.get("net", (0, 0))[1] > 0:
             ms, n = prof["net"]
-            avg_s = ms * 1e-3 / n
+            avg_s = max(ms * 1e-3 / n - gap_s, 1e-9)
             leaves_per_launch = delta["expansions"] / (steps * S * n_streams)
             achieved = leaves_per_launch * flops_per_leaf / avg_s / 1e12
             # hip3x issues 6 bf16 MFMA flops per algorithmic flop: priced against the dense bf16 peak / 6
@@ -460,22 +498,32 @@ class Leg:
                         if pmc.get(kname, {}).get("mfma_busy") else None,
                         "avg_launch_us": avg_s * 1e6, "launches_timed": n, "leaves_per_launch": leaves_per_launch,
                         "flops_per_leaf": flops_per_leaf,
-                        "clock_note": "peak is the guide's figure at 2.4 GHz. Workgroup clocks stamped inside the engine's "
-                                      "own launches (profiles/r04_net_launch_clock.txt; not measured in this run): in steady "
-                                      "state a workgroup's 312 k cycles take 132 us at 2.36-2.37 GHz; the first milliseconds "
-                                      "after an idle gap (a host synchronisation) run at 2.1 GHz and climb. avg_launch_us is "
-                                      "above that because it averages in the 7.5 % of launches whose leaf count exceeds one "
-                                      "round of full tiles (1 536) and pay a second, short round (mean 190 us), and the event "
-                                      "pair's own gap"}
+                        "event_pair_gap_us": gap_s * 1e6, "timing": timing_note,
+                        "pmc_source_head": pmc_head, "pmc_stale": pmc_stale,
+                        "clock_note": "peak is the guide's figure at 2.4 GHz; in steady state the device holds 2.36-2.37 GHz "
+                                      "(workgroup clocks stamped inside the engine's own launches, "
+                                      "profiles/r04_net_launch_clock.txt; not measured in this run), the first milliseconds "
+                                      "after an idle gap (a host synchronisation) run at 2.1 GHz and climb."
+                                      + (" A full-tile workgroup of this leg is 312 k cycles = 132 us at that clock; "
+                                         "avg_launch_us is above it because it averages in the 7.5 % of launches whose leaf "
+                                         "count exceeds one round of full tiles (1 536) and pay a second, short round "
+                                         "(mean 190 us)." if section is None and kname == "k_net_forward_w" else "")}
             kernel_us += S * avg_s * 1e6
         if roofline is None:  # torch evaluators: the net is not our kernel; the tree walk is the dominant own kernel
             roofline = roofline_tree
         ms_per_step = dt * 1e3 / steps
         what = "arena matches (two nets, one tree per player)" if self.arena else "self-play games"
         board = "Connect4 6x7" if self.game_name == "c4" else "m,n,k 15x15 k=5"
-        netdesc = {"hip": "fused HIP MFMA kernel", "hipw": "fused HIP MFMA kernel, 3x3 convs in row-Winograd F(2,3) form,",
-                   "hip3x": "fused HIP kernel, 3x3 convs as 3-way split bf16 MFMA with f32 accumulate,",
-                   "gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net]
+        # named after the kernel this leg really launches (HipNet.mode: "hipw" picks the row or the 2-D form by board)
+        if self.hipnet is not None:
+            netdesc = {"f32": "fused HIP MFMA kernel k_net_forward, direct 3x3 convs,",
+                       "f32w1": "fused HIP MFMA kernel k_net_forward_w, 3x3 convs in row-Winograd F(2,3) form,",
+                       "f32w2": "fused HIP MFMA kernels k_net_forward_w2 + k_net_heads, 3x3 convs in 2-D Winograd "
+                                "F(2x2,3x3) form, FC heads batched 32 boards per workgroup,",
+                       "3xbf16": "fused HIP kernel k_net_forward_3x, 3x3 convs as 3-way split bf16 MFMA with f32 "
+                                 "accumulate,"}[self.hipnet.mode]
+        else:
+            netdesc = {"gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net]
         return {
             "value": exp_all / dt, "unit": "node-expansions/s", "steps": steps, "warmup": warmup,
             "ms_per_step": ms_per_step,
@@ -612,7 +660,12 @@ def main():
         # MID-GAME: --config4-warmup moves at full size first, so that trees are deep, eviction has work to do and
         # games finish inside the timed moves.
         for key, spec, st, wu in (("config5", dict(game_name="c4", G=512, S=100, B=8, arena=True), 6, 3),
-                                  ("config4", dict(game_name="gomoku15", G=1024, S=50, B=8, arena=False),
+                                  # config 4 on two streams of 512 games (no CU mask): a 15x15 net launch is 30 rounds of
+                                  # workgroups, the last one partly filled -- the other half's tree-side kernels run there.
+                                  # One board per net workgroup: a game's bits do not depend on the split
+                                  # (tests/test_gpu_tuples.py::test_gomoku15_games_do_not_depend_on_the_stream_split)
+                                  ("config4", dict(game_name="gomoku15", G=1024, S=50, B=8, arena=False, streams=2,
+                                                   stream_mask=0),
                                    args.config4_steps, args.config4_warmup)):
             try:
                 x = Leg(args, rank=rank, world=world, device=device, **spec)

@@ -2200,7 +2200,10 @@ struct caro_engine {
   long long prof_n[8];
 };
 
-enum ProfKind { PK_SELECT = 0, PK_COMPACT = 1, PK_EXPAND = 2, PK_STEP = 3, PK_NET = 4, PK_N = 8 };
+enum ProfKind { PK_SELECT = 0, PK_COMPACT = 1, PK_EXPAND = 2, PK_STEP = 3, PK_NET = 4, PK_EMPTY = 5, PK_N = 8 };
+// PK_EMPTY: an event pair with NOTHING between its records, taken right behind a sampled net launch -- what a pair
+// costs by itself on a busy stream (~3 us); the reader subtracts it from the kernels' averages
+static void prof_empty(caro_engine* h, hipStream_t st);
 
 static void prof_flush(caro_engine* h) {
   for (size_t i = 0; i < h->ev_used; ++i) {
@@ -2233,6 +2236,7 @@ static int prof_begin(caro_engine* h, int kind, hipStream_t st) {
 static void prof_end(caro_engine* h, int i, hipStream_t st) {
   if (i >= 0) (void)hipEventRecord(h->ev[2 * i + 1], st);
 }
+static void prof_empty(caro_engine* h, hipStream_t st) { prof_end(h, prof_begin(h, PK_EMPTY, st), st); }
 
 template <class T>
 static int dalloc(caro_engine* h, T** p, size_t n) {
@@ -2363,9 +2367,14 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   v.uid_base = cfg->uid_base;
   v.uid_stride = cfg->uid_stride ? cfg->uid_stride : (uint64_t)cfg->n_games;
   v.cap = cfg->node_cap > 0 ? cfg->node_cap : 4096;
+  // packing limits of the minibatch records: path_rec.x = node slot (24 bits) | action << 24 (8 bits), d_rec.x holds
+  // the path length and the leaf rank in 8 bits each -- a table of more than 2^24 slots would alias nodes silently
+  static_assert(MAXB <= 255, "leaf rank travels in 8 bits of d_rec.x");
+  if (v.cap > (1 << 23)) { delete h; return fail(CARO_E_INVAL, "node_cap too large: at most 2^23 nodes per tree (slot ids travel in 24 bits)"); }
   int hc = 64;
   while (hc < 2 * v.cap) hc <<= 1;
   v.hcap = hc;
+  if (v.A > 256 || v.maxd > 255) { delete h; return fail(CARO_E_INVAL, "board too large for the path records (actions < 256, depth <= 255)"); }
   {
     const char* e = getenv("CARO_TREE_SKEW");
     v.tstride = hc + (e ? atoi(e) : 0);
@@ -2548,6 +2557,7 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
       rc = caro_net_forward_pair_at(net0, net1, planes, counts, -1, max_rows, probs, values, stream);
     else rc = caro_net_forward(net0, planes, counts, 0, max_rows, probs, values, stream);
     prof_end(h, p0, st);
+    prof_empty(h, st);
     if (!rc && !fused) rc = caro_expand_backup(h, probs, values, stream);
     if (rc) { h->prof_gate = 1; return rc; }
   }
@@ -2591,6 +2601,7 @@ int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int la
     const int rc = caro_net_forward_slots(net0, h->v.n_nets == 2 ? net1 : nullptr, planes, cur, h->v.g_pack, h->v.G,
                                           batch, probs, values, stream);
     prof_end(h, p0, st);
+    prof_empty(h, st);
     if (rc) { h->prof_gate = 1; return rc; }
   }
   h->prof_gate = 1;

@@ -725,6 +725,20 @@ __device__ __forceinline__ void fetch_chunk(const float* ww, int c, unsigned wri
   for (int m = 0; m < WCH / 4 / NT; ++m) dma_b128(src + m * NT, dst + m * NT * 16);
 }
 
+// The same transfer addressed as UNIFORM base (a scalar register pair) + 32-bit lane offset: the lane holds one
+// register (16 tid) for the whole kernel instead of a 64-bit pointer per thread and the per-chunk address arithmetic
+// becomes scalar -- what k_net_forward_w2, which runs at its 256-register limit, uses (its pointer pairs were spilled).
+__device__ __forceinline__ void dma_b128_s(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void fetch_chunk_s(const float* ww, int c, unsigned wring, int tid) {
+  const char* base = reinterpret_cast<const char*>(ww) + (size_t)c * (WCH * 4);
+  const unsigned voff = (unsigned)tid * 16u;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(wring + (unsigned)(c % WNBUF) * (WCH * 4) + (unsigned)(tid >> 6) * 1024u);
+#pragma unroll
+  for (int m = 0; m < WCH / 4 / NT; ++m) dma_b128_s(base + m * NT * 16, voff, dst + m * NT * 16);
+}
+
 // the head parameters (heads_f32<true>) -> ring buffer 0 + HEAD_STAGE_AT, issued when that buffer has seen its last
 // chunk; over-reads up to 8 KiB past the block (the packed buffer is padded by a whole tap chunk)
 __device__ __forceinline__ void fetch_heads(const float* hp, int hspan, unsigned wring, int tid) {
@@ -1347,17 +1361,21 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
   // cells (2ty + u, 2tx + 1 - bh)
   const int xo = 2 * tx + bh, xp = 2 * tx + 1 - bh;
   const int g0 = ct * 8 + h;  // granule of channel group q is g0 + 2q
-  int orow[2], prow[2], okey[2], pkey[2];
+  // float index (into act) of channel group 0 of an output cell; group q sits at index ^ (8 q): its granule is
+  // (g0 + 2q) ^ key, g0 + 2q = g0 | 2q (g0 = 8 ct + h never carries into bits 1-2), so the XOR with 2q commutes with
+  // the key.  ONE index per cell instead of four addresses: the epilogue's eight + eight addresses held across the
+  // main loops were what the register allocator spilled (14 registers, reloaded one by one in front of their uses).
+  int oidx[2], pidx[2];
   bool ovalid[2], pvalid[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int y = 2 * ty + u;
     ovalid[u] = tvalid && y < H && xo < W;
     pvalid[u] = tvalid && y < H && xp < W;
-    orow[u] = y * W + xo;
-    prow[u] = y * W + xp;
-    okey[u] = (((xo + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
-    pkey[u] = (((xp + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
+    const int okey = (((xo + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
+    const int pkey = (((xp + 1) >> 1) & 7) | ((((y + 1) >> 1) & 1) << 3);
+    oidx[u] = (y * W + xo) * NF + ((g0 ^ okey) << 2);
+    pidx[u] = (y * W + xp) * NF + ((g0 ^ pkey) << 2);
   }
 
   f4v CA0, CA1, CA2, CA3, CB0, CB1, CB2, CB3;  // the 4 x 2 input cells of the operand set in flight
@@ -1397,7 +1415,7 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
       /*@CHUNK_BARRIER*/ __syncthreads();                                                                    \
     }                                                                                                        \
-    if (/*@FETCH_ON*/ c0 + (T) / 2 + 2 < W2NCHUNK) fetch_chunk(p.ww2, c0 + (T) / 2 + 2, wring, tid);         \
+    if (/*@FETCH_ON*/ c0 + (T) / 2 + 2 < W2NCHUNK) fetch_chunk_s(p.ww2, c0 + (T) / 2 + 2, wring, tid);       \
   }                                                                                                          \
   {                                                                                                          \
     const float sg_ = ((T) >> 3) ? sg1 : sg0;                                                                \
@@ -1479,12 +1497,13 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
     // ---- epilogue.  Requested in front of the barrier: the OLD values of this wave's output cells (the residual input;
     // only this wave ever writes these cells)
     float4 old0[4], old1[4];
-    float* own0 = act + orow[0] * NF;
-    float* own1 = act + orow[1] * NF;
+    // (the four indices are loop-invariant; "rewritten" here so that the per-group addresses are formed where they are
+    // used instead of living in sixteen registers through the main loops)
+    asm volatile("" : "+v"(oidx[0]), "+v"(oidx[1]), "+v"(pidx[0]), "+v"(pidx[1]));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      old0[q] = ovalid[0] ? *reinterpret_cast<const float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
-      old1[q] = ovalid[1] ? *reinterpret_cast<const float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      old0[q] = ovalid[0] ? *reinterpret_cast<const float4*>(act + (oidx[0] ^ (8 * q))) : make_float4(0.f, 0.f, 0.f, 0.f);
+      old1[q] = ovalid[1] ? *reinterpret_cast<const float4*>(act + (oidx[1] ^ (8 * q))) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // this wave's own share of its outputs, formed while the loads travel: bh 0: Z[b=0] + Z[b=1], bh 1: Z[b=2] + Z[b=3]
     f32x16 S0, S1;
@@ -1500,14 +1519,12 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
     asm volatile("" ::: "memory");
     /*@LST(layer, 5)*/
     {  // the partner's partial sums go into the partner's output cells
-      float* pr0 = act + prow[0] * NF;
-      float* pr1 = act + prow[1] * NF;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (pvalid[0])
-          *reinterpret_cast<float4*>(pr0 + (((g0 + 2 * q) ^ pkey[0]) << 2)) = make_float4(Zs0[4 * q], Zs0[4 * q + 1], Zs0[4 * q + 2], Zs0[4 * q + 3]);
+          *reinterpret_cast<float4*>(act + (pidx[0] ^ (8 * q))) = make_float4(Zs0[4 * q], Zs0[4 * q + 1], Zs0[4 * q + 2], Zs0[4 * q + 3]);
         if (pvalid[1])
-          *reinterpret_cast<float4*>(pr1 + (((g0 + 2 * q) ^ pkey[1]) << 2)) = make_float4(Zs1[4 * q], Zs1[4 * q + 1], Zs1[4 * q + 2], Zs1[4 * q + 3]);
+          *reinterpret_cast<float4*>(act + (pidx[1] ^ (8 * q))) = make_float4(Zs1[4 * q], Zs1[4 * q + 1], Zs1[4 * q + 2], Zs1[4 * q + 3]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1519,8 +1536,8 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
     const float sgn = bh ? -1.f : 1.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 r0 = ovalid[0] ? *reinterpret_cast<const float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 r1 = ovalid[1] ? *reinterpret_cast<const float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 r0 = ovalid[0] ? *reinterpret_cast<const float4*>(act + (oidx[0] ^ (8 * q))) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 r1 = ovalid[1] ? *reinterpret_cast<const float4*>(act + (oidx[1] ^ (8 * q))) : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 n0, n1;
       n0.x = old0[q].x + leaky(fmaf(sgn, S0[4 * q], r0.x), slope);
       n0.y = old0[q].y + leaky(fmaf(sgn, S0[4 * q + 1], r0.y), slope);
@@ -1530,8 +1547,8 @@ __device__ __forceinline__ void trunk_w2d(const NetParams& p, float* act, float*
       n1.y = old1[q].y + leaky(fmaf(sgn, S1[4 * q + 1], r1.y), slope);
       n1.z = old1[q].z + leaky(fmaf(sgn, S1[4 * q + 2], r1.z), slope);
       n1.w = old1[q].w + leaky(fmaf(sgn, S1[4 * q + 3], r1.w), slope);
-      if (ovalid[0]) *reinterpret_cast<float4*>(own0 + (((g0 + 2 * q) ^ okey[0]) << 2)) = n0;
-      if (ovalid[1]) *reinterpret_cast<float4*>(own1 + (((g0 + 2 * q) ^ okey[1]) << 2)) = n1;
+      if (ovalid[0]) *reinterpret_cast<float4*>(act + (oidx[0] ^ (8 * q))) = n0;
+      if (ovalid[1]) *reinterpret_cast<float4*>(act + (oidx[1] ^ (8 * q))) = n1;
     }
     // new activations visible to every wave; also the chunk barrier of the next layer's first chunk (this wave's share
     // of its second chunk has arrived, nobody reads this layer's last chunks any more)
@@ -1600,8 +1617,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w2(NetParams p0, NetParam
   float* win = wbuf + 2 * WCH;
   if (tid < 320) dma_b128(reinterpret_cast<const float4*>(p.w_in) + tid,
                           __builtin_amdgcn_readfirstlane(lds_addr(win) + (unsigned)(tid >> 6) * 1024u));
-  fetch_chunk(p.ww2, 0, lds_addr(wbuf), tid);
-  fetch_chunk(p.ww2, 1, lds_addr(wbuf), tid);
+  fetch_chunk_s(p.ww2, 0, lds_addr(wbuf), tid);
+  fetch_chunk_s(p.ww2, 1, lds_addr(wbuf), tid);
   for (int k = tid + (R * NF) / 4; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   static_assert(2 * (WCH / 4 / NT) == 8, "s_waitcnt vmcnt(8) below counts 2 chunks x WCH / 4 / NT transfers per thread");
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // conv_in's weights have arrived; the 2 x 4 chunk transfers may be on their way
@@ -1634,7 +1651,9 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w2(NetParams p0, NetParam
 // consecutive in the action), the value head Linear(HW,20) + LeakyReLU + Linear(20,1) + tanh as fma chains in the
 // reference's order, the softmax with sixteen threads per board.  One read of the policy matrix serves 32 boards.
 constexpr int HB = 32;               // boards per workgroup
+constexpr int HEADS_MAX_CELLS = 225;  // largest board k_net_heads is sized for (caro_net_winograd2d_supported)
 constexpr int HPL = 228;             // floats per staged feature plane (225 cells, rows 16-byte aligned)
+static_assert(HPL >= HEADS_MAX_CELLS && HPL % 4 == 0, "a staged feature plane holds every cell of the largest board");
 constexpr int HFS = 3 * HPL + 8;     // floats per staged board (692 = 52 mod 64: the 32 rows of an operand read spread over the banks)
 constexpr int HLG = 256;             // floats per logit row (A <= 255)
 __global__ __launch_bounds__(NT, 1) void k_net_heads(NetParams p0, NetParams p1, const int32_t* __restrict__ counts,
@@ -1643,7 +1662,7 @@ __global__ __launch_bounds__(NT, 1) void k_net_heads(NetParams p0, NetParams p1,
                                                        float* __restrict__ values) {
   __shared__ __attribute__((aligned(16))) float F[HB * HFS];
   __shared__ __attribute__((aligned(16))) float logit[HB * HLG];
-  __shared__ float wv1[20 * 225];
+  __shared__ float wv1[20 * HEADS_MAX_CELLS];
   __shared__ float hid[HB * 20];
   __shared__ float part[HB * 16];
   __shared__ float rsum[HB];
@@ -1687,6 +1706,7 @@ __global__ __launch_bounds__(NT, 1) void k_net_heads(NetParams p0, NetParams p1,
         }
       }
     }
+    static_assert(9 * NT >= 20 * HEADS_MAX_CELLS, "nine rounds of the block cover the value head's first matrix");
     float tw[9];
 #pragma unroll
     for (int u = 0; u < 9; ++u) tw[u] = tid + u * NT < 20 * HW ? p.w_v1[tid + u * NT] : 0.f;
@@ -2172,8 +2192,9 @@ struct caro_net {
   float* wpT_dev;      // policy matrix transposed, or null
   // f32w2 mode: the feature rows [rows][3][HW] that travel from k_net_forward_w2 to k_net_heads and the output row of
   // every dense board -- one set per stream the handle is launched on (launches on different streams may overlap)
-  struct HeadRows { void* stream; float* feat; int32_t* rowl; int64_t rows; } hrows[8];
+  struct HeadRows { void* stream; float* feat; int32_t* rowl; int64_t rows; uint64_t used; } hrows[8];
   int n_hrows;
+  uint64_t hrows_clock;  // launches through the table so far: `used` of a slot = the clock of its last launch (LRU)
   int device;
   unsigned long long* dbg_stamps;  // diagnostic (caro_net_debug_stamps): per-workgroup stamps of the slot launches too
 };
@@ -2234,6 +2255,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   n->ww2_dev = nullptr;
   n->wpT_dev = nullptr;
   n->n_hrows = 0;
+  n->hrows_clock = 0;
   const size_t pad = (size_t)cnet::TPC * cnet::WCHUNK;  // k_net_forward reads one chunk past the last tap
   if (hipMalloc((void**)&n->dev, (n_floats + pad) * sizeof(float)) != hipSuccess) {
     delete n;
@@ -2411,7 +2433,9 @@ int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats
  * One board per workgroup, its 2x2-output tiles in two 32-row MFMA blocks: boards of 12x12 .. 15x15 cells. */
 int caro_net_winograd2d_size(void) { return cnet::W2NCHUNK * cnet::WCH; }
 int caro_net_winograd2d_supported(int H, int W) {
-  return (255 / (H * W) == 1 && ((H + 1) / 2) <= 8 && ((W + 1) / 2) <= 8) ? 1 : 0;
+  // H*W <= HEADS_MAX_CELLS: k_net_heads stages HPL floats per feature plane and keeps 20 * 225 value-head weights
+  // in LDS -- a 15x16 board (240 cells, 8 x 8 tiles) would pass the tile test and overrun both
+  return (H * W >= 128 && H * W <= cnet::HEADS_MAX_CELLS && ((H + 1) / 2) <= 8 && ((W + 1) / 2) <= 8) ? 1 : 0;
 }
 int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_floats) {
   if (!n || !ww2_host) return nfail(CARO_E_INVAL, "null argument");
@@ -2467,6 +2491,7 @@ int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro
   n->ww2_dev = nullptr;
   n->wpT_dev = nullptr;
   n->n_hrows = 0;
+  n->hrows_clock = 0;
   n->p.H = H; n->p.W = W; n->p.HW = H * W; n->p.A = A; n->p.TB = 4;
   *out = n;
   return 0;
@@ -2497,10 +2522,20 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
       for (int k = 0; k < n0->n_hrows; ++k)
         if (n0->hrows[k].stream == stream) hr = &n0->hrows[k];
       if (!hr) {
-        if (n0->n_hrows == 8) return nfail(CARO_E_STATE, "a large-board net handle serves at most 8 streams");
-        hr = &n0->hrows[n0->n_hrows++];
+        if (n0->n_hrows == 8) {
+          // table full (a long-lived net launched on transient streams: engines recreated per iteration): the least
+          // recently used slot goes.  hipFree waits for the device, so nothing in flight still reads its rows.
+          hr = &n0->hrows[0];
+          for (int k = 1; k < 8; ++k)
+            if (n0->hrows[k].used < hr->used) hr = &n0->hrows[k];
+          if (hr->feat) (void)hipFree(hr->feat);
+          if (hr->rowl) (void)hipFree(hr->rowl);
+        } else {
+          hr = &n0->hrows[n0->n_hrows++];
+        }
         hr->stream = stream; hr->feat = nullptr; hr->rowl = nullptr; hr->rows = 0;
       }
+      hr->used = ++n0->hrows_clock;
       if (hr->rows < need) {
         if (hr->feat) (void)hipFree(hr->feat);
         if (hr->rowl) (void)hipFree(hr->rowl);

@@ -324,7 +324,7 @@ class SelfPlayEngine:
         ms = (C.c_double * 8)()
         n = (C.c_int64 * 8)()
         _lib.check(self.L.caro_profile_read(self.h, ms, n, 1 if reset else 0))
-        return {k: (ms[i], n[i]) for i, k in enumerate(["select", "compact", "expand_backup", "step", "net"])}
+        return {k: (ms[i], n[i]) for i, k in enumerate(["select", "compact", "expand_backup", "step", "net", "empty"])}
 
     def live_games(self):
         out = C.c_int32(0)

@@ -151,6 +151,33 @@ def staggered_ok(game, batch):
     return batch * lpd == 64
 
 
+def _self_play_loop(eng, game, n_games, G, searches, batch, stagger, restarts, st, slot_gen, last_gen, take):
+    """the moves of self_play until the wanted games have finished (separate so that self_play can close its engine,
+    and end the rank, on any failure)"""
+    if stagger:
+        # every pass of `searches` launches is one ply per game on average; a game has at most HW plies and sits out
+        # fewer than `searches` launches at the start: a bound on the passes that a healthy run never reaches
+        hw = game.obs_shape[1] * game.obs_shape[2]
+        max_passes = (hw + 4) * (-(-n_games // G)) + 8
+        passes = 0
+        while st["finished"] < n_games:
+            take(eng.move(searches, batch, recycle=restarts))  # host-pipelined: hands out the previous pass's rows
+            passes += 1
+            if passes > max_passes:
+                raise _lib.CaroError("self_play: %d of %d games finished after %d passes" % (st["finished"], n_games, passes))
+        take(eng.flush())
+    else:
+        while st["finished"] < n_games:
+            eng.search(searches, batch)
+            eng.step()
+            # restart drained slots while some slot still has a wanted generation to begin
+            d = eng.drain(recycle=bool(restarts and (slot_gen < last_gen).any()))
+            ng = int(d["games"].shape[0])
+            take(d)
+            if not ng and eng.live_games() == 0:
+                break
+
+
 def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0, searches=cfg.MCTS_SEARCHES,
               batch=cfg.MCTS_BATCH_SIZE, concurrent=None, stagger=False):
     """Play n_games (per rank) with the (best) net against itself, tuples appended on the device.
@@ -199,28 +226,19 @@ def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_ba
             keep = torch.repeat_interleave(want, recs[:, 3] + 1)  # a game of s steps holds s + 1 rows
             gatherer.push({f: d[f][keep] for f in ("states", "players", "pi", "z")})
 
-    if stagger:
-        # every pass of `searches` launches is one ply per game on average; a game has at most HW plies and sits out
-        # fewer than `searches` launches at the start: a bound on the passes that a healthy run never reaches
-        hw = game.obs_shape[1] * game.obs_shape[2]
-        max_passes = (hw + 4) * (-(-n_games // G)) + 8
-        passes = 0
-        while st["finished"] < n_games:
-            take(eng.move(searches, batch, recycle=restarts))  # host-pipelined: hands out the previous pass's rows
-            passes += 1
-            if passes > max_passes:
-                raise _lib.CaroError("self_play: %d of %d games finished after %d passes" % (st["finished"], n_games, passes))
-        take(eng.flush())
-    else:
-        while st["finished"] < n_games:
-            eng.search(searches, batch)
-            eng.step()
-            # restart drained slots while some slot still has a wanted generation to begin
-            d = eng.drain(recycle=bool(restarts and (slot_gen < last_gen).any()))
-            ng = int(d["games"].shape[0])
-            take(d)
-            if not ng and eng.live_games() == 0:
-                break
+    try:
+        _self_play_loop(eng, game, n_games, G, searches, batch, stagger, restarts, st, slot_gen, last_gen, take)
+    except BaseException:
+        # the engine goes whatever happens (its trees are gigabytes).  Under several ranks the error must END this rank:
+        # the peers are on their way to the collective in gatherer.flush() and would wait there for the backend's
+        # timeout; a rank that exits non-zero is what the launcher's fail-fast path (bench.py / torchrun) acts on.
+        eng.close()
+        if parallel.is_dist():
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(13)
+        raise
     # multi-GPU: the loop above is driven by rank-local counts, so the exchange is ONE collective at the end, when every
     # rank has left its loop
     out = gatherer.flush()

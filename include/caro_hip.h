@@ -181,7 +181,9 @@ int caro_drain_tuples_end(caro_engine* h, int64_t* n_tuples, int64_t* n_games);
 int caro_counters(caro_engine* h, int64_t counters[8], void* stream);
 /* HIP-event timing of the path's kernels on the stream they are launched on (bench.py's live
  * roofline).  Kinds: 0 select, 1 scan+encode, 2 expand+backup, 3 step, 4 net forward (bracketed by the
- * caller with caro_profile_begin/_end around caro_net_forward), 5-7 free.
+ * caller with caro_profile_begin/_end around caro_net_forward), 5 an EMPTY pair (two event records with nothing
+ * between them, taken behind every sampled net launch of caro_search_batch / caro_search_staggered: what a pair
+ * costs by itself on the busy stream, to be subtracted from the other kinds' averages), 6-7 free.
  * caro_profile_read synchronises on the recorded events; ms[] / launches[] are running totals. */
 int caro_profile_enable(caro_engine* h, int on);
 int caro_profile_begin(caro_engine* h, int kind, void* stream); /* returns a slot, or -1 when profiling is off */

@@ -189,3 +189,51 @@ def test_net_kernel_touches_m0_only_in_front_of_its_lds_dma():
         assert ins[k][0] == "s_mov_b32" and ins[k][1].strip(",") == "m0", " ".join(ins[k])
         nxt = next(i[0] for i in ins[k + 1:k + 6] if i[0] != "s_nop")
         assert nxt == "global_load_lds_dwordx4", (" ".join(ins[k]), nxt)
+
+
+def test_winograd2d_predicate_matches_what_the_heads_kernel_is_sized_for():
+    """k_net_heads stages 228 floats per feature plane and 20 x 225 value-head weights -- boards of more
+    than 225 cells (15x16: 8 x 8 tiles, 240 cells) must not be offered the 2-D Winograd form (host-side predicate)"""
+    from caro_ai_amd import _lib
+    L = _lib.load()
+    ok = {(h, w) for h in range(1, 20) for w in range(1, 20) if L.caro_net_winograd2d_supported(h, w)}
+    assert (15, 15) in ok and (12, 12) in ok and (14, 14) in ok and (13, 15) in ok
+    assert all(128 <= h * w <= 225 and h <= 16 and w <= 16 for h, w in ok)
+    assert (15, 16) not in ok and (16, 15) not in ok and (16, 16) not in ok and (11, 11) not in ok and (6, 7) not in ok
+
+
+def _code_object_metadata(obj_name):
+    """kernel name -> metadata dict (.vgpr_count, .vgpr_spill_count, .private_segment_fixed_size ...) of the gfx950 code
+    object inside a built .o"""
+    import subprocess
+    import tempfile
+    import yaml
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "caro_ai_amd", "csrc", obj_name)
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "llvm-readelf"))):
+        pytest.skip("needs the built object and the ROCm llvm tools")
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "x.fatbin"), os.path.join(tmp, "x.co")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj,
+                               os.path.join(tmp, "copy.o")])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", co], text=True)
+    doc = notes[notes.index("---"):notes.rindex("...")]
+    return {k[".name"]: k for k in yaml.safe_load(doc)["amdhsa.kernels"]}
+
+
+def test_hot_kernels_do_not_spill():
+    """k_net_forward_w2 ran with 14 spilled registers and 60 bytes of scratch per lane (reloads inside
+    its MFMA loop).  The hot kernels of every bench leg keep everything in registers: no spilled VGPRs, no scratch."""
+    net = _code_object_metadata("caro_net.hip.o")
+    eng = _code_object_metadata("caro_engine.hip.o")
+    seen = 0
+    for md, wanted in ((net, ("k_net_forward_w2", "k_net_forward_wE", "k_net_heads")), (eng, ("k_tree_stag", "k_treeI"))):
+        for name, k in md.items():
+            if any(w in name for w in wanted):
+                assert k[".vgpr_spill_count"] == 0 and k[".vgpr_count"] <= 256, (name, k[".vgpr_spill_count"])
+                if md is net or "C4Rules" in name:  # (the m,n,k tree kernels index small per-thread arrays: scratch, no spill)
+                    seen += 1
+                    assert k[".private_segment_fixed_size"] == 0, (name, k[".private_segment_fixed_size"])
+    assert seen >= 5

@@ -728,3 +728,12 @@ def test_rules_kernels_vs_oracle_random_playouts(d, n_games):
         ref = o.states_to_training_batch([S2[i]], [1 - P_[i]])[0].reshape(-1)
         assert np.array_equal(pl[i], ref)
     assert M > (50000 if d["kind"] == "c4" else 3000)
+
+
+def test_engine_create_refuses_tables_the_path_records_cannot_address():
+    """path records carry the node slot in 24 bits; a node_cap that needs more than 2^24 slots per tree is
+    refused instead of aliasing nodes"""
+    from caro_ai_amd import _lib
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    with pytest.raises(_lib.CaroError, match="node_cap too large"):
+        _engine(ConnectFour(), 1, [_synth(ConnectFour())], node_cap=(1 << 23) + 1)

@@ -298,3 +298,44 @@ def test_kept_drains_do_not_pin_the_staging_block_on_large_boards(monkeypatch):
         for k in a:
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     assert held_v > 10 * held                                         # ... and every non-empty drain pins its block
+
+
+def test_gomoku15_games_do_not_depend_on_the_stream_split():
+    """bench.py's config-4 leg plays its 1024 games as two engines of 512 on two HIP streams sharing ONE net handle
+    (per-stream feature rows).  The 15 x 15 net kernel evaluates one board per workgroup, so a leaf's priors do not
+    depend on which launch or tile carries it: 16 games as one engine == the same uids as 2 x 8 on two streams, root
+    boards and visit counts bit for bit at every move, conv net (2-D Winograd form), eviction on as config 4 runs."""
+    from caro_ai_amd.engine import SelfPlayEngine, StreamedSelfPlay
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.lib.model import Net
+    from caro_ai_amd.net_hip import HipNet
+    game = TicTacToe(15, 5)
+    torch.manual_seed(0)
+    net = Net(game.obs_shape, game.action_space).to(DEV).eval()
+    hip = HipNet(net, DEV)
+    assert hip.mode == "f32w2"
+    kw = dict(max_batch=8, steps_before_tau_0=10, seed=3, device=DEV, searches_hint=6, evict=True, node_cap=1024)
+    one = SelfPlayEngine(game, 16, evaluators=[hip], **kw)
+    two = StreamedSelfPlay(game, 16, lambda: [hip], n_streams=2, partition_cus=False, **kw)
+    for mv in range(12):
+        one.search(6, 8)
+        two.search(6, 8)
+        torch.cuda.synchronize()
+        pi1, n1 = one.policy()
+        n2 = []
+        for e, st in two._each():
+            with torch.cuda.stream(st):
+                n2.append(e.policy()[1])
+        torch.cuda.synchronize()
+        assert torch.equal(n1, torch.cat(n2)), mv
+        one.step()
+        two.step()
+        torch.cuda.synchronize()
+        k1 = one.roots()[0]
+        k2 = np.concatenate([e.roots()[0] for e in two.parts])
+        assert np.array_equal(np.asarray(k1), k2), mv
+    assert int(n1.sum()) > 16 * 40
+    c1, c2 = one.counters(), [e.counters() for e in two.parts]
+    assert c1["expansions"] == sum(c["expansions"] for c in c2) and c1["overflows"] == 0
+    one.close()
+    two.close()

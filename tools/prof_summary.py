@@ -123,6 +123,19 @@ def main():
     for extra in ("config5", "config4"):  # profile_r03.sh: the same three passes on BASELINE configs 5 and 4
         if os.path.isdir(os.path.join(src, extra + "_fetch")):
             out_json[extra] = section(extra + "_")
+    # what the passes were taken on (tools/profile_r05.sh leaves the kernel sources' hashes beside the counters), and
+    # the commit that holds exactly those sources -- bench.py refuses to quote the counters once the sources differ
+    sha_file = os.path.join(src, "source_sha256.json")
+    if os.path.exists(sha_file):
+        import subprocess
+        sys.path.insert(0, os.path.join(root, "tools"))
+        from source_sha import source_sha256
+        out_json["source_sha256"] = json.load(open(sha_file))
+        same = out_json["source_sha256"] == source_sha256(root)
+        clean = subprocess.run(["git", "-C", root, "diff", "--quiet", "HEAD", "--", "caro_ai_amd/csrc"]).returncode == 0
+        head = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+        out_json["pmc_source_head"] = head if (same and clean) else None
+        print("PMC passes taken on the sources of commit", out_json["pmc_source_head"])
     json.dump(out_json, open(os.path.join(root, "profiles", pmc_name), "w"), indent=1)
 
 

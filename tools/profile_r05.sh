@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-5 profiles on the GPU box (one gpurun call): kernel-trace stats of the driver's bench command, and the PMC
+# passes (HBM bytes, MFMA busy), each in its own rocprofv3 run as the pool requires -- this round at the driver's
+# --steps 20 --warmup 5 for the headline, and the same three passes on BASELINE configs 5 and 4.
+# Output: gpurun_out/<dir>/ ; summarise with  python tools/prof_summary.py gpurun_out/<dir> r05_x pmc_r05.json
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/${1:-prof_r05}
+WHAT=${2:-all}   # "stats": the kernel-trace pass of the headline only
+mkdir -p $OUT
+# what is profiled: bench.py quotes the counters of pmc_r05.json only while the kernel sources still hash to this
+python3 $ROOT/tools/source_sha.py > $OUT/source_sha256.json
+cd /tmp && export TMPDIR=/tmp
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra-configs --sustained-moves 0 --no-profile"
+H="--steps 20 --warmup 5"
+C5="--arena --games 512 --searches 100 --steps 3 --warmup 2"
+C4="--game gomoku15 --searches 50 --steps 2 --warmup 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B $H > $OUT/stats.json 2> $OUT/stats.err
+echo stats done
+if [ "$WHAT" = "stats" ]; then exit 0; fi
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lockstep -- $B $H --stagger 0 > $OUT/stats_lockstep.json 2> $OUT/stats_lockstep.err
+echo lock-step stats done
+run_pmc() {  # $1 prefix, $2.. bench arguments
+  local pre=$1; shift
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${pre}_fetch -- $B "$@" > $OUT/${pre}_fetch.json 2> $OUT/${pre}_fetch.err
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${pre}_write -- $B "$@" > $OUT/${pre}_write.json 2> $OUT/${pre}_write.err
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${pre}_mfma -- $B "$@" > $OUT/${pre}_mfma.json 2> $OUT/${pre}_mfma.err
+  echo $pre done
+}
+run_pmc pmc $H
+run_pmc config5 $C5
+run_pmc config4 $C4
+find $OUT -name "*_agent_info.csv" -delete
+du -sh $OUT
