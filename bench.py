@@ -39,10 +39,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
-MFMA_BF16_PEAK_TFS = 2500.0 # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 PMC_FILE = os.path.join("profiles", "pmc_r05.json")
 CPU_RATIO_FILE = os.path.join("profiles", "cpu_ratio_r03.json")
-NET_KERNEL = {"hip": "k_net_forward", "hipw": "k_net_forward_w", "hip3x": "k_net_forward_3x"}
+NET_KERNEL = {"hip": "k_net_forward", "hipw": "k_net_forward_w"}
 
 
 def host_cores():
@@ -278,7 +277,7 @@ class Leg:
         from caro_ai_amd.engine import SelfPlayEngine, StreamedSelfPlay, torch_evaluator
         from caro_ai_amd.lib.game.connect_four import ConnectFour
         from caro_ai_amd.lib.game.tictactoe import TicTacToe
-        from caro_ai_amd.lib.model import FoldedNet, GemmNet
+        from caro_ai_amd.lib.model import GemmNet
         self.args, self.game_name, self.G, self.S, self.B, self.arena = args, game_name, G, S, B, arena
         self.rank, self.world, self.device = rank, world, device
         if game_name == "c4":
@@ -303,12 +302,12 @@ class Leg:
         self.hipnet = None
         if self.is_hip:
             from caro_ai_amd.net_hip import HipNet
-            mode = {"hip": "f32", "hipw": "f32w", "hip3x": "3xbf16"}[args.net]
+            mode = {"hip": "f32", "hipw": "f32w"}[args.net]
             self.hipnet = HipNet(net, str(device), mode=mode)
             hipnets = [self.hipnet] + ([HipNet(net2, str(device), mode=mode)] if arena else [])
             make_evaluators = lambda: list(hipnets)
         else:
-            fnet = {"gemm": GemmNet, "folded": FoldedNet, "net": lambda n: n}[args.net](net).to(device).eval()
+            fnet = GemmNet(net).to(device).eval()
             make_evaluators = lambda: [torch_evaluator(fnet, form="net")]
         self.n_streams = (args.streams if streams is None else streams) if self.is_hip else 1
         stream_mask = args.stream_mask if stream_mask is None else stream_mask
@@ -420,15 +419,19 @@ class Leg:
         kernel_us = 0.0
         roofline = roofline_tree = None
         pmc_head, pmc_stale = pmc_status()
-        # An event pair by itself: the engine records a pair with NOTHING between its two records right behind every
-        # sampled net launch (kind "empty").  Its mean elapsed time is what bracketing adds to every sampled launch
-        # (~3 us: rocprofv3 saw 141.0 / 25.65 us where the pairs said 143.9 / 28.8) and is subtracted below.
-        gap_s = 0.0
-        if prof is not None and prof.get("empty", (0, 0))[1] > 0:
-            gap_s = prof["empty"][0] * 1e-3 / prof["empty"][1]
-        timing_note = ("HIP-event pairs on the launch stream around a sample of the launches (every 12th minibatch), "
-                       "minus the mean of the EMPTY pairs recorded beside them (%.2f us, %d pairs)"
-                       % (gap_s * 1e6, prof["empty"][1] if prof and "empty" in prof else 0))
+        # What an event pair adds to the kernel it brackets (the dispatch behind an event's barrier packet; rocprofv3
+        # sees the kernel alone): calibrated in the run itself.  Behind every fourth sampled net launch the engine
+        # brackets ONE launch of an empty kernel (E1 = K0 + o) and TWO (E2 = 2 K0 + g + o):  o = 2 E1 - E2 (+ g, the
+        # sub-microsecond gap between two dependent launches: o is underestimated, the kernels' times stay conservative).
+        gap_s, ncal, e1, e2 = 0.0, 0, 0.0, 0.0
+        if prof is not None and prof.get("null1", (0, 0))[1] > 0 and prof.get("null2", (0, 0))[1] > 0:
+            e1 = prof["null1"][0] * 1e-3 / prof["null1"][1]
+            e2 = prof["null2"][0] * 1e-3 / prof["null2"][1]
+            gap_s, ncal = min(max(2.0 * e1 - e2, 0.0), e1), prof["null1"][1]
+        timing_note = ("HIP-event pairs on the launch stream around a sample of the launches (every 12th minibatch), minus "
+                       "what a pair adds to the kernel it brackets: %.2f us = 2 E1 - E2 of pairs around one / two launches "
+                       "of an empty kernel recorded beside them (E1 %.2f us, E2 %.2f us, %d calibrations)"
+                       % (gap_s * 1e6, e1 * 1e6, e2 * 1e6, ncal))
         if prof is not None and prof["select"][1] > 0:
             ms, n = prof["select"]
             avg_s = max(ms * 1e-3 / n - gap_s, 1e-9)  # timed on a sample of the launches (every 12th minibatch, all indices equally)
@@ -438,7 +441,7 @@ class Leg:
             fused = prof.get("compact", (0, 0))[1] == 0
             tname = ("k_tree_stag" if self.stagger else "k_tree") if fused else "k_select"
             others = {k: (max(v[0] * 1e3 / v[1] - gap_s * 1e6, 0.0) if v[1] else None) for k, v in prof.items()
-                      if k not in ("select", "net", "empty")}
+                      if k not in ("select", "net", "null1", "null2")}
             roofline_tree = {"bound": "hbm", "kernel": tname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(tname, {}).get("hbm"),
                              "traffic_source": traffic_note if pmc.get(tname) else None,
@@ -454,15 +457,14 @@ class Leg:
             avg_s = max(ms * 1e-3 / n - gap_s, 1e-9)
             leaves_per_launch = delta["expansions"] / (steps * S * n_streams)
             achieved = leaves_per_launch * flops_per_leaf / avg_s / 1e12
-            # hip3x issues 6 bf16 MFMA flops per algorithmic flop: priced against the dense bf16 peak / 6
-            peak = MFMA_F32_PEAK_TFS if args.net != "hip3x" else MFMA_BF16_PEAK_TFS / 6.0
+            peak = MFMA_F32_PEAK_TFS
             kname = NET_KERNEL[args.net]
             if args.net == "hipw" and self.hipnet.mode == "f32w2":
                 kname = "k_net_forward_w2"  # large boards: the 2-D Winograd form
             # What the matrix pipe EXECUTES per launch.  hipw, row-Winograd F(2,3): 60 transformed taps x 32 MFMAs x
             # 8 waves x 4096 flop per workgroup of TB boards, tile padding and the last partial tile included -- 2/3 of
             # the 3x3 multiplies of the direct form; hipw on large boards, 2-D Winograd F(2x2,3x3): 80 taps x 4 blocks
-            # of 32 MFMAs per board -- 4/9.  hip / hip3x: the direct form executes its algorithmic count.
+            # of 32 MFMAs per board -- 4/9.  hip: the direct form executes its algorithmic count.
             executed = None
             if args.net == "hipw":
                 tb = self.hipnet.L.caro_net_boards_per_workgroup(self.hipnet.h)
@@ -519,11 +521,9 @@ class Leg:
             netdesc = {"f32": "fused HIP MFMA kernel k_net_forward, direct 3x3 convs,",
                        "f32w1": "fused HIP MFMA kernel k_net_forward_w, 3x3 convs in row-Winograd F(2,3) form,",
                        "f32w2": "fused HIP MFMA kernels k_net_forward_w2 + k_net_heads, 3x3 convs in 2-D Winograd "
-                                "F(2x2,3x3) form, FC heads batched 32 boards per workgroup,",
-                       "3xbf16": "fused HIP kernel k_net_forward_3x, 3x3 convs as 3-way split bf16 MFMA with f32 "
-                                 "accumulate,"}[self.hipnet.mode]
+                                "F(2x2,3x3) form, FC heads batched 32 boards per workgroup,"}[self.hipnet.mode]
         else:
-            netdesc = {"gemm": "torch gather+GEMM", "folded": "torch conv2d BN-folded", "net": "torch module"}[args.net]
+            netdesc = {"gemm": "torch gather+GEMM"}[args.net]
         return {
             "value": exp_all / dt, "unit": "node-expansions/s", "steps": steps, "warmup": warmup,
             "ms_per_step": ms_per_step,
@@ -592,11 +592,11 @@ def main():
     ap.add_argument("--evict", type=int, default=-1,
                     help="drop unreachable nodes after every move (result-neutral); default: on for gomoku15")
     ap.add_argument("--weights", default=os.path.join(ROOT, "tests", "golden", "weights", "best_026_12000.dat"))
-    ap.add_argument("--net", default="hipw", choices=["hip", "hipw", "hip3x", "gemm", "folded", "net"],
-                    help="inference form of lib/model.py Net: hipw = fused HIP fp32 MFMA kernel, 3x3 convs in row-Winograd "
-                         "F(2,3) form (default); hip = the same with direct 3x3 convs; hip3x = direct convs on the bf16 "
-                         "MFMA pipe via three-way split operands (opt-in); torch "
-                         "gather+GEMM; BN-folded conv2d; or the module as is")
+    ap.add_argument("--net", default="hipw", choices=["hipw", "hip", "gemm"],
+                    help="inference form of lib/model.py Net: hipw = fused HIP fp32 MFMA kernel, 3x3 convs in Winograd form "
+                         "(row form F(2,3); 2-D form F(2x2,3x3) on 13x13 .. 15x15 boards) -- the default and the only form "
+                         "that is tuned; the other two are A/B baselines: hip = the same kernel structure with direct 3x3 "
+                         "convs, gemm = PyTorch-ROCm gather + GEMM (leaf counts cross to the host)")
     ap.add_argument("--streams", type=int, default=1,
                     help="split the games of a GPU over this many engines on separate HIP streams (tree kernels of "
                          "one part overlap the net kernel of another)")
@@ -659,29 +659,47 @@ def main():
         # BASELINE.json configs 5 and 4 at full size (parity of both is tests/ business).  config 4 is measured in
         # MID-GAME: --config4-warmup moves at full size first, so that trees are deep, eviction has work to do and
         # games finish inside the timed moves.
-        for key, spec, st, wu in (("config5", dict(game_name="c4", G=512, S=100, B=8, arena=True), 6, 3),
-                                  # config 4 on two streams of 512 games (no CU mask): a 15x15 net launch is 30 rounds of
-                                  # workgroups, the last one partly filled -- the other half's tree-side kernels run there.
-                                  # One board per net workgroup: a game's bits do not depend on the split
-                                  # (tests/test_gpu_tuples.py::test_gomoku15_games_do_not_depend_on_the_stream_split)
-                                  ("config4", dict(game_name="gomoku15", G=1024, S=50, B=8, arena=False, streams=2,
-                                                   stream_mask=0),
-                                   args.config4_steps, args.config4_warmup)):
-            try:
-                x = Leg(args, rank=rank, world=world, device=device, **spec)
-                r = x.run(st, wu, profile=not args.no_profile, label=key)
-                x.close()
-                del x
-                torch.cuda.empty_cache()
-                extras[key] = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "data",
-                                                 "sims_per_s", "games_per_s", "games_finished", "mean_depth",
-                                                 "expansions_per_sim", "overflows", "evict", "live_nodes",
-                                                 "kernel_ms_per_step", "roofline", "roofline_tree")}
-            except Exception as e:  # the headline line survives a failing side leg, but says so: extras_rc != 0
-                import traceback
-                traceback.print_exc()
-                extras[key] = {"error": repr(e)}
-                extras_rc = 1
+        keep = ("value", "unit", "steps", "warmup", "ms_per_step", "config", "data", "sims_per_s", "games_per_s",
+                "games_finished", "mean_depth", "expansions_per_sim", "overflows", "evict", "live_nodes",
+                "kernel_ms_per_step", "roofline", "roofline_tree")
+
+        def side_leg(key, spec, st, wu, profile):
+            x = Leg(args, rank=rank, world=world, device=device, **spec)
+            r = x.run(st, wu, profile=profile, label=key)
+            x.close()
+            del x
+            torch.cuda.empty_cache()
+            return {k: r[k] for k in keep}
+
+        c4 = dict(game_name="gomoku15", G=1024, S=50, B=8, arena=False)
+        try:
+            extras["config5"] = side_leg("config5", dict(game_name="c4", G=512, S=100, B=8, arena=True), 6, 3,
+                                         not args.no_profile)
+        except Exception as e:  # the headline line survives a failing side leg, but says so: extras_rc != 0
+            import traceback
+            traceback.print_exc()
+            extras["config5"] = {"error": repr(e)}
+            extras_rc = 1
+        try:
+            # config 4 twice.  (1) ONE stream, HIP events on: its launches do not overlap, so `roofline` / `roofline_tree`
+            # / `kernel_ms_per_step` price single launches.  (2) the games as two engines of 512 on two streams (no CU
+            # mask), events off: a 15x15 net launch is 30 rounds of workgroups, the last one partly filled, and the other
+            # half's tree-side kernels run there -- this is the leg's `value`.  One board per net workgroup: a game's bits
+            # do not depend on the split (tests/test_gpu_tuples.py::test_gomoku15_games_do_not_depend_on_the_stream_split).
+            one = side_leg("config4", c4, args.config4_steps, args.config4_warmup, not args.no_profile)
+            two = side_leg("config4-2streams", dict(c4, streams=2, stream_mask=0), args.config4_steps,
+                           args.config4_warmup, False)
+            for k in ("roofline", "roofline_tree", "kernel_ms_per_step", "live_nodes"):
+                two[k] = one[k]
+            two["single_stream"] = {"value": one["value"], "ms_per_step": one["ms_per_step"],
+                                    "note": "the same configuration on one stream, in this run: roofline, roofline_tree, "
+                                            "kernel_ms_per_step and live_nodes of this leg are measured there"}
+            extras["config4"] = two
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            extras["config4"] = {"error": repr(e)}
+            extras_rc = 1
 
     if rank == 0:
         out = {"metric": "self-play MCTS node-expansions/sec/GPU (Connect4, 200 sims/move); 1->8 GPU scaling"
@@ -689,7 +707,7 @@ def main():
                "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.net != "hip3x" else "f32 (3x3 conv products as 3-way split bf16, f32 accumulate)"}
+               "dtype": "f32"}
         out.update({k: v for k, v in res.items() if k not in out})
         out["dist"] = dist_rec
         out["sustained"] = sustained

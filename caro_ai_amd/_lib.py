@@ -60,7 +60,6 @@ _SIGNATURES = {
     "caro_net_packed_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "caro_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int64, C.c_int, _P]),
     "caro_net_destroy": (None, [_P]),
-    "caro_net_enable_3xbf16": (C.c_int, [_P, _P, C.c_int64]),
     "caro_net_enable_winograd": (C.c_int, [_P, _P, C.c_int64]),
     "caro_net_winograd2d_size": (C.c_int, []),
     "caro_net_winograd2d_supported": (C.c_int, [C.c_int, C.c_int]),

@@ -7,10 +7,12 @@
 // minibatch) and ~45 launches; MIOpen has no gfx950 database in this image.
 // Here the grid is sized for the maximum and every workgroup reads L itself.
 //
-// Three kernels share conv_in, the heads and the launch interface:
-//   k_net_forward_w  (default)  3x3 convolutions in row-Winograd F(2,3) form, float32 MFMA -- see trunk_w
-//   k_net_forward               direct 3x3 form, float32 MFMA (the round-1 kernel; `--net hip`)
-//   k_net_forward_3x (opt-in)   direct form on the bf16 pipe with three-way split operands
+// Three kernels share conv_in, the heads and the launch interface (all float32 on v_mfma_f32_32x32x2_f32):
+//   k_net_forward_w  (default)  3x3 convolutions in row-Winograd F(2,3) form -- see trunk_w
+//   k_net_forward_w2 (default on 13x13 .. 15x15 boards)  2-D Winograd F(2x2,3x3) form + k_net_heads -- see trunk_w2d
+//   k_net_forward               direct 3x3 form (the round-1 kernel; `--net hip`, the A/B baseline of the Winograd forms)
+// (A fourth, direct convolutions on the bf16 pipe with three-way split operands, was removed in round 5: untuned since
+// round 1, no large-board or K-split form, and the headline stays on the float32 pipe.  git history has it.)
 // Common structure (one workgroup = 512 threads = 8 waves = one CU, two waves per SIMD; TB boards):
 //   rows r = board*HW + cell, at most 255 real rows; row 255 is a permanent zero
 //   row (3x3 padding).  Activations X[row][64] float32 stay in LDS for the whole
@@ -67,7 +69,6 @@ struct NetParams {
   const float* w_p;     // [A][2*HW]
   const float* b_p;     // [A]
   const float* w_pT;    // w_p quad-transposed (made at upload: per plane [HW/4][A][4] + [HW%4][A]), for boards whose head block is not staged in LDS
-  const uint4* w3;      // 3xbf16 mode: [45 taps][1536 granules] LDS image of the split residual weights, or null
   const float* ww;      // f32w mode: [5][3 dx][2 granule halves] chunks of [4 p][2 h][64 co][16] transformed residual weights (LDS image order of trunk_w), or null
   const uint32_t* wtab; // f32w mode: [128] tile of MFMA row (row tile, lane): board | ty << 8 | x << 16 | valid << 24
   const float* ww2;     // f32w2 mode: [5][8 chunks][2 b][4 a][2 h][64 co][8] 2-D Winograd F(2x2,3x3) transformed residual weights (LDS image order of trunk_w2d), or null
@@ -1817,316 +1818,6 @@ __global__ __launch_bounds__(NT, 1) void k_net_heads(NetParams p0, NetParams p1,
 
 
 // ===================================================================================================
-// 3 x bf16 mode (opt-in): the same network function with the 3x3 convolutions evaluated on the bf16 MFMA
-// pipe.  Every float32 operand x is split exactly into three bf16 terms x = hi + mid + lo (+ <= 2^-27 |x|),
-// and a product is accumulated as hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid in float32: the dropped
-// terms are <= 2^-26 relative, i.e. below float32 rounding.  v_mfma_f32_32x32x16_bf16 covers 16 k per 32
-// cycles against 2 k per 64 for the f32 form, so the six MFMAs cost 6/16 of the float32 issue time.
-// Layout: activations as three bf16 planes per row (24 granules of 16 B, XOR-swizzled), weights per tap as
-// [split][co][k] bf16 rows; the MFMA is issued with the WEIGHTS as first operand, so a lane's 16 results are
-// 4 groups of 4 consecutive channels of ONE activation row and go back to LDS as 8-byte writes.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int ROW_G = 24;                 // granules per activation row: 3 splits x 8
-constexpr int ACT3_G = 256 * ROW_G;       // 6144 granules = 96 KiB
-constexpr int W3_G = 3 * 64 * 8;          // 1536 granules = 24 KiB per tap
-constexpr int LDS3_G = ACT3_G + 2 * W3_G; // 144 KiB
-
-__device__ __forceinline__ int agran(int row, int s, int g) { return row * ROW_G + s * 8 + (g ^ ((row >> 1) & 7)); }
-__device__ __forceinline__ unsigned bf16_rne(float x) {
-  const unsigned u = __float_as_uint(x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = bf16_rne(x);
-  float r = x - __uint_as_float(hi << 16);   // exact
-  mid = bf16_rne(r);
-  r = r - __uint_as_float(mid << 16);        // exact
-  lo = bf16_rne(r);
-}
-// four float32 values -> three 8-byte groups of bf16
-__device__ __forceinline__ void split3x4(const float* x, uint2& H, uint2& M, uint2& L) {
-  unsigned h[4], m[4], l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) split3(x[j], h[j], m[j], l[j]);
-  H = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-  M = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-  L = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
-}
-__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
-__device__ __forceinline__ void join3x4(uint2 H, uint2 M, uint2 L, float* x) {
-  x[0] = (bf_lo(H.x) + bf_lo(M.x)) + bf_lo(L.x);
-  x[1] = (bf_hi(H.x) + bf_hi(M.x)) + bf_hi(L.x);
-  x[2] = (bf_lo(H.y) + bf_lo(M.y)) + bf_lo(L.y);
-  x[3] = (bf_hi(H.y) + bf_hi(M.y)) + bf_hi(L.y);
-}
-
-__global__ __launch_bounds__(NT, 2) void k_net_forward_3x(NetParams p0, NetParams p1,
-                                                            const float* __restrict__ planes,
-                                                            const int32_t* __restrict__ counts, int which, int row1,
-                                                            float* __restrict__ probs, float* __restrict__ values,
-                                                            const int32_t* __restrict__ gpack, int gG, int gB) {
-  __shared__ uint4 lds[LDS3_G];
-  uint4* wbuf = lds + ACT3_G;
-  char* actb = reinterpret_cast<char*>(lds);
-
-  int L, row0, board0;
-  bool second = false;
-  if (which < 2) {
-    L = counts[which];
-    row0 = which ? counts[0] : 0;
-    board0 = blockIdx.x * p0.TB;
-  } else {
-    const int L0 = counts[0];
-    const int t0 = (L0 + p0.TB - 1) / p0.TB;
-    second = (int)blockIdx.x >= t0;
-    L = second ? counts[1] : L0;
-    row0 = second ? (row1 >= 0 ? row1 : L0) : 0;
-    board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
-  }
-  if (board0 >= L) return;
-  const NetParams p = second ? p1 : p0;
-  const float slope = p.slope;
-  const int nb = min(p.TB, L - board0);
-  const int HW = p.HW;
-  const int R = nb * HW;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int i = lane & 31, h = lane >> 5;
-
-  for (int k = tid; k < ACT3_G; k += NT) lds[k] = make_uint4(0u, 0u, 0u, 0u);
-  float* wf = reinterpret_cast<float*>(wbuf);
-  for (int k = tid; k < 9 * 2 * NF; k += NT) wf[k] = p.w_in[k];
-  int* smap = reinterpret_cast<int*>(wf + 1536);  // [TB] plane / output row of every board of this tile
-  tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
-  const int slot_v = tid < nb ? smap[tid] : 0;
-
-  // ---- conv_in (float32 on the VALU), result split into the three planes
-  {
-    const int r = tid & 255;
-    const int chalf = tid >> 8;
-    if (r < R) {
-      const int bi = r / HW, cell = r - bi * HW;
-      const int y = cell / p.W, x = cell - y * p.W;
-      const float* pl = planes + (size_t)smap[bi] * 2 * HW;
-      float in0[9], in1[9];  // the 18 inputs of this row (statically indexed: stays in registers)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int ny = y + t / 3 - 1, nx = x + t % 3 - 1;
-        const bool ok = ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
-        in0[t] = ok ? pl[ny * p.W + nx] : 0.f;
-        in1[t] = ok ? pl[HW + ny * p.W + nx] : 0.f;
-      }
-#pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        const int c4 = chalf * 8 + cc;
-        float o[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) o[u] = p.b_in[c4 * 4 + u];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const float i0 = in0[t], i1 = in1[t];
-          const float4 w0 = *reinterpret_cast<const float4*>(wf + (2 * t) * NF + c4 * 4);
-          const float4 w1 = *reinterpret_cast<const float4*>(wf + (2 * t + 1) * NF + c4 * 4);
-          o[0] = fmaf(i0, w0.x, o[0]); o[1] = fmaf(i0, w0.y, o[1]); o[2] = fmaf(i0, w0.z, o[2]); o[3] = fmaf(i0, w0.w, o[3]);
-          o[0] = fmaf(i1, w1.x, o[0]); o[1] = fmaf(i1, w1.y, o[1]); o[2] = fmaf(i1, w1.z, o[2]); o[3] = fmaf(i1, w1.w, o[3]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) o[u] = leaky(o[u], slope);
-        uint2 H, M, Lo;
-        split3x4(o, H, M, Lo);
-        const int g = c4 >> 1, half = (c4 & 1) * 8;
-        *reinterpret_cast<uint2*>(actb + agran(r, 0, g) * 16 + half) = H;
-        *reinterpret_cast<uint2*>(actb + agran(r, 1, g) * 16 + half) = M;
-        *reinterpret_cast<uint2*>(actb + agran(r, 2, g) * 16 + half) = Lo;
-      }
-    }
-  }
-  __syncthreads();
-  // ---- stage the weights of tap 0
-#pragma unroll
-  for (int m = 0; m < 3; ++m) wbuf[tid + NT * m] = p.w3[tid + NT * m];
-  __syncthreads();
-
-  const int myrow = wave * 32 + i;
-  const bool rvalid = myrow < R;
-  const int rbi = myrow / HW;
-  const int rcell = myrow - rbi * HW;
-  const int ry = rcell / p.W, rx = rcell - ry * p.W;
-  const int wswz = (i >> 1) & 7;
-
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    acc0[e] = 0.f;
-    acc1[e] = 0.f;
-  }
-  uint4 wn0, wn1, wn2;
-  wn0 = wn1 = wn2 = make_uint4(0u, 0u, 0u, 0u);
-  for (int ft = 0; ft < NTAPS; ++ft) {
-    const int cur = ft & 1;
-    const int layer = ft / 9, tap = ft % 9;
-    const bool has_next = ft + 1 < NTAPS;
-    if (has_next) {  // issue early
-      const uint4* src = p.w3 + (size_t)(ft + 1) * W3_G;
-      wn0 = src[tid];
-      wn1 = src[tid + NT];
-      wn2 = src[tid + 2 * NT];
-    }
-    const int ny = ry + tap / 3 - 1, nx = rx + tap % 3 - 1;
-    const bool ok = rvalid && ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
-    const int nrow = ok ? rbi * HW + ny * p.W + nx : ZROW;
-    const uint4* arow = lds + nrow * ROW_G;
-    const int aswz = (nrow >> 1) & 7;
-    const uint4* w0 = wbuf + cur * W3_G + i * 8;          // co = i      (col tile 0), split s adds 64*8 granules
-    const uint4* w1 = wbuf + cur * W3_G + (32 + i) * 8;   // co = 32 + i (col tile 1)
-#define CARO_LOAD3(AH, AM, AL, W0H, W0M, W0L, W1H, W1M, W1L, KB)                    \
-  {                                                                                  \
-    const int ga = ((2 * (KB) + h) ^ aswz), gw = ((2 * (KB) + h) ^ wswz);            \
-    AH = arow[ga]; AM = arow[8 + ga]; AL = arow[16 + ga];                             \
-    W0H = w0[gw]; W0M = w0[512 + gw]; W0L = w0[1024 + gw];                            \
-    W1H = w1[gw]; W1M = w1[512 + gw]; W1L = w1[1024 + gw];                            \
-  }
-#define CARO_BF(X) __builtin_bit_cast(bf16x8, X)
-#define CARO_MFMA3(ACC, WH, WM, WL, AH, AM, AL)                                                      \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CARO_BF(WM), CARO_BF(AM), ACC, 0, 0, 0);             \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CARO_BF(WH), CARO_BF(AL), ACC, 0, 0, 0);             \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CARO_BF(WL), CARO_BF(AH), ACC, 0, 0, 0);             \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CARO_BF(WH), CARO_BF(AM), ACC, 0, 0, 0);             \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CARO_BF(WM), CARO_BF(AH), ACC, 0, 0, 0);             \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CARO_BF(WH), CARO_BF(AH), ACC, 0, 0, 0);
-    uint4 xah, xam, xal, xw0h, xw0m, xw0l, xw1h, xw1m, xw1l;
-    uint4 yah, yam, yal, yw0h, yw0m, yw0l, yw1h, yw1m, yw1l;
-    CARO_LOAD3(xah, xam, xal, xw0h, xw0m, xw0l, xw1h, xw1m, xw1l, 0)
-#pragma unroll
-    for (int kb = 0; kb < 4; kb += 2) {
-      CARO_LOAD3(yah, yam, yal, yw0h, yw0m, yw0l, yw1h, yw1m, yw1l, kb + 1)
-      __builtin_amdgcn_sched_barrier(0);
-      CARO_MFMA3(acc0, xw0h, xw0m, xw0l, xah, xam, xal)
-      CARO_MFMA3(acc1, xw1h, xw1m, xw1l, xah, xam, xal)
-      __builtin_amdgcn_sched_barrier(0);
-      if (kb + 2 < 4) CARO_LOAD3(xah, xam, xal, xw0h, xw0m, xw0l, xw1h, xw1m, xw1l, kb + 2)
-      __builtin_amdgcn_sched_barrier(0);
-      CARO_MFMA3(acc0, yw0h, yw0m, yw0l, yah, yam, yal)
-      CARO_MFMA3(acc1, yw1h, yw1m, yw1l, yah, yam, yal)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#undef CARO_LOAD3
-#undef CARO_MFMA3
-#undef CARO_BF
-    if (has_next) {  // write late: the other buffer was last read one tap ago
-      uint4* dst = wbuf + (cur ^ 1) * W3_G;
-      dst[tid] = wn0;
-      dst[tid + NT] = wn1;
-      dst[tid + 2 * NT] = wn2;
-    }
-    if (tap == 8) {
-      __syncthreads();  // every wave has read this layer's input activations
-      // epilogue, in place: v = v + leaky(conv(v) + b); a lane holds 4 x 4 consecutive channels of its row
-      const float* bias = p.b_res + layer * NF;
-      const int row = wave * 32 + i;
-      const bool real = row < R;
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c0 = ct * 32 + 8 * q + 4 * h;
-          const int g = c0 >> 3, half = (c0 & 7) * 2;
-          char* ph = actb + agran(row, 0, g) * 16 + half;
-          char* pm = actb + agran(row, 1, g) * 16 + half;
-          char* pl3 = actb + agran(row, 2, g) * 16 + half;
-          float oldv[4], nv[4];
-          join3x4(*reinterpret_cast<uint2*>(ph), *reinterpret_cast<uint2*>(pm), *reinterpret_cast<uint2*>(pl3), oldv);
-          const float4 bc = *reinterpret_cast<const float4*>(bias + c0);
-          const float bb[4] = {bc.x, bc.y, bc.z, bc.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float a = ct == 0 ? acc0[4 * q + j] : acc1[4 * q + j];
-            nv[j] = real ? oldv[j] + leaky(a + bb[j], slope) : 0.f;
-          }
-          uint2 H, M, Lo;
-          split3x4(nv, H, M, Lo);
-          *reinterpret_cast<uint2*>(ph) = H;
-          *reinterpret_cast<uint2*>(pm) = M;
-          *reinterpret_cast<uint2*>(pl3) = Lo;
-        }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        acc0[e] = 0.f;
-        acc1[e] = 0.f;
-      }
-    }
-    __syncthreads();  // staged weights / new activations visible to every wave
-  }
-
-  // ---- heads: reconstruct float32 activations of the row, then as the float32 kernel
-  float* feat = reinterpret_cast<float*>(wbuf);  // [3][256]
-  int* omap = reinterpret_cast<int*>(feat + 768 + 20 * 32 + 1024 + 64);  // [TB] output rows, behind `stat`
-  if (tid < nb) omap[tid] = slot_v;
-  {
-    const int r = tid;
-    if (r < R) {
-      float s0 = p.b_head[0], s1 = p.b_head[1], s2 = p.b_head[2];
-      for (int g = 0; g < 8; ++g) {
-        const uint4 H = lds[agran(r, 0, g)], M = lds[agran(r, 1, g)], Lo = lds[agran(r, 2, g)];
-        float v[8];
-        join3x4(make_uint2(H.x, H.y), make_uint2(M.x, M.y), make_uint2(Lo.x, Lo.y), v);
-        join3x4(make_uint2(H.z, H.w), make_uint2(M.z, M.w), make_uint2(Lo.z, Lo.w), v + 4);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int c = g * 8 + j;
-          s0 = fmaf(v[j], p.w_head[c], s0);
-          s1 = fmaf(v[j], p.w_head[NF + c], s1);
-          s2 = fmaf(v[j], p.w_head[2 * NF + c], s2);
-        }
-      }
-      feat[r] = leaky(s0, slope);
-      feat[256 + r] = leaky(s1, slope);
-      feat[512 + r] = leaky(s2, slope);
-    }
-  }
-  __syncthreads();
-  float* hid = feat + 768;
-  float* logit = feat + 768 + 20 * 32;
-  for (int k = tid; k < nb * 20; k += NT) {
-    const int bi = k / 20, u = k - bi * 20;
-    float s = p.b_v1[u];
-    const float* w = p.w_v1 + u * HW;
-    const float* f = feat + bi * HW;
-    for (int c = 0; c < HW; ++c) s = fmaf(f[c], w[c], s);
-    hid[k] = leaky(s, slope);
-  }
-  for (int k = tid; k < nb * p.A; k += NT) {
-    const int bi = k / p.A, a = k - bi * p.A;
-    float s = p.b_p[a];
-    const float* w = p.w_p + (size_t)a * 2 * HW;
-    const float* f0 = feat + 256 + bi * HW;
-    const float* f1 = feat + 512 + bi * HW;
-    for (int c = 0; c < HW; ++c) s = fmaf(f0[c], w[c], s);
-    for (int c = 0; c < HW; ++c) s = fmaf(f1[c], w[HW + c], s);
-    logit[k] = s;
-  }
-  __syncthreads();
-  float* stat = logit + 256 * 4;
-  if (tid < nb) {
-    float s = p.b_v2[0];
-    for (int u = 0; u < 20; ++u) s = fmaf(hid[tid * 20 + u], p.w_v2[u], s);
-    values[slot_v] = tanhf(s);
-    float mx = -3.4e38f;
-    for (int a = 0; a < p.A; ++a) mx = fmaxf(mx, logit[tid * p.A + a]);
-    float sum = 0.f;
-    for (int a = 0; a < p.A; ++a) sum += expf(logit[tid * p.A + a] - mx);
-    stat[2 * tid] = mx;
-    stat[2 * tid + 1] = sum;
-  }
-  __syncthreads();
-  for (int k = tid; k < nb * p.A; k += NT) {
-    const int bi = k / p.A;
-    probs[(size_t)omap[bi] * p.A + (k - bi * p.A)] = expf(logit[k] - stat[2 * bi]) / stat[2 * bi + 1];
-  }
-}
-
-// ===================================================================================================
 // Table evaluator (caro_net_create_hash): priors and value are exact dyadic float32 functions of a 64-bit
 // hash of the leaf's planes (the arithmetic is integer only, so every implementation of the definition in
 // include/caro_hip.h gives the same bits).  It takes the place of the conv net wherever the search itself is to
@@ -2185,7 +1876,6 @@ struct caro_net {
   uint64_t salt;       // table evaluator
   cnet::NetParams p;
   float* dev;
-  uint4* w3_dev;  // split residual weights (3xbf16 mode), or null
   float* ww_dev;  // transformed residual weights (f32w mode), or null
   uint32_t* wtab_dev;  // tile table (f32w mode), or null
   float* ww2_dev;      // 2-D Winograd transformed residual weights (f32w2 mode), or null
@@ -2249,7 +1939,6 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   n->kind = 0;
   n->salt = 0;
   n->device = device_id;
-  n->w3_dev = nullptr;
   n->ww_dev = nullptr;
   n->wtab_dev = nullptr;
   n->ww2_dev = nullptr;
@@ -2284,7 +1973,6 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   p.b_v2 = q;   q += 1;
   p.w_p = q;    q += (size_t)A * 2 * HW;
   p.b_p = q;    q += A;
-  p.w3 = nullptr;
   p.ww = nullptr;
   p.wtab = nullptr;
   p.ww2 = nullptr;
@@ -2316,21 +2004,6 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   return 0;
 }
 
-/* opt-in 3xbf16 mode: upload the split residual weights (45 taps x 1536 granules x 8 bf16, LDS image order of
- * k_net_forward_3x, packed by caro_ai_amd/net_hip.py); from then on the forward calls of this net use the
- * bf16 MFMA pipe for the 3x3 convolutions (float32 accumulate, error below float32 rounding). */
-int caro_net_enable_3xbf16(caro_net* n, const uint16_t* w3_host, int64_t n_u16) {
-  if (!n || !w3_host) return nfail(CARO_E_INVAL, "null argument");
-  if (n->kind != 0) return nfail(CARO_E_STATE, "not a conv net");
-  const int64_t want = (int64_t)cnet::NTAPS * cnet::W3_G * 8;
-  if (n_u16 != want) return nfail(CARO_E_INVAL, "split weight image has the wrong size");
-  if (hipSetDevice(n->device) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
-  if (!n->w3_dev && hipMalloc((void**)&n->w3_dev, want * 2) != hipSuccess) return nfail(CARO_E_NOMEM, "hipMalloc failed");
-  if (hipMemcpy(n->w3_dev, w3_host, want * 2, hipMemcpyHostToDevice) != hipSuccess) return nfail(CARO_E_HIP, "hipMemcpy failed");
-  n->p.w3 = n->w3_dev;
-  return 0;
-}
-
 /* f32w mode: upload the row-Winograd F(2,3) transformed residual weights ([5][4 p][3 dx] chunks of 4096 floats in
  * the LDS image order of the plain residual weights, packed by caro_ai_amd/net_hip.py:pack_net_w); from then on the
  * forward calls of this net run k_net_forward_w: float32 MFMA like the default, two thirds of the multiplies.
@@ -2338,7 +2011,6 @@ int caro_net_enable_3xbf16(caro_net* n, const uint16_t* w3_host, int64_t n_u16) 
 int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats) {
   if (!n || !ww_host) return nfail(CARO_E_INVAL, "null argument");
   if (n->kind != 0) return nfail(CARO_E_STATE, "not a conv net");
-  if (n->p.w3) return nfail(CARO_E_STATE, "net is already in 3xbf16 mode");
   const int64_t want = (int64_t)cnet::WTAPS * cnet::WCHUNK;
   if (n_floats != want) return nfail(CARO_E_INVAL, "transformed weight image has the wrong size");
   if (hipSetDevice(n->device) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
@@ -2440,7 +2112,7 @@ int caro_net_winograd2d_supported(int H, int W) {
 int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_floats) {
   if (!n || !ww2_host) return nfail(CARO_E_INVAL, "null argument");
   if (n->kind != 0) return nfail(CARO_E_STATE, "not a conv net");
-  if (n->p.w3 || n->p.ww) return nfail(CARO_E_STATE, "net is already in another arithmetic mode");
+  if (n->p.ww) return nfail(CARO_E_STATE, "net is already in another arithmetic mode");
   if (!caro_net_winograd2d_supported(n->p.H, n->p.W))
     return nfail(CARO_E_INVAL, "2-D Winograd form: boards of one per workgroup with at most 8 x 8 tiles (12x12 .. 15x15)");
   const int64_t want = (int64_t)cnet::W2NCHUNK * cnet::WCH;
@@ -2458,7 +2130,6 @@ int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_flo
 
 void caro_net_destroy(caro_net* n) {
   if (!n) return;
-  if (n->w3_dev) (void)hipFree(n->w3_dev);
   if (n->ww_dev) (void)hipFree(n->ww_dev);
   if (n->wtab_dev) (void)hipFree(n->wtab_dev);
   if (n->ww2_dev) (void)hipFree(n->ww2_dev);
@@ -2485,7 +2156,6 @@ int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro
   n->salt = salt;
   n->device = device_id;
   n->dev = nullptr;
-  n->w3_dev = nullptr;
   n->ww_dev = nullptr;
   n->wtab_dev = nullptr;
   n->ww2_dev = nullptr;
@@ -2511,10 +2181,7 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
                        probs_dev, values_dev, gpack, G, B);
   } else {
     const unsigned grid = net_grid(n0, max_rows) + (which == 2 ? 1u : 0u);  // +1: each class rounds up
-    if (n0->p.w3)
-      hipLaunchKernelGGL(cnet::k_net_forward_3x, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
-                         counts_dev, which, row1, probs_dev, values_dev, gpack, G, B);
-    else if (n0->p.ww2) {
+    if (n0->p.ww2) {
       // the trunk launch leaves every board's three feature planes in n0's feature buffer; the FC heads of the whole
       // launch follow, 32 boards per workgroup (k_net_heads).  The buffer grows to the largest launch seen (first call).
       const int64_t need = max_rows + (row1 > 0 ? row1 : 0) + 64;
@@ -2565,7 +2232,7 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
 }
 static int pair_ok(const caro_net* n0, const caro_net* n1) {
   if (n0->p.H != n1->p.H || n0->p.W != n1->p.W || n0->p.A != n1->p.A) return nfail(CARO_E_INVAL, "nets differ in shape");
-  if (n0->kind != n1->kind || (n0->p.w3 == nullptr) != (n1->p.w3 == nullptr) ||
+  if (n0->kind != n1->kind || 
       (n0->p.ww == nullptr) != (n1->p.ww == nullptr) || (n0->p.ww2 == nullptr) != (n1->p.ww2 == nullptr))
     return nfail(CARO_E_INVAL, "nets differ in kind / arithmetic mode");
   return 0;
@@ -2617,7 +2284,7 @@ int caro_net_forward_stamped(caro_net* n, const float* planes_dev, const int32_t
                              int64_t max_rows, float* probs_dev, float* values_dev, uint64_t* stamps_dev,
                              void* stream) {
   if (!n || !stamps_dev) return nfail(CARO_E_INVAL, "null argument");
-  if (n->kind != 0 || n->p.w3) return nfail(CARO_E_STATE, "stamps: float32 conv kernels only");
+  if (n->kind != 0) return nfail(CARO_E_STATE, "stamps: conv kernels only");
   return net_launch(n, n, planes_dev, counts_dev, which, -1, max_rows, probs_dev, values_dev, nullptr, 0, 0,
                     (unsigned long long*)stamps_dev, stream);
 }

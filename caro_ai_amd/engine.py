@@ -27,7 +27,7 @@ COUNTER_NAMES = ["sims", "levels", "expansions", "terminals", "dropped", "overfl
 
 # inference= values served by the fused HIP net kernel -> HipNet mode
 # hipw: Winograd, the form chosen by the board (row form F(2,3); 2-D form F(2x2,3x3) from 13x13 up); hipw1 / hipw2 force one
-HIP_NET_MODES = {"hip": "f32", "hipw": "f32w", "hipw1": "f32w1", "hipw2": "f32w2", "hip3x": "3xbf16"}
+HIP_NET_MODES = {"hip": "f32", "hipw": "f32w", "hipw1": "f32w1", "hipw2": "f32w2"}
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
@@ -273,8 +273,10 @@ class SelfPlayEngine:
         nt, ng = C.c_int64(0), C.c_int64(0)
         _lib.check(self.L.caro_drain_tuples_end(self.h, C.addressof(nt), C.addressof(ng)))
         nt, ng = nt.value, ng.value
-        if nt == 0 and ng == 0:
-            return {"states": s[:0], "players": p[:0], "pi": pi[:0], "z": z[:0], "games": games[:0]}
+        if nt == 0 and ng == 0:  # (fresh zero-size tensors: a zero-row VIEW would keep the staging block alive as well)
+            self._dr = None
+            return {"states": s.new_empty((0, self.KW)), "players": p.new_empty((0,)), "pi": pi.new_empty((0, self.A)),
+                    "z": z.new_empty((0,)), "games": games.new_empty((0, 4))}
         out = {"states": s[:nt], "players": p[:nt], "pi": pi[:nt], "z": z[:nt], "games": games[:ng]}
         # A view keeps the WHOLE staging allocation alive.  Connect four: 3 MB, nothing.  15 x 15: G * 225 rows of
         # 1.8 KB = 106 MB per drain at 256 games, of which a move's finished games fill a few percent -- a consumer
@@ -324,7 +326,7 @@ class SelfPlayEngine:
         ms = (C.c_double * 8)()
         n = (C.c_int64 * 8)()
         _lib.check(self.L.caro_profile_read(self.h, ms, n, 1 if reset else 0))
-        return {k: (ms[i], n[i]) for i, k in enumerate(["select", "compact", "expand_backup", "step", "net", "empty"])}
+        return {k: (ms[i], n[i]) for i, k in enumerate(["select", "compact", "expand_backup", "step", "net", "null1", "null2"])}
 
     def live_games(self):
         out = C.c_int32(0)

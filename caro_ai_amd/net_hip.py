@@ -127,49 +127,12 @@ def wino2d_pays(H: int, W: int) -> bool:
     return 64 * 16 <= 0.75 * rows * 12
 
 
-def _bf16_rne(x32: np.ndarray) -> np.ndarray:
-    """float32 -> bf16 bits, round to nearest even (the rounding of k_net_forward_3x's bf16_rne)"""
-    u = x32.view(np.uint32).astype(np.uint64)
-    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
-
-
-def split3(x32: np.ndarray):
-    """exact three-way split x = hi + mid + lo (+ <= 2^-27 |x|) into bf16 bit patterns"""
-    x32 = np.ascontiguousarray(x32, dtype=np.float32)
-    hi = _bf16_rne(x32)
-    r = x32 - (hi << 16).astype(np.uint32).view(np.float32)
-    mid = _bf16_rne(r)
-    r = r - (mid << 16).astype(np.uint32).view(np.float32)
-    lo = _bf16_rne(r)
-    return hi.astype(np.uint16), mid.astype(np.uint16), lo.astype(np.uint16)
-
-
-def pack_net_3x(net: Net) -> np.ndarray:
-    """uint16[45 * 1536 * 8]: per tap the [split][co][k] bf16 rows of the folded 3x3 weights in the LDS image
-    order of k_net_forward_3x (granule g = k >> 3 of row (split, co) sits at ((s*64+co)*8 + (g ^ ((co>>1)&7))))."""
-    net = net.eval()
-    co = np.arange(64)[:, None]
-    k = np.arange(64)[None, :]
-    gran = (co * 8 + ((k >> 3) ^ ((co >> 1) & 7)))          # granule of (co, k) inside one split
-    idx = (gran * 8 + (k & 7))                               # u16 index inside one split
-    out = np.zeros((5, 9, 3, 64 * 64), np.uint16)
-    for li, blk in enumerate(net.residual_blocks()):
-        w, _ = _fold(blk)
-        w = w.cpu().numpy()                                   # [co, ci, ky, kx]
-        for tap in range(9):
-            parts = split3(w[:, :, tap // 3, tap % 3])        # each [co, ci=k]
-            for s_, part in enumerate(parts):
-                out[li, tap, s_, idx.reshape(-1)] = part.reshape(-1)
-    return out.reshape(-1)
-
-
 class HipNet:
     """Device-resident packed weights + the forward launch.
     mode "f32w" (default): float32 on v_mfma_f32_32x32x2_f32, the 3x3 convolutions in Winograd form -- the row form
                  F(2,3) ("f32w1"), or on large boards (13x13 up, one board per workgroup) the 2-D form F(2x2,3x3) ("f32w2").
     mode "f32w1" / "f32w2": that form, forced.
-    mode "f32": the same with direct 3x3 convolutions (a plain fma chain in k order).
-    mode "3xbf16": opt-in, 3x3 convolutions on the bf16 MFMA pipe with three-way split operands."""
+    mode "f32": the same with direct 3x3 convolutions (a plain fma chain in k order): the A/B baseline."""
 
     device_counts = True  # the engine may call forward_dev without knowing L on the host
 
@@ -191,9 +154,6 @@ class HipNet:
             w2 = pack_net_w2(net)
             assert w2.size == self.L.caro_net_winograd2d_size()
             _lib.check(self.L.caro_net_enable_winograd2d(self.h, w2.ctypes.data, w2.size))
-        elif mode == "3xbf16":
-            w3 = pack_net_3x(net)
-            _lib.check(self.L.caro_net_enable_3xbf16(self.h, w3.ctypes.data, w3.size))
         elif mode == "f32w1":
             ww = pack_net_w(net)
             _lib.check(self.L.caro_net_enable_winograd(self.h, ww.ctypes.data, ww.size))

@@ -252,7 +252,7 @@ def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_ba
 
 
 def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="cuda:0", seed=0,
-             reference_stores=False):
+             reference_stores=False, counts=False):
     """challenger (net1) vs champion (net2): `rounds` games, 20 x 16 sims, tau = 0 from move 0, one tree per
     player; returns challenger_win / (wins + losses + draws)  (train.py:120-149).
     With several ranks each plays a contiguous share of the rounds (round = game uid, so the set of games is the
@@ -283,7 +283,8 @@ def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="c
                                  mcts_batch_size=16, device=device)
                 res.append(r)
         wins, losses, draws = parallel.allreduce_counts((res.count(1), res.count(-1), res.count(0)), device)
-        return wins / max(1, wins + losses + draws)
+        ratio = wins / max(1, wins + losses + draws)
+        return (ratio, (wins, losses, draws)) if counts else ratio
     from caro_ai_amd.lib.utils import play_games
     lo, n = parallel.shard_rounds(rounds, rank, world)
     res = []
@@ -291,7 +292,8 @@ def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="c
         res = play_games(game, n, None, challenger, champion, steps_before_tau_0=0, mcts_searches=20,
                          mcts_batch_size=16, concurrent=n, seed=seed, uid_base=lo, device=device)
     wins, losses, draws = parallel.allreduce_counts((res.count(1), res.count(-1), res.count(0)), device)
-    return wins / max(1, wins + losses + draws)
+    ratio = wins / max(1, wins + losses + draws)
+    return (ratio, (wins, losses, draws)) if counts else ratio  # counts=True: + (wins, losses, draws) of the challenger
 
 
 class _NullWriter:
@@ -327,6 +329,71 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
+def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, reference_evaluate=False, ddp=False,
+        sample_seed=None, stop=None, log=print):
+    """The reference's training loop (train.py:165-217): self-play with the best net -> replay buffer -> TRAIN_ROUNDS SGD
+    steps -> every EVALUATE_EVERY_STEP iterations the arena gate (challenger = the net being trained against the best
+    net; promoted when its win ratio exceeds BEST_NET_WIN_RATIO: `NetWrapper.sync`, `best_%03d_%05d.dat`).
+    `games` self-play games per iteration (reference: PLAY_EPISODES = 1), `iterations` 0 = for ever.
+    sample_seed: seed of the replay sampling (None: torch's global generator, as the reference); stop(history) -> True
+    ends the loop early.  Returns the history: per trained iteration the three losses, per evaluation (iteration, win
+    ratio, promoted), the number of promotions, the best net wrapper."""
+    rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
+    writer = writer or _NullWriter()
+    best_net = NetWrapper(net)
+    optimizer = optim.SGD(net.parameters(), lr=cfg.LEARNING_RATE, momentum=0.9)
+    replay_buffer = DeviceReplayBuffer(game, cfg.REPLAY_BUFFER, device)
+    hist = {"loss_total": [], "loss_value": [], "loss_policy": [], "evaluations": [], "promotions": 0,
+            "best_net": best_net, "speed_nodes": [], "iterations": 0}
+    step_idx = best_idx = 0
+    while iterations == 0 or step_idx < iterations:
+        sp = self_play(game, replay_buffer, best_net.target_model, games, device=device, seed=step_idx,
+                       uid_base=step_idx * games * world, stagger=True)
+        step_idx += 1
+        hist["iterations"] = step_idx
+        hist["speed_nodes"].append(sp["speed_nodes"])
+        writer.add_scalar("speed_steps", sp["speed_steps"], step_idx)
+        writer.add_scalar("speed_nodes", sp["speed_nodes"], step_idx)
+        if rank == 0 and log:
+            log("Step %d, steps %3d, leaves %4d, steps/s %5.2f, leaves/s %6.2f, best_idx %d, replay %d" % (
+                step_idx, sp["steps"], sp["nodes"], sp["speed_steps"], sp["speed_nodes"], best_idx, len(replay_buffer)))
+        if len(replay_buffer) < cfg.MIN_REPLAY_TO_TRAIN:
+            continue
+        gen = None
+        if (ddp and world > 1) or sample_seed is not None:
+            gen = torch.Generator(device=replay_buffer.device)
+            gen.manual_seed((sample_seed or 0) + step_idx)  # ddp: every rank draws the same batches from its (identical) buffer
+        if ddp and world > 1:
+            losses = train_neural_net(game, replay_buffer, net, optimizer, device, generator=gen, ddp=True)
+        elif rank == 0:
+            losses = train_neural_net(game, replay_buffer, net, optimizer, device, generator=gen)
+        if rank == 0:
+            for k, v in losses.items():
+                writer.add_scalar(k, v, step_idx)
+                hist[k].append(float(v))
+        # (ddp: the parameters are already identical; the batch-norm running statistics are each rank's own: rank 0's go out)
+        parallel.broadcast_weights(net)
+        if step_idx % cfg.EVALUATE_EVERY_STEP == 0:
+            win_ratio = evaluate(game, net, best_net.target_model, rounds=cfg.EVALUATION_ROUNDS, device=device,
+                                 seed=step_idx, reference_stores=reference_evaluate)
+            if rank == 0 and log:
+                log("Net evaluated, win ratio = %.2f" % win_ratio)
+            writer.add_scalar("eval_win_ratio", win_ratio, step_idx)
+            promoted = win_ratio > cfg.BEST_NET_WIN_RATIO
+            hist["evaluations"].append((step_idx, win_ratio, promoted))
+            if promoted:
+                if rank == 0 and log:
+                    log("Net is better than cur best, sync")
+                best_net.sync()
+                best_idx += 1
+                hist["promotions"] = best_idx
+                if rank == 0 and saves_path:
+                    torch.save(net.state_dict(), os.path.join(saves_path, "best_%03d_%05d.dat" % (best_idx, step_idx)))
+        if stop is not None and stop(hist):
+            break
+    return hist
+
+
 def main(argv=None):
     args = parse_args(argv)
     rank, local_rank, world = parallel.init()
@@ -338,46 +405,8 @@ def main(argv=None):
     game = game_provider.get_game(args)
     net = Net(input_shape=game.obs_shape, actions_n=game.action_space).to(device)
     parallel.broadcast_weights(net)
-    best_net = NetWrapper(net)
-    optimizer = optim.SGD(net.parameters(), lr=cfg.LEARNING_RATE, momentum=0.9)
-    replay_buffer = DeviceReplayBuffer(game, cfg.REPLAY_BUFFER, device)
-    step_idx = best_idx = 0
-    while args.iterations == 0 or step_idx < args.iterations:
-        sp = self_play(game, replay_buffer, best_net.target_model, args.games, device=device, seed=step_idx,
-                       uid_base=step_idx * args.games * world, stagger=True)
-        step_idx += 1
-        writer.add_scalar("speed_steps", sp["speed_steps"], step_idx)
-        writer.add_scalar("speed_nodes", sp["speed_nodes"], step_idx)
-        if rank == 0:
-            print("Step %d, steps %3d, leaves %4d, steps/s %5.2f, leaves/s %6.2f, best_idx %d, replay %d" % (
-                step_idx, sp["steps"], sp["nodes"], sp["speed_steps"], sp["speed_nodes"], best_idx,
-                len(replay_buffer)), flush=True)
-        if len(replay_buffer) < cfg.MIN_REPLAY_TO_TRAIN:
-            continue
-        if args.ddp and world > 1:
-            gen = torch.Generator(device=replay_buffer.device)
-            gen.manual_seed(step_idx)  # every rank draws the same batches from its (identical) buffer
-            losses = train_neural_net(game, replay_buffer, net, optimizer, device, generator=gen, ddp=True)
-        elif rank == 0:
-            losses = train_neural_net(game, replay_buffer, net, optimizer, device)
-        if rank == 0:
-            for k, v in losses.items():
-                writer.add_scalar(k, v, step_idx)
-        # (ddp: the parameters are already identical; the batch-norm running statistics are each rank's own: rank 0's go out)
-        parallel.broadcast_weights(net)
-        if step_idx % cfg.EVALUATE_EVERY_STEP == 0:
-            win_ratio = evaluate(game, net, best_net.target_model, rounds=cfg.EVALUATION_ROUNDS, device=device,
-                                 seed=step_idx, reference_stores=args.reference_evaluate)
-            if rank == 0:
-                print("Net evaluated, win ratio = %.2f" % win_ratio)
-            writer.add_scalar("eval_win_ratio", win_ratio, step_idx)
-            if win_ratio > cfg.BEST_NET_WIN_RATIO:
-                if rank == 0:
-                    print("Net is better than cur best, sync")
-                best_net.sync()
-                best_idx += 1
-                if rank == 0:
-                    torch.save(net.state_dict(), os.path.join(saves_path, "best_%03d_%05d.dat" % (best_idx, step_idx)))
+    fit(game, net, device, args.games, iterations=args.iterations, saves_path=saves_path, writer=writer,
+        reference_evaluate=args.reference_evaluate, ddp=args.ddp, log=lambda m: print(m, flush=True))
     writer.close()
 
 

@@ -181,9 +181,10 @@ int caro_drain_tuples_end(caro_engine* h, int64_t* n_tuples, int64_t* n_games);
 int caro_counters(caro_engine* h, int64_t counters[8], void* stream);
 /* HIP-event timing of the path's kernels on the stream they are launched on (bench.py's live
  * roofline).  Kinds: 0 select, 1 scan+encode, 2 expand+backup, 3 step, 4 net forward (bracketed by the
- * caller with caro_profile_begin/_end around caro_net_forward), 5 an EMPTY pair (two event records with nothing
- * between them, taken behind every sampled net launch of caro_search_batch / caro_search_staggered: what a pair
- * costs by itself on the busy stream, to be subtracted from the other kinds' averages), 6-7 free.
+ * caller with caro_profile_begin/_end around caro_net_forward); 5 / 6 calibrate the pairs themselves: a pair
+ * around ONE launch of an empty kernel (E1) and a pair around TWO (E2), recorded behind every fourth sampled net
+ * launch of caro_search_batch / caro_search_staggered -- a pair adds o = 2 E1 - E2 (+ the sub-microsecond gap between
+ * two dependent launches) to the kernel it brackets, to be subtracted from the other kinds' averages; 7 free.
  * caro_profile_read synchronises on the recorded events; ms[] / launches[] are running totals. */
 int caro_profile_enable(caro_engine* h, int on);
 int caro_profile_begin(caro_engine* h, int kind, void* stream); /* returns a slot, or -1 when profiling is off */
@@ -237,10 +238,6 @@ typedef struct caro_net caro_net;
 int64_t caro_net_packed_size(int H, int W, int A);
 int caro_net_create(int H, int W, int A, float negative_slope, const float* packed_host, int64_t n_floats,
                     int device_id, caro_net** out);
-/* opt-in: evaluate the 3x3 convolutions of this net on the bf16 MFMA pipe with every float32 operand split into
- * three bf16 terms (six MFMAs per k-block, float32 accumulate; product error below float32 rounding).
- * w3_host: 45 taps x 1536 granules x 8 bf16 in the kernel's LDS image order (caro_ai_amd/net_hip.py packs it). */
-int caro_net_enable_3xbf16(caro_net* n, const uint16_t* w3_host, int64_t n_u16);
 /* f32w mode: the 3x3 convolutions in row-Winograd F(2,3) form (float32 MFMA, two thirds of the multiplies;
  * results differ from the direct form by float32 rounding only).  ww_host = [5][4][3][4096] floats from
  * caro_ai_amd/net_hip.py:pack_net_w ([layer][transformed tap p][dx], each in the order of the plain tap chunks); the

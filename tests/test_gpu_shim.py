@@ -368,8 +368,8 @@ def _compare_with_recorded_games(d, eng, g, n_moves):
 
 
 # the net arithmetic under test: fused HIP kernel (row-Winograd; the same forced onto full 128-row tiles, the
-# tile bench.py's 1024-game launches use; direct form; split-bf16) and the torch GEMM form
-NET_FORMS = ["hipw", "hipw-fulltiles", "hip", "hip3x", "gemm"]
+# tile bench.py's 1024-game launches use; direct form) and the torch GEMM form
+NET_FORMS = ["hipw", "hipw-fulltiles", "hip", "gemm"]
 
 
 @pytest.mark.parametrize("inference", NET_FORMS)

@@ -262,8 +262,8 @@ def test_kept_drains_do_not_pin_the_staging_block_on_large_boards(monkeypatch):
     from caro_ai_amd.engine import SelfPlayEngine
     from caro_ai_amd.lib.game.tictactoe import TicTacToe
     from caro_ai_amd.net_hip import HashNet
-    game = TicTacToe(15, 5)
-    G, S, B = 64, 1, 8
+    game = TicTacToe(15, 3)  # k = 3 on the 15 x 15 board: 225 actions per row as config 4, games that end early and
+    G, S, B = 64, 2, 8       # at different times (a few per move: the case in which a kept view pins the most)
 
     def run(limit):
         if limit is not None:
@@ -273,7 +273,7 @@ def test_kept_drains_do_not_pin_the_staging_block_on_large_boards(monkeypatch):
         torch.cuda.synchronize()
         base = torch.cuda.memory_allocated()
         kept, peak = [], 0
-        for _ in range(260):
+        for _ in range(120):
             eng.search(S, B)
             eng.step()
             kept.append(eng.drain(recycle=True))

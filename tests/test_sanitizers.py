@@ -15,7 +15,7 @@ from tests.conftest import ROOT
 @pytest.mark.skipif(shutil.which("gcc") is None or shutil.which("g++") is None, reason="needs gcc / g++")
 def test_oracle_and_host_helpers_under_asan_ubsan():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"])
-    env = dict(os.environ, CARO_ASAN_K="not real_weights and not conv_net")
+    env = dict(os.environ, CARO_ASAN_K="not real_weights and not conv_net and not arena_32")
     env.pop("LD_PRELOAD", None)
     r = subprocess.run(["sh", os.path.join(ROOT, "oracle", "asan", "run.sh")], env=env, capture_output=True, text=True,
                        timeout=900)

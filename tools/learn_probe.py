@@ -41,11 +41,14 @@ def run(kind="ttt", iterations=12, games=256, every=2, seed=0, verbose=True):
         msg = "it %2d  replay %5d  loss %.4f (v %.4f  p %.4f)  %.0f exp/s" % (
             it, len(rb), ls["loss_total"], ls["loss_value"], ls["loss_policy"], sp["speed_nodes"])
         if it % every == 0:
-            r = train.evaluate(game, net, best.target_model, rounds=cfg.EVALUATION_ROUNDS, device=dev, seed=it)
-            r0 = train.evaluate(game, net, initial, rounds=cfg.EVALUATION_ROUNDS, device=dev, seed=1000 + it)
+            r, wld = train.evaluate(game, net, best.target_model, rounds=cfg.EVALUATION_ROUNDS, device=dev, seed=it,
+                                    counts=True)
+            r0, wld0 = train.evaluate(game, net, initial, rounds=cfg.EVALUATION_ROUNDS, device=dev, seed=1000 + it,
+                                      counts=True)
             hist["gate"].append(r)
             hist["vs_initial"].append(r0)
-            msg += "  | vs best %.2f  vs initial %.2f" % (r, r0)
+            hist.setdefault("wld_vs_initial", []).append(wld0)
+            msg += "  | vs best %.2f %s  vs initial %.2f %s" % (r, wld, r0, wld0)
             if r > cfg.BEST_NET_WIN_RATIO:
                 best.sync()
                 hist["promotions"] += 1
@@ -60,4 +63,5 @@ if __name__ == "__main__":
     a = sys.argv[1:]
     h = run(a[0] if a else "ttt", int(a[1]) if len(a) > 1 else 12, int(a[2]) if len(a) > 2 else 256,
             int(a[3]) if len(a) > 3 else 2)
-    print({k: (v if not isinstance(v, list) else [round(x, 3) for x in v]) for k, v in h.items()})
+    print({k: (v if not isinstance(v, list) else [round(float(x), 3) if not isinstance(x, tuple) else x for x in v])
+           for k, v in h.items()})

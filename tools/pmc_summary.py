@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 # longest names first: the first key found in the (mangled) kernel name wins
-SHORT = {"k_tree": "k_tree", "k_net_forward_w": "k_net_forward_w", "k_net_forward_3x": "k_net_forward_3x", "k_select": "k_select",
+SHORT = {"k_tree": "k_tree", "k_net_forward_w": "k_net_forward_w", "k_select": "k_select",
          "k_net_forward": "k_net_forward", "k_expand_backup": "k_expand_backup",
          "k_encode": "k_encode", "k_scan": "k_scan", "k_step": "k_step", "k_drain_copy": "k_drain_copy"}
 
