@@ -2392,8 +2392,11 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   v.hcap = hc;
   if (v.A > 256 || v.maxd > 255) { delete h; return fail(CARO_E_INVAL, "board too large for the path records (actions < 256, depth <= 255)"); }
   {
+    // experiment knobs (tools/exp/slot_alias.sh; NOTES round 5: neither changes the tree kernel's time), result-neutral
     const char* e = getenv("CARO_TREE_SKEW");
-    v.tstride = hc + (e ? atoi(e) : 0);
+    const long skew = e ? strtol(e, nullptr, 0) : 0;
+    if (skew < 0 || skew > 65536) { delete h; return fail(CARO_E_INVAL, "CARO_TREE_SKEW must be 0 .. 65536 slots"); }
+    v.tstride = hc + (int)skew;
     e = getenv("CARO_SLOT_ROT");
     v.slot_rot = e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
   }
