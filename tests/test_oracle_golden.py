@@ -456,3 +456,27 @@ def test_arena_32_games_vs_reference(name):
             assert g["pi"][ply].index(1.0) == n.index(max(n)) and sum(g["pi"][ply]) == 1.0
         res.append(r["result"])
     assert {"wins": res.count(1), "losses": res.count(-1), "draws": res.count(0)} == d["tally"]
+
+
+def test_reference_callers_themselves_produce_the_round4_fixtures():
+    """the persistent-store fixtures of round 4 were recorded by calling the reference's `play_game` in a hand-written
+    copy of the call pattern of `self_play` / `evaluate`.  tests/golden/make_golden_r5_callers.py ran the reference's
+    OWN `train.self_play` (ref train.py:24-59) and `train.evaluate` (:120-149) under the same harness and asserted, ply
+    by ply, that they produce exactly those fixtures; what it wrote down is compared here with the fixtures the oracle
+    (above) and the GPU shim (tests/test_gpu_shim.py) reproduce bit for bit: the drop-in callers are pinned to the real
+    functions, not to a reading of them."""
+    chk = load_golden("callers_check.json.gz")
+    sp = load_golden("persist_selfplay_c4.json.gz")
+    ev = load_golden("persist_evaluate_c4.json.gz")
+    assert [(c["uid"], c["result"], c["steps"], c["store_len_after"]) for c in chk["self_play"]["calls"]] == \
+        [(g["uid"], g["result"], g["steps"], g["store_len_after"]) for g in sp["games"]]
+    for c, g in zip(chk["self_play"]["calls"], sp["games"]):
+        h = hashlib.sha256()
+        r = g["replay"]
+        for s, p, pi, z in zip(r["states"], r["players"], r["pi"], r["z"]):
+            h.update(("%d|%d|%s|%d;" % (int(s), int(p), ",".join(repr(float(x)) for x in pi), int(z))).encode())
+        assert h.hexdigest() == c["replay_sha256"] and len(r["z"]) == c["replay_rows"]
+    assert chk["self_play"]["tracked"] == ["speed_nodes", "speed_steps"]   # the metric names train.py:53-54 reports
+    assert [(c["uid"], c["result"], c["steps"]) for c in chk["evaluate"]["rounds"]] == \
+        [(g["uid"], g["result"], g["steps"]) for g in ev["rounds"]]
+    assert chk["evaluate"]["win_ratio"] == ev["win_ratio"]

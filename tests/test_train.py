@@ -291,3 +291,56 @@ def test_self_play_closes_its_engine_when_a_move_fails(monkeypatch):
     with pytest.raises(_lib.CaroError, match="injected failure"):
         train.self_play(g, rb, net, 64, device="cuda:0", stagger=True)
     assert len(seen["engines"]) == 1 and seen["engines"][0].h is None   # closed on the failure path
+
+
+def test_train_step_equals_the_step_recorded_from_the_reference():
+    """f1 PINNED (round 5): the reference's own `train_neural_net` (ref train.py:62-117) was run in the build container
+    (tests/golden/make_golden_r5_train.py says how a function of that script can be run: a never-called stand-in for the
+    tensorboardX import, the module globals `net` / `step_idx` set as `__main__` would) on the tuples of 32 recorded
+    games, the shipped best_026_12000.dat, SGD(0.1, 0.9), its own TRAIN_ROUNDS = 10 x BATCH_SIZE = 256, with the
+    indices `random.sample` drew logged.  `caro_ai_amd.train.train_neural_net` on the CPU, fed the same ten batches:
+    the three loss means and EVERY tensor of the state_dict afterwards -- weights, biases, batch-norm running statistics
+    and counters -- bit for bit (same torch build, same operations in the same order)."""
+    import hashlib
+    from caro_ai_amd import train
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    from tests.conftest import GOLDEN, load_golden
+    torch.set_num_threads(1)
+    fx = load_golden("train_step_c4.json.gz")
+    g = ConnectFour()
+    d = load_golden(fx["tuples_from"])
+    states, players, pis, zs = [], [], [], []
+    for gm in d["games"]:
+        states += [int(s) for s in gm["states"]]
+        players += gm["players"]
+        pis += gm["pi"]
+        zs += gm["z"]
+    assert len(zs) == fx["n_tuples"]
+    assert (cfg.TRAIN_ROUNDS, cfg.BATCH_SIZE, cfg.LEARNING_RATE) == (fx["train_rounds"], fx["batch_size"], fx["lr"])
+
+    class Recorded(train.DeviceReplayBuffer):
+        """the ring with `sample` replaced by the batches the reference drew"""
+        calls = 0
+
+        def sample(self, batch_size, generator=None):
+            idx = torch.tensor(fx["indices"][self.calls], dtype=torch.int64)
+            self.calls += 1
+            assert idx.numel() == batch_size
+            return self.states[idx], self.players[idx], self.pi[idx], self.z[idx]
+
+    rb = Recorded(g, cfg.REPLAY_BUFFER, "cpu")
+    rb.extend({"states": torch.from_numpy(g.to_keys(states).view(np.int64)), "players": torch.tensor(players, dtype=torch.int32),
+               "pi": torch.tensor(pis, dtype=torch.float64), "z": torch.tensor(zs, dtype=torch.int32)})
+    net = Net(g.obs_shape, g.action_space)
+    net.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", fx["weights"]), map_location="cpu"))
+    opt = torch.optim.SGD(net.parameters(), lr=cfg.LEARNING_RATE, momentum=fx["momentum"])
+    out = train.train_neural_net(g, rb, net, opt, device="cpu")
+    assert rb.calls == fx["train_rounds"]
+    for k, v in fx["losses"].items():
+        assert abs(out[k] - v) <= 1e-12 * max(1.0, abs(v)), (k, out[k], v)
+    sd = net.state_dict()
+    assert set(sd) == set(fx["state_dict"])
+    differ = [k for k, t in sd.items()
+              if hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest() != fx["state_dict"][k]["sha256"]]
+    assert not differ, [(k, float(sd[k].double().sum()), fx["state_dict"][k]["sum"]) for k in differ[:5]]
