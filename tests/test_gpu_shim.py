@@ -792,3 +792,54 @@ def test_evaluate_with_reference_stores_reproduces_the_reference_rounds():
             U.play_game = inner
     assert [r for r, _ in seen] == [gm["result"] for gm in rounds]
     assert ratio == d["win_ratio"]
+
+
+def test_reference_play_script_loop_on_this_packages_play_game():
+    """INTEGRATION level 1 at script level.  The reference's arena script play.py (ref play.py:15-76) was RUN as
+    `__main__` in the build container (tests/golden/make_golden_r5_play.py: numpy seeded, the shipped checkpoints, two
+    rounds per ordered pair, its own 40 x 8 sims per move, fresh stores per game; harness: eval-mode nets) and what it
+    printed was recorded.  Here the loop of that script runs on THIS package's modules -- `lib.model.Net`,
+    `lib.utils.play_game`, `lib.utils.update_counts`, `config` -- with the same seed (play_game draws the opener, the
+    Dirichlet rows and the moves from numpy's global generator exactly where the reference does) and the nets on the
+    CPU (so the net arithmetic is the reference's; the trees are on the GPU): every game's (result, steps) and every
+    printed line are the reference's."""
+    from caro_ai_amd import config as cfg
+    from caro_ai_amd.lib import model, utils
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    torch.set_num_threads(1)
+    fx = load_golden("play_script_c4.json.gz")
+    assert (cfg.PLAY_MCTS_SEARCHES, cfg.PLAY_MCTS_BATCH_SIZE) == (fx["searches"], fx["batch"])
+    game = ConnectFour()
+    nets = []
+    for fname in fx["models"]:
+        net = model.Net(game.obs_shape, game.action_space)
+        net.load_state_dict(torch.load(os.path.join(GOLDEN, "weights", fname), map_location=lambda storage, loc: storage))
+        nets.append((fname, net.eval()))
+    lines, games = [], []
+    total_agent = {}
+    np.random.seed(fx["seed"])
+    for idx1, n1 in enumerate(nets):
+        for idx2, n2 in enumerate(nets):
+            if idx1 == idx2:
+                continue
+            wins, losses, draws = 0, 0, 0
+            for _ in range(fx["rounds"]):
+                r, steps = utils.play_game(game=game, mcts_stores=None, replay_buffer=None, net1=n1[1], net2=n2[1],
+                                           steps_before_tau_0=0, mcts_searches=cfg.PLAY_MCTS_SEARCHES,
+                                           mcts_batch_size=cfg.PLAY_MCTS_BATCH_SIZE, device="cpu")
+                games.append([int(r), int(steps)])
+                if r > 0.5:
+                    wins += 1
+                elif r < -0.5:
+                    losses += 1
+                else:
+                    draws += 1
+            lines.append("%s vs %s -> w=%d, l=%d, d=%d" % (n1[0], n2[0], wins, losses, draws))
+            utils.update_counts(total_agent, n1[0], (wins, losses, draws))
+            utils.update_counts(total_agent, n2[0], (losses, wins, draws))
+    leaders = sorted(total_agent.items(), reverse=True, key=lambda p: p[1][0])
+    lines.append("Leaderboard:")
+    for name, (w, l, d) in leaders:
+        lines.append("%s: \t w=%d, l=%d, d=%d" % (name, w, l, d))
+    assert games == fx["games"], (games, fx["games"])
+    assert lines == fx["stdout"], (lines, fx["stdout"])
