@@ -843,3 +843,50 @@ def test_reference_play_script_loop_on_this_packages_play_game():
         lines.append("%s: \t w=%d, l=%d, d=%d" % (name, w, l, d))
     assert games == fx["games"], (games, fx["games"])
     assert lines == fx["stdout"], (lines, fx["stdout"])
+
+
+@pytest.mark.parametrize("kind", ["c4", "ttt3"])
+def test_play_session_follows_the_reference_session(kind):
+    """SURVEY 8(f) rank 4, pinned: the reference's `lib/play_session.Session` (ref lib/play_session.py:7-49) was driven
+    through whole games in the build container (tests/golden/make_golden_r5_session.py: a scripted human, the bot's
+    `move_bot` = 40 x 8 sims on the session's persistent store, tau = 0, numpy seeded; harness: eval-mode net).  This
+    package's Session with the same seed and the same human -- the net on the CPU, so that its arithmetic is the
+    reference's, the tree on the GPU -- makes the same moves, reports the same position values, renders the same
+    boards and ends with a store of the same size."""
+    from caro_ai_amd import config as cfg
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from caro_ai_amd.lib.play_session import Session
+    torch.set_num_threads(1)
+    fx = load_golden("session.json.gz")
+    assert (cfg.BOT_MCTS_SEARCHES, cfg.BOT_MCTS_BATCH_SIZE) == (fx["searches"], fx["batch"])
+    game = ConnectFour() if kind == "c4" else TicTacToe()
+    for gm in fx[kind]["games"]:
+        np.random.seed(gm["seed"])
+        s = Session(game, os.path.join(GOLDEN, "weights", fx[kind]["weights"]), gm["player_moves_first"], device="cuda:0")
+        s.model.cpu()      # the net where the reference's runs ...
+        s.device = "cpu"   # ... the tree stays on the GPU (MCTS(tree_device="cuda:0"))
+        turns, outcome, turn = [], None, 0
+        while outcome is None:
+            if gm["player_moves_first"] or turns:
+                legal = game.possible_moves(s.state)
+                mv = int(legal[(3 * turn + 1) % len(legal)])
+                assert s.is_valid_move(mv)
+                if s.move_player(mv):
+                    outcome = "human"
+                    break
+                if s.is_draw():
+                    outcome = "draw"
+                    break
+            won = s.move_bot()
+            want = gm["turns"][len(turns)]
+            got = {"move": int(s.moves[-1]), "value": float(s.value), "state": str(s.state), "render": s.render()}
+            assert got == want, (kind, gm["seed"], len(turns), got, want)
+            turns.append(got)
+            if won:
+                outcome = "bot"
+            elif s.is_draw():
+                outcome = "draw"
+            turn += 1
+        assert outcome == gm["outcome"] and [int(m) for m in s.moves] == gm["moves"] and len(turns) == len(gm["turns"])
+        assert len(s.mcts_store) == gm["store_len"]
