@@ -851,8 +851,8 @@ def test_play_session_follows_the_reference_session(kind):
     through whole games in the build container (tests/golden/make_golden_r5_session.py: a scripted human, the bot's
     `move_bot` = 40 x 8 sims on the session's persistent store, tau = 0, numpy seeded; harness: eval-mode net).  This
     package's Session with the same seed and the same human -- the net on the CPU, so that its arithmetic is the
-    reference's, the tree on the GPU -- makes the same moves, reports the same position values, renders the same
-    boards and ends with a store of the same size."""
+    reference's, the tree on the GPU -- makes the same moves, reports the same position values (to 1e-5), renders the
+    same boards and ends with a store of the same size."""
     from caro_ai_amd import config as cfg
     from caro_ai_amd.lib.game.connect_four import ConnectFour
     from caro_ai_amd.lib.game.tictactoe import TicTacToe
@@ -881,7 +881,13 @@ def test_play_session_follows_the_reference_session(kind):
             won = s.move_bot()
             want = gm["turns"][len(turns)]
             got = {"move": int(s.moves[-1]), "value": float(s.value), "state": str(s.state), "render": s.render()}
-            assert got == want, (kind, gm["seed"], len(turns), got, want)
+            # moves, boards and the rendered board exactly; the reported value (a float32 Q = W / N whose W sums the
+            # net's values) to 1e-5: torch's CPU convolutions differ in the last bit between the build container's
+            # processor and the GPU box's, which no visit count of these games notices but a printed float does
+            assert (got["move"], got["state"]) == (want["move"], want["state"]), (kind, gm["seed"], len(turns), got, want)
+            assert abs(got["value"] - want["value"]) <= 1e-5, (got["value"], want["value"])
+            board = lambda r: r[r.index("<pre>"):]
+            assert board(got["render"]) == board(want["render"]) and got["render"].startswith("Position evaluation: ")
             turns.append(got)
             if won:
                 outcome = "bot"
