@@ -34,7 +34,24 @@ class ConnectFour(PackedGame):
     def from_key(self, key):
         return int(np.asarray(key, dtype=np.uint64).reshape(-1)[0])
 
-    # list form <-> int, for callers that used the reference's codec (:108-147)
+    # list form <-> int, for callers that used the reference's codec (:94-155)
+    @staticmethod
+    def bits_to_int(bits):
+        """most significant bit first (:95-100)"""
+        value = 0
+        for bit in bits:
+            value = (value << 1) | int(bit)
+        return value
+
+    @staticmethod
+    def int_to_bits(num, bits):
+        """the low `bits` bits of num, most significant first (:103-108)"""
+        return [(int(num) >> shift) & 1 for shift in range(bits - 1, -1, -1)]
+
+    def convert_mcts_state_to_nn_state(self, mcts_state):
+        """the list view of a state (:149-155)"""
+        return self.decode_binary(mcts_state)
+
     def decode_binary(self, state_int):
         assert isinstance(state_int, int)
         cols = []

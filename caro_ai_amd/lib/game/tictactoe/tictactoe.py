@@ -28,6 +28,25 @@ class TicTacToe(PackedGame):
     def obs_shape(self):
         return (2, self.board_len, self.board_len)
 
+    # matrix form <-> int, for callers that used the reference's codec (:44-135)
+    @staticmethod
+    def flatten_nested_list(nested_list):
+        return [cell for row in nested_list for cell in row]
+
+    def _pad_mcts_state(self, mcts_state_str):
+        """leading zeros of the digit string are tokens of player 0 (:89-100)"""
+        return mcts_state_str.rjust(self._cells, "0")
+
+    def encode_game_state(self, state_list):
+        """rows of tokens (0 / 1, 2 = empty) -> the base-10 state int (:102-114)"""
+        return int("".join(str(int(cell)) for row in state_list for cell in row))
+
+    def convert_mcts_state_to_list_state(self, mcts_state):
+        """the base-10 state int -> rows of tokens (:116-135)"""
+        d = self._digits(mcts_state)
+        n = self.board_len
+        return [[int(d[r * n + c]) for c in range(n)] for r in range(n)]
+
     def _digits(self, state_int):
         s = str(int(state_int)).rjust(self._cells, "0")  # leading zeros are tokens of player 0 (:88-100)
         return np.frombuffer(s.encode(), dtype=np.uint8) - ord("0")
@@ -60,7 +79,7 @@ class TicTacToe(PackedGame):
 
     def render(self, mcts_state):
         d = self._digits(mcts_state)
-        sym = {0: "X", 1: "O"}
+        sym = {self.player_white: "\u274c", self.player_black: "\u2b55"}  # the reference's cross / circle marks (tictactoe.py:252-255)
         rows = []
         for r in range(self.board_len):
             cells = [sym.get(int(d[r * self.board_len + c]), str(r * self.board_len + c))

@@ -26,6 +26,7 @@ moved there and the priors back, lib/mcts.py:214-218).  The tree itself is
 always on the GPU; there is no CPU search path.
 """
 import ctypes as C
+import math as m
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -292,6 +293,37 @@ class MCTS:
     value = property(lambda self: self._view("W"), lambda self, m: self._assign("W", m))
     value_avg = property(lambda self: self._view("Q"), lambda self, m: self._assign("Q", m))
     probs = property(lambda self: self._view("P"), lambda self, m: self._assign("P", m))
+
+    # ------------------------------------------------------------ the reference's per-step helpers, host side
+    # The search runs in the kernels (descend_level: noise, PUCT, mask, argmax in one pass); these are the same
+    # formulas on Python lists for callers (and tests) that reach into the reference's MCTS -- same names, arguments,
+    # results and numpy draws as lib/mcts.py:48-95, 192-223.  The engine never calls them.
+    def _add_noise(self, probs):
+        """(1 - EXPLORE) * P + EXPLORE * Dirichlet(ALPHA) over ALL actions; one draw from numpy's global stream"""
+        noise = np.random.dirichlet([cfg.ALPHA] * self.game.action_space)
+        keep = 1 - cfg.EXPLORE
+        return [keep * p + cfg.EXPLORE * n for p, n in zip(probs, noise)]
+
+    def _calculate_upper_bound(self, values_avg, probs, counts):
+        """Q + c_puct * P * sqrt(sum N) / (1 + N) per action (no +1 under the root: all zero at a fresh node)"""
+        root = m.sqrt(sum(counts))
+        return [q + self.c_puct * p * root / (1 + n) for q, p, n in zip(values_avg, probs, counts)]
+
+    def _mask_invalid_actions(self, scores, cur_state):
+        """-inf on the illegal actions of `cur_state`, in place"""
+        for a in self.game.invalid_moves(cur_state):
+            scores[a] = -np.inf
+
+    def _expand_tree(self, expand_states, expand_players, expand_queue, backup_queue, net, device="cpu"):
+        """evaluate the queued leaves in one batch, create their nodes, queue their backups (lib/mcts.py:192-223)"""
+        import torch.nn.functional as F
+        planes = torch.tensor(self.game.states_to_training_batch(expand_states, expand_players)).to(device)
+        with torch.no_grad():
+            logits, values = net(planes)
+        priors = F.softmax(logits, dim=1).cpu().numpy()
+        for (leaf_state, states, actions), value, prior in zip(expand_queue, values.cpu().numpy()[:, 0], priors):
+            self._create_node(leaf_state, prior)
+            backup_queue.append((value, states, actions))
 
     # ------------------------------------------------------------ pieces the reference's tests poke
     def _create_node(self, leaf_state: int, prob):

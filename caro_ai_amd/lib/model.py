@@ -44,6 +44,15 @@ class Net(nn.Module):
         self.conv_policy = _conv_block(NUM_FILTERS, 2, 1, 0)
         self.policy = nn.Sequential(nn.Linear(2 * cells, actions_n))
 
+    # the reference's shape probes (lib/model.py:74-80): how many features the 1x1 heads hand to their linear layers
+    # for a trunk output of `shape` = (filters, H, W).  The constructor above knows the answer (1 or 2 planes of H*W
+    # cells); the probes stay for callers that ask the net itself.
+    def _get_conv_val_size(self, shape):
+        return int(self.conv_val[0].out_channels * shape[1] * shape[2])
+
+    def _get_conv_policy_size(self, shape):
+        return int(self.conv_policy[0].out_channels * shape[1] * shape[2])
+
     def residual_blocks(self):
         return [getattr(self, "conv_%d" % i) for i in range(1, self.N_RESIDUAL + 1)]
 

@@ -25,6 +25,43 @@ def update_counts(counts_dict, key, counts):
     counts_dict[key] = (v[0] + counts[0], v[1] + counts[1], v[2] + counts[2])
 
 
+class TBMeanTracker:
+    """The metric tracker train.py wraps its loop in (`with TBMeanTracker(writer, batch_size=10) as tb_tracker`,
+    reference lib/utils.py:111-159): `track(name, value, step)` collects values per name and, every `batch_size`-th
+    value of a name, writes their mean to `writer.add_scalar(name, mean, step)`; leaving the block closes the writer.
+    Values may be numbers, numpy arrays / scalars or tensors (their mean is what counts)."""
+
+    def __init__(self, writer, batch_size):
+        assert isinstance(batch_size, int)
+        assert writer is not None
+        self.writer = writer
+        self.batch_size = batch_size
+
+    def __enter__(self):
+        self._batches = collections.defaultdict(list)
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self.writer.close()
+
+    @staticmethod
+    def _as_float(value):
+        import torch
+        assert isinstance(value, (float, int, np.ndarray, np.generic)) or torch.is_tensor(value)
+        if torch.is_tensor(value):
+            return value.detach().float().mean().item()
+        return float(np.mean(value))
+
+    def track(self, param_name, value, iter_index):
+        assert isinstance(param_name, str)
+        assert isinstance(iter_index, int)
+        pending = self._batches[param_name]
+        pending.append(self._as_float(value))
+        if len(pending) >= self.batch_size:
+            self.writer.add_scalar(param_name, np.mean(pending), iter_index)
+            pending.clear()
+
+
 def _first_mover(net1_plays_first):
     """player index (0 = net1) that opens the game; `None` draws it from numpy's global stream (utils.py:65-68)"""
     if net1_plays_first is None:

@@ -64,6 +64,21 @@ def main():
     for k in ("c4", "ttt3"):
         for g in out[k]["games"]:
             print(k, g["player_moves_first"], g["outcome"], g["moves"], g["store_len"])
+    # `render` of other boards (the session only shows 6x7 and 3x3): a few random positions each
+    rng = np.random.default_rng(5)
+    renders = []
+    for kind, n, k, game in (("c4", 0, 0, c4), ("mnk", 3, 3, ttt), ("mnk", 5, 4, mg.TicTacToe(5, 4)),
+                             ("mnk", 15, 5, mg.TicTacToe(15, 5))):
+        for _ in range(3):
+            st, pl = game.initial_state, 0
+            for _ply in range(int(rng.integers(1, 12))):
+                legal = game.possible_moves(st)
+                st, won = game.move(st, int(legal[int(rng.integers(len(legal)))]), pl)
+                pl = 1 - pl
+                if won:
+                    break
+            renders.append({"kind": kind, "n": n, "k": k, "state": str(st), "render": game.render(st)})
+    out["renders"] = renders
     mg.dump("session.json.gz", out)
 
 

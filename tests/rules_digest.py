@@ -57,3 +57,49 @@ def block_digest(game, seed, block, n_plies, A):
 
     wins, draws = playout_block(game, seed, block, n_plies, A, sink)
     return {"sha256": h.hexdigest(), "wins": wins, "draws": draws}
+
+
+def helpers_digest(helpers, n, seed, cases):
+    """SHA-256 over what the six line helpers of the m,n,k game return on `cases` random n x n boards and cells
+    (tests/golden/make_golden_r5_helpers.py runs it on the reference's module, the test on this package's)"""
+    rng = np.random.default_rng([seed, n])
+    h = hashlib.sha256()
+    for _ in range(cases):
+        m = rng.integers(0, 3, size=(n, n)).tolist()  # tokens 0 / 1, 2 = empty
+        c = (int(rng.integers(n)), int(rng.integers(n)))
+        lines = [f(m, c) for f in (helpers.get_row, helpers.get_col, helpers.get_diag, helpers.get_antidiag)]
+        h.update(repr(lines).encode())
+        for k in (3, 4, 5):
+            for tok in (0, 1):
+                h.update(bytes([int(helpers.k_in_a_row(ln, k, tok)) for ln in lines]))
+                h.update(bytes([int(helpers.check_win(m, c, k, tok))]))
+    return h.hexdigest()
+
+
+def codec_digest(game, seed, cases):
+    """SHA-256 over the list / matrix views of `cases` random positions of `game` through the codec helpers a caller of
+    the reference can reach: connect four -- decode_binary, convert_mcts_state_to_nn_state, int_to_bits, bits_to_int,
+    encode_lists; m,n,k -- convert_mcts_state_to_list_state, encode_game_state, flatten_nested_list, _pad_mcts_state"""
+    rng = np.random.default_rng([seed, game.action_space])
+    h = hashlib.sha256()
+    c4 = hasattr(game, "decode_binary")
+    for _ in range(cases):
+        s, p = game.initial_state, 0
+        for _ply in range(int(rng.integers(0, min(30, game.action_space * 3)))):
+            legal = game.possible_moves(s)
+            if not legal:
+                break
+            s, won = game.move(s, int(legal[int(rng.integers(len(legal)))]), p)
+            p = 1 - p
+            if won:
+                break
+        if c4:
+            cols = game.decode_binary(s)
+            bits = game.int_to_bits(s, 63)
+            assert game.encode_lists(cols) == s and game.bits_to_int(bits) == s
+            h.update(repr((cols, game.convert_mcts_state_to_nn_state(s), bits, game.int_to_bits(s, 3))).encode())
+        else:
+            m = game.convert_mcts_state_to_list_state(s)
+            assert game.encode_game_state(m) == s
+            h.update(repr((m, game.flatten_nested_list(m), game._pad_mcts_state(str(s)))).encode())
+    return h.hexdigest()

@@ -237,3 +237,124 @@ def test_hot_kernels_do_not_spill():
                     seen += 1
                     assert k[".private_segment_fixed_size"] == 0, (name, k[".private_segment_fixed_size"])
     assert seen >= 5
+
+
+def test_render_is_the_references_text():
+    """`BaseGame.render` (what the chat front end shows; ref connect_four.py / tictactoe.py:237-259) on positions the
+    reference rendered (tests/golden/make_golden_r5_session.py): the boards of two whole sessions per game, and random
+    positions on 6x7, 3x3, 5x5 and 15x15 -- character for character (the m,n,k marks are the reference's cross / circle)"""
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    from tests.conftest import load_golden
+    fx = load_golden("session.json.gz")
+    n = 0
+    for kind, game in (("c4", ConnectFour()), ("ttt3", TicTacToe())):
+        for gm in fx[kind]["games"]:
+            for t in gm["turns"]:
+                r = t["render"]
+                assert game.render(int(t["state"])) == r[r.index("<pre>") + 5:-len("</pre>")]
+                n += 1
+    for r in fx["renders"]:
+        game = ConnectFour() if r["kind"] == "c4" else TicTacToe(r["n"], r["k"])
+        assert game.render(int(r["state"])) == r["render"], r
+        n += 1
+    assert n > 30
+
+
+def test_tictactoe_helpers_known_answers_and_reference_digests():
+    """the reference's line helpers (ref lib/game/tictactoe/tictactoe_helpers.py:7-179) under their own names in
+    caro_ai_amd.lib.game.tictactoe.tictactoe_helpers: the reference's known answers (test_tictactoe_helpers.py:14-53),
+    and on 1 500 random boards of 3x3 .. 15x15 the same outputs as the reference's functions, digest for digest
+    (tests/golden/make_golden_r5_helpers.py ran those)."""
+    from caro_ai_amd.lib.game.tictactoe import tictactoe_helpers as th
+    from tests.conftest import load_golden
+    from tests.rules_digest import helpers_digest as digest
+    b = [[1, -1, 1], [-1, -1, 0], [0, -1, 1]]
+    assert th.get_col(b, [0, 0]) == [1, -1, 0] == th.get_col(b, [1, 0])
+    assert th.get_col(b, [2, 1]) == [-1, -1, -1] and th.get_col(b, [1, 2]) == [1, 0, 1]
+    assert th.get_diag(b, [0, 0]) == [1, -1, 1] == th.get_diag(b, [1, 1])
+    assert th.get_diag(b, [1, 0]) == [-1, -1] == th.get_diag(b, [2, 1]) and th.get_diag(b, [1, 2]) == [-1, 0]
+    assert th.get_antidiag(b, [0, 0]) == [1] and th.get_antidiag(b, [1, 0]) == [-1, -1]
+    assert th.get_antidiag(b, [2, 1]) == [-1, 0] == th.get_antidiag(b, [1, 2]) and th.get_antidiag(b, [1, 1]) == [0, -1, 1]
+    assert th.get_row(b, [1, 2]) == [-1, -1, 0]
+    for arr, k, tok, want in [([1, 1, 1], 3, 1, True), ([-1, -1, -1], 3, -1, True), ([1, 0, 1], 3, 1, False),
+                              ([-1, -1, 1], 3, -1, False), ([1, 1, 1, 0], 3, 1, True), ([0, -1, -1, -1], 3, -1, True),
+                              ([1, 0, 1, 1], 3, 1, False), ([-1, 1, -1, 1], 3, -1, False), ([1, 1], 3, 1, False)]:
+        assert th.k_in_a_row(arr, k, tok) is want, (arr, k, tok)
+    with pytest.raises(AssertionError):
+        th.k_in_a_row([1, 1], 1, 1)
+    assert th.check_win([[1, -1, 1], [0, -1, 0], [0, -1, 1]], (1, 1), 3, -1) and not th.check_win(b, (0, 0), 3, 1)
+    assert th.check_win([[0, -1, 1], [0, 1, 0], [1, -1, 1]], (2, 0), 3, 1)
+    fx = load_golden("helpers_digest.json.gz")
+    for n, want in fx["digests"].items():
+        assert digest(th, int(n), fx["seed"], fx["cases"]) == want, n
+
+
+def test_codec_helpers_of_the_game_classes_equal_the_references():
+    """the list / matrix views a caller of the reference can reach beside the BaseGame interface (SURVEY 8(a) rows a14 /
+    a18): ConnectFour.bits_to_int / int_to_bits / encode_lists / decode_binary / convert_mcts_state_to_nn_state (ref
+    connect_four.py:94-155), TicTacToe.flatten_nested_list / _pad_mcts_state / encode_game_state /
+    convert_mcts_state_to_list_state (ref tictactoe.py:44-135) -- known answers, and on random positions the digests the
+    REFERENCE's classes produced (tests/golden/make_golden_r5_helpers.py); the modules sit where the reference's do
+    (lib.game.connect_four.connect_four, lib.game.tictactoe.tictactoe, lib.game.tictactoe.tictactoe_helpers)"""
+    from caro_ai_amd.lib.game.connect_four.connect_four import ConnectFour
+    from caro_ai_amd.lib.game.tictactoe.tictactoe import TicTacToe
+    from tests.conftest import load_golden
+    from tests.rules_digest import codec_digest
+    c4, t3 = ConnectFour(), TicTacToe()
+    assert c4.int_to_bits(5, 3) == [1, 0, 1] and c4.int_to_bits(9, 3) == [0, 0, 1] and c4.bits_to_int([1, 0, 1, 1]) == 11
+    assert c4.convert_mcts_state_to_nn_state(c4.initial_state) == [[]] * 7
+    assert t3.convert_mcts_state_to_list_state(int("120020100")) == [[1, 2, 0], [0, 2, 0], [1, 0, 0]]
+    assert t3.convert_mcts_state_to_list_state(int("000120100")) == [[0, 0, 0], [1, 2, 0], [1, 0, 0]]
+    assert t3.encode_game_state([[0, 0, 0], [1, 2, 0], [1, 0, 0]]) == int("000120100")
+    assert t3.flatten_nested_list([[1, 2], [3]]) == [1, 2, 3] and t3._pad_mcts_state("12") == "000000012"
+    fx = load_golden("helpers_digest.json.gz")
+    assert codec_digest(c4, fx["seed"], fx["cases"]) == fx["codec"]["c4"]
+    for n, k in ((3, 3), (5, 4), (15, 5)):
+        assert codec_digest(TicTacToe(n, k), fx["seed"], fx["cases"]) == fx["codec"]["mnk%d" % n], n
+
+
+def test_mcts_host_side_helpers_and_tb_tracker():
+    """names a caller of the reference can reach that the kernels made redundant, kept as host-side functions with the
+    reference's results (compared with the reference's own methods in the build container, round 5): MCTS._add_noise
+    (one numpy Dirichlet draw, all A actions, lib/mcts.py:48-62), _calculate_upper_bound (:64-84; NEP-50 types: float32
+    in, float32 out), _mask_invalid_actions (:86-95), and lib.utils.TBMeanTracker (lib/utils.py:111-159)."""
+    import math
+    from caro_ai_amd import config as cfg
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.mcts import MCTS
+    from caro_ai_amd.lib.utils import TBMeanTracker
+    g = ConnectFour()
+    t = MCTS(g)  # no engine until the first search: these helpers need no GPU
+    P = [np.float32(x) for x in (0.1, 0.2, 0.05, 0.25, 0.15, 0.05, 0.2)]
+    np.random.seed(3)
+    got = t._add_noise(P)
+    np.random.seed(3)
+    nz = np.random.dirichlet([cfg.ALPHA] * 7)
+    assert got == [(1 - cfg.EXPLORE) * p + cfg.EXPLORE * n for p, n in zip(P, nz)] and all(type(x) is np.float64 for x in got)
+    Q, N = [np.float32(0.5), np.float32(-0.25)] + [np.float32(0)] * 5, [3, 1, 0, 0, 0, 0, 0]
+    ub = t._calculate_upper_bound(Q, P, N)
+    assert all(type(x) is np.float32 for x in ub)
+    assert ub[0] == np.float32(0.5) + np.float32(cfg.C_PUCT) * P[0] * np.float32(math.sqrt(4)) / np.float32(4)
+    assert t._calculate_upper_bound([0.0] * 7, P, [0] * 7) == [0.0] * 7   # no +1 under the root: all zero at a fresh node (Q4)
+    s = g.initial_state
+    for _ in range(6):
+        s, _ = g.move(s, 2, 0)
+    scores = [1.0] * 7
+    t._mask_invalid_actions(scores, s)
+    assert scores == [1.0, 1.0, -np.inf, 1.0, 1.0, 1.0, 1.0]
+
+    class Writer:
+        rows, closed = [], False
+
+        def add_scalar(self, name, value, step):
+            self.rows.append((name, float(value), step))
+
+        def close(self):
+            self.closed = True
+
+    w = Writer()
+    with TBMeanTracker(w, 3) as tb:
+        for i, v in enumerate([1.0, 2, np.float32(3.5), np.array([1.0, 3.0]), torch.tensor([2.0, 4.0]), 7]):
+            tb.track("x", v, i)
+    assert w.rows == [("x", 2.1666666666666665, 2), ("x", 4.0, 5)] and w.closed   # what the reference's tracker writes

@@ -88,3 +88,13 @@ def test_inference_forms_match_eval_net(form, path, shape, A):
     assert (lg - lg2).abs().max().item() < 2e-4
     assert (vl - vl2).abs().max().item() < 2e-5
     assert lg2.shape == (37, A) and vl2.shape == (37, 1)
+
+
+def test_shape_probes_of_the_reference_net():
+    """lib/model.py:74-80: the feature counts the 1x1 heads hand to their linear layers"""
+    from caro_ai_amd.lib.model import Net
+    for shape, A in (((2, 6, 7), 7), ((2, 3, 3), 9), ((2, 15, 15), 225)):
+        net = Net(shape, A)
+        body = (64, shape[1], shape[2])
+        assert net._get_conv_val_size(body) == shape[1] * shape[2] == net.value[0].in_features
+        assert net._get_conv_policy_size(body) == 2 * shape[1] * shape[2] == net.policy[0].in_features
