@@ -72,7 +72,7 @@ class ConnectFour(PackedGame):
 
     def move(self, state_int, col, player):
         assert isinstance(state_int, int)
-        assert isinstance(col, (int, np.integer))
+        assert isinstance(col, int)  # (the reference refuses numpy integers too, connect_four.py:250-255)
         assert 0 <= col < self.game_cols
         assert player == self.player_black or player == self.player_white
         return self._move_key(state_int, col, player)

@@ -74,7 +74,9 @@ class TicTacToe(PackedGame):
 
     def move(self, mcts_state, move, player):
         assert player == self.player_white or player == self.player_black
-        assert 0 <= move < self.action_space
+        assert 0 <= move <= self.action_space  # the reference's bound is off by one (tictactoe.py:227) ...
+        if move == self.action_space:           # ... and the cell just behind the board is its IndexError
+            raise IndexError("list index out of range")
         return self._move_key(mcts_state, move, player)
 
     def render(self, mcts_state):

@@ -358,3 +358,31 @@ def test_mcts_host_side_helpers_and_tb_tracker():
         for i, v in enumerate([1.0, 2, np.float32(3.5), np.array([1.0, 3.0]), torch.tensor([2.0, 4.0]), 7]):
             tb.track("x", v, i)
     assert w.rows == [("x", 2.1666666666666665, 2), ("x", 4.0, 5)] and w.closed   # what the reference's tracker writes
+
+
+def test_argument_checks_are_the_references():
+    """differential run against the reference's classes in the build container (round 5): which calls assert, which
+    raise something else, which go through -- connect_four.py:250-255 (types are `int`, numpy integers are refused; a
+    full column asserts), tictactoe.py:226-227 (the bound is off by one: the cell just behind the board is an IndexError,
+    an occupied square is NOT refused)"""
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    c4, t3 = ConnectFour(), TicTacToe()
+    full = c4.initial_state
+    for _ in range(3):
+        full, _ = c4.move(full, 0, 0)
+        full, _ = c4.move(full, 0, 1)
+    for bad in (lambda: c4.move(full, 0, 1), lambda: c4.move(c4.initial_state, 7, 1), lambda: c4.move(c4.initial_state, -1, 1),
+                lambda: c4.move(c4.initial_state, 0, 2), lambda: c4.move(float(c4.initial_state), 0, 1),
+                lambda: c4.move(c4.initial_state, np.int64(3), 1), lambda: c4.move(c4.initial_state, "3", 1),
+                lambda: c4.possible_moves(1.0), lambda: c4.possible_moves(np.int64(c4.initial_state)),
+                lambda: c4.decode_binary(1.5), lambda: c4.encode_lists([[]] * 6), lambda: c4.encode_lists(tuple([[]] * 7)),
+                lambda: t3.move(t3.initial_state, 10, 0), lambda: t3.move(t3.initial_state, -1, 0),
+                lambda: t3.move(t3.initial_state, 0, 2)):
+        with pytest.raises(AssertionError):
+            bad()
+    with pytest.raises(IndexError):
+        t3.move(t3.initial_state, 9, 0)
+    assert t3.move(int("212222222"), 1, 0) == (202222222, False)   # an occupied square is overwritten, as in the reference
+    assert sorted(c4.invalid_moves(full)) == [0] and t3.possible_moves(int("010101010")) == []
+    assert c4.states_to_training_batch([full], [0, 1]).shape == (1, 2, 6, 7)   # a longer who_moves list is tolerated
