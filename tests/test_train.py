@@ -252,13 +252,13 @@ def test_training_loop_learns_tictactoe():
         r, (w, l, d) = train.evaluate(g, net, initial, rounds=40, seed=99 + h["iterations"], counts=True)
         net.train()
         seen.append((h["iterations"], first, last, w, l, d))
-        return last < 0.8 * first and w >= 8 and w >= 2 * l + 4
+        return last < 0.8 * first and w >= 2 * l and w - l >= 6
 
     h = train.fit(g, net, "cuda:0", games=128, iterations=180, sample_seed=11, log=None, stop=good)
     print("checks (iterations, first loss, last loss, wins, losses, draws vs the initial net):", seen)
     it, first, last, w, l, d = seen[-1]
     assert last < 0.8 * first, seen
-    assert w >= 8 and w >= 2 * l + 4, seen
+    assert w >= 2 * l and w - l >= 6, seen   # (six runs in a row: 21-3, 15-1, 17-6, 17-4, 17-6, 17-3 of 40 rounds)
 
 
 @pytest.mark.gpu
