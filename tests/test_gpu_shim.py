@@ -46,6 +46,12 @@ class TestBackup:
         assert len(t) == 0 and t.is_leaf(s1)
 
 
+def _game_for(d):
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    return ConnectFour() if d["kind"] == "c4" else TicTacToe(d["n"], d["k"])
+
+
 def _synth_module(game):
     """A lib.model.Net whose forward is the synthetic table net (logits = log P so softmax returns ~P)."""
     from caro_ai_amd.lib.model import Net
@@ -896,3 +902,76 @@ def test_play_session_follows_the_reference_session(kind):
             turn += 1
         assert outcome == gm["outcome"] and [int(m) for m in s.moves] == gm["moves"] and len(turns) == len(gm["turns"])
         assert len(s.mcts_store) == gm["store_len"]
+
+
+@pytest.mark.parametrize("name", ["c4", "ttt3", "mnk5"])
+def test_mcts_class_follows_the_reference_call_by_call(name, monkeypatch):
+    """SURVEY 8(a) rows a1-a12 at the level of the CLASS: a script of calls on the reference's `MCTS` (find_leaf on an
+    empty and on a grown tree, search_minibatch, search_batch, is_leaf, len(), the four dicts, get_policy_value at
+    tau = 1 / 0, a walk down the tree on the same store, clear()) was run on the reference with numpy seeded and
+    recorded call by call (tests/golden/make_golden_r5_mcts_api.py; table net, softmax = identity: every number exact
+    on any machine).  The same calls on this package's MCTS, tree on the GPU, the Dirichlet rows drawn from numpy's
+    global generator where the reference draws them: every return value equal -- visit counts, float32 W, priors, pi
+    and the leaf tuples exactly; Q exactly where W has absorbed a float32 value, otherwise to float32 (the reference
+    holds python floats there)."""
+    import torch.nn.functional as F
+    from caro_ai_amd.lib.model import Net
+    from caro_ai_amd.lib.mcts import MCTS
+    from tests.synth_net import SynthNet
+    fx = load_golden("mcts_api.json.gz")[name]
+    game = _game_for(fx)
+    monkeypatch.setattr(F, "softmax", lambda x, dim=1: x)
+
+    class TableNet(Net):
+        def forward(self, x):
+            P, v = SynthNet(int(np.prod(x.shape[1:])), self.actions_n, x.device)(x)
+            return P, v.reshape(-1, 1)
+
+    net = TableNet(game.obs_shape, game.action_space)
+    t = MCTS(game)
+    np.random.seed(fx["seed"])
+
+    def same_q(got, want, strong):
+        return all(float(g) == w if f else np.float32(g) == np.float32(w) for g, w, f in zip(got, want, strong))
+
+    def check_node(s, want):
+        assert [int(x) for x in t.visit_count[s]] == want["N"]
+        assert [float(x) for x in t.value[s]] == want["W"]
+        assert [float(x) for x in t.probs[s]] == want["P"]
+        assert same_q(t.value_avg[s], want["Q"], want["W_f32"]), (t.value_avg[s], want["Q"])
+
+    strong_of = {}
+    for i, call in enumerate(fx["log"]):
+        op = call[0]
+        if op == "find_leaf":
+            value, leaf, player, states, actions = t.find_leaf(int(call[1]), call[2])
+            got = {"value": None if value is None else float(value), "leaf": str(leaf), "player": int(player),
+                   "states": [str(x) for x in states], "actions": [int(a) for a in actions]}
+            assert got == call[3], (i, got, call[3])
+        elif op == "len":
+            assert len(t) == call[1]
+        elif op == "is_leaf":
+            assert bool(t.is_leaf(int(call[1]))) == call[2], i
+        elif op == "search_minibatch":
+            t.search_minibatch(call[1], int(call[2]), call[3], net, device="cuda:0")
+            assert len(t) == call[4]["len"], i
+            check_node(int(call[2]), call[4]["node"])
+        elif op == "search_batch":
+            t.search_batch(call[1], call[2], int(call[3]), call[4], net, device="cuda:0")
+            assert len(t) == call[5]["len"], i
+            check_node(int(call[3]), call[5]["node"])
+            strong_of[call[3]] = call[5]["node"]["W_f32"]
+        elif op == "get_policy_value":
+            pi, q = t.get_policy_value(int(call[1]), tau=call[2])
+            assert [float(x) for x in pi] == call[3], (i, pi, call[3])
+            assert same_q(q, call[4], strong_of[call[1]]), (i, q, call[4])
+        elif op == "move":
+            assert game.move(int(call[1]), call[2], call[3]) == (int(call[4]), call[5])
+        elif op == "keys":
+            assert sorted(str(k) for k in t.visit_count.keys()) == sorted(call[1])
+            assert sum(sum(int(x) for x in v) for v in t.visit_count.values()) == call[2]
+        elif op == "clear":
+            t.clear()
+            assert len(t) == call[1] and bool(t.is_leaf(game.initial_state)) == call[2]
+        else:
+            raise AssertionError(op)
