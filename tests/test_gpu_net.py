@@ -299,3 +299,25 @@ def test_winograd_2d_c_abi_refuses_what_it_cannot_do():
     torch.cuda.synchronize()
     assert (p1 - p2).abs().max().item() < 1e-5 and not np.array_equal(p1.cpu().numpy(), np.zeros_like(p1.cpu().numpy()))
     hn.close(); hw.close()
+
+
+def test_large_board_net_serves_more_streams_than_it_has_slots():
+    """ADVICE r4: the 2-D Winograd form keeps per-stream feature rows (trunk -> k_net_heads) in a table of eight slots;
+    a long-lived net launched on transient streams -- engines recreated per iteration -- used to fail for good with
+    CARO_E_STATE at the ninth stream.  The least recently used slot is evicted now: twelve streams in turn, then the
+    first ones again, every launch returns the same bits."""
+    from caro_ai_amd.net_hip import HipNet
+    shape, A = (2, 15, 15), 225
+    net = _net(shape, A, None)
+    hn = HipNet(net, "cuda:0")
+    assert hn.mode == "f32w2"
+    x = _boards(40, shape, 3).to("cuda:0")
+    p0, v0 = hn(x)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    for st in streams + streams[:3]:
+        with torch.cuda.stream(st):
+            p, v = hn(x)
+        st.synchronize()
+        assert torch.equal(p, p0) and torch.equal(v, v0)
+    hn.close()
