@@ -6,8 +6,9 @@ They close the pinning gaps the round-4 review named:
                             lib/mcts.py:144-146: a full board inside the tree backs up 0.0), table net, mixed
                             searches x batch, one and two stores -- every earlier recorded game ended +-1
   rules_digest.json.gz      SURVEY 8(c) G1 at its stated size: 10^5 random connect-four plies, 10^4 each for 3x3 and
-                            15x15 k=5, as one SHA-256 per 1000-ply block (tests/rules_digest.py says what a block is
-                            and what its digest absorbs: next state, won, legal mask, planes)
+                            15x15 k=5 (+ 5 000 each for 5x5 k=4, 8x8 k=5, 10x10 k=5: the other lane geometries of the
+                            rule kernels), as one SHA-256 per 1000-ply block (tests/rules_digest.py says what a block
+                            is and what its digest absorbs: next state, won, legal mask, planes)
   arena_c4_320_x16.json.gz  SURVEY 8(c) G5: 32 seeded tau=0 arena games best_026 vs best_025, one store per player:
   arena_c4_800_x16.json.gz  16 at 40 x 8 sims/move (ref play.py:47-52 with config.py:18-19) and 16 at 100 x 8
                             (BASELINE config 5); per ply the root N vector (= the argmax move), pi, z; W / L / D
@@ -50,9 +51,14 @@ def draws():
     mg.dump("draws_ttt3.json.gz", {"kind": "mnk", "n": 3, "k": 3, "games": kept})
 
 
+MID = {"mnk5": (5, 4), "mnk8": (8, 5), "mnk10": (10, 5)}  # the other lane geometries of the rule kernels: 5 blocks each
+
+
 def _rules_block(job):
     name, b = job
-    game = {"c4": mg.ConnectFour, "ttt3": mg.TicTacToe, "mnk15": lambda: mg.TicTacToe(15, 5)}[name]()
+    makers = {"c4": mg.ConnectFour, "ttt3": mg.TicTacToe, "mnk15": lambda: mg.TicTacToe(15, 5)}
+    makers.update({k: (lambda nk=nk: mg.TicTacToe(*nk)) for k, nk in MID.items()})
+    game = makers[name]()
     return name, b, rd.block_digest(game, RULES_SEED, b, BLOCK, game.action_space)
 
 
@@ -60,6 +66,9 @@ def rules():
     jobs = [("c4", b) for b in range(100)] + [("ttt3", b) for b in range(10)] + [("mnk15", b) for b in range(10)]
     out = {"c4": {"kind": "c4", "blocks": [None] * 100}, "ttt3": {"kind": "mnk", "n": 3, "k": 3, "blocks": [None] * 10},
            "mnk15": {"kind": "mnk", "n": 15, "k": 5, "blocks": [None] * 10}}
+    for name, (n, k) in MID.items():
+        jobs += [(name, b) for b in range(5)]
+        out[name] = {"kind": "mnk", "n": n, "k": k, "blocks": [None] * 5}
     with mp.Pool(8) as pool:
         for name, b, dg in pool.imap_unordered(_rules_block, jobs):
             out[name]["blocks"][b] = dg

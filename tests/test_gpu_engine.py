@@ -123,7 +123,7 @@ def test_rules_kernels_vs_reference(name):
         assert np.packbits(planes[i].astype(np.uint8)).tobytes().hex() == r["planes"]
 
 
-@pytest.mark.parametrize("name", ["c4", "ttt3", "mnk15"])
+@pytest.mark.parametrize("name", ["c4", "ttt3", "mnk15", "mnk5", "mnk8", "mnk10"])
 def test_rules_kernels_vs_reference_digests(name):
     """SURVEY 8(c) G1 at its stated size (tests/golden/make_golden_r5.py: 10^5 random connect-four plies, 10^4 each for
     3x3 and 15x15 k=5 played through the REFERENCE's game classes, one SHA-256 per 1000-ply block over next state, won,
@@ -141,7 +141,7 @@ def test_rules_kernels_vs_reference_digests(name):
     for b in range(nb):
         tallies.append(rd.playout_block(game, d["seed"], b, bl, A, lambda s_, lg, m, p, s2, won: recs.append((s_, m, p))))
     M = len(recs)
-    assert M == nb * bl == (100000 if name == "c4" else 10000)
+    assert M == nb * bl == {"c4": 100000, "ttt3": 10000, "mnk15": 10000}.get(name, 5000)
     keys = torch.from_numpy(game.to_keys([r[0] for r in recs]).view(np.int64)).to(DEV)
     moves = torch.tensor([r[1] for r in recs], dtype=torch.int32, device=DEV)
     players = torch.tensor([r[2] for r in recs], dtype=torch.int32, device=DEV)

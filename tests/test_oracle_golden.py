@@ -416,7 +416,7 @@ def test_drawn_games_vs_reference():
     assert len(shapes) >= 3 and any(s[2] == 2 for s in shapes)
 
 
-@pytest.mark.parametrize("name", ["c4", "ttt3", "mnk15"])
+@pytest.mark.parametrize("name", ["c4", "ttt3", "mnk15", "mnk5", "mnk8", "mnk10"])
 def test_rules_digest_vs_reference(name):
     """SURVEY 8(c) G1 at its stated size -- 10^5 random connect-four plies, 10^4 each for 3x3 and 15x15 k=5, played
     through the reference's game classes and kept as one SHA-256 per 1000-ply block over (next state, won, legal mask,
@@ -425,7 +425,7 @@ def test_rules_digest_vs_reference(name):
     d = load_golden("rules_digest.json.gz")
     s = d["sets"][name]
     o = make_oracle(s)
-    assert len(s["blocks"]) * d["block"] == (100000 if name == "c4" else 10000)
+    assert len(s["blocks"]) * d["block"] == {"c4": 100000, "ttt3": 10000, "mnk15": 10000}.get(name, 5000)
     for b, want in enumerate(s["blocks"]):
         assert rd.block_digest(o, d["seed"], b, d["block"], o.A) == want, (name, b)
 
