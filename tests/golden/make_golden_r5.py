@@ -14,7 +14,8 @@ They close the pinning gaps the round-4 review named:
                             (BASELINE config 5); per ply the root N vector (= the argmax move), pi, z; W / L / D
 
 Harness as make_golden.py (table-driven np.random.dirichlet / np.random.choice keyed (seed, uid, ply, sim),
-net.eval() + no_grad, fresh stores per game).  Usage:  python tests/golden/make_golden_r5.py [draws|rules|arena ...]
+net.eval() + no_grad, fresh stores per game).  Also synth_mid.json.gz: whole table-net games on 6x6, 8x8 and 10x10.
+Usage:  python tests/golden/make_golden_r5.py [draws|rules|arena|mid ...]
 """
 import multiprocessing as mp
 import os
@@ -78,6 +79,21 @@ def rules():
     mg.dump("rules_digest.json.gz", {"seed": RULES_SEED, "block": BLOCK, "sets": out})
 
 
+def mid():
+    """whole table-net games on the board sizes between 5x5 and 15x15 (lane geometries 64 x 1 with one and two actions per
+    lane), recorded like make_golden.py's: synth_mid.json.gz"""
+    games = []
+    for i, (n, k, S, B, ns, sbt0) in enumerate([(6, 4, 8, 8, 1, 3), (8, 5, 10, 1, 1, 4), (8, 5, 6, 8, 2, 0),
+                                                (10, 5, 6, 8, 1, 5), (10, 5, 16, 1, 1, 2)]):
+        g = mg.TicTacToe(n, k)
+        rec = mg.strip(mg.play_reference(g, mg.SynthNet(g), mg.SynthNet(g), ns, sbt0, S, B, i & 1, 19, 9500 + i, True), False)
+        rec["n"], rec["k"] = n, k
+        games.append(rec)
+        print("mid game %d: %dx%d k=%d, %dx%d sims, %d stores: %d plies, result %d" % (i, n, n, k, S, B, ns, rec["plies"],
+                                                                                   rec["result"]), flush=True)
+    mg.dump("synth_mid.json.gz", {"kind": "mnk-mixed", "games": games})
+
+
 _nets = None
 
 
@@ -104,9 +120,9 @@ def arena():
 
 def main():
     t0 = time.time()
-    what = sys.argv[1:] or ["draws", "rules", "arena"]
+    what = sys.argv[1:] or ["draws", "rules", "arena", "mid"]
     for w in what:
-        {"draws": draws, "rules": rules, "arena": arena}[w]()
+        {"draws": draws, "rules": rules, "arena": arena, "mid": mid}[w]()
         print("%s done, %.0f s" % (w, time.time() - t0), flush=True)
 
 

@@ -237,6 +237,15 @@ def test_engine_replays_reference_drawn_games(form):
         _play_and_check_golden(d, g, form)
 
 
+def test_engine_replays_reference_games_on_mid_size_boards(form):
+    """whole table-net games recorded from the reference on 6x6 k4, 8x8 k5 (one and two stores; 8x8 with batch 1 is a
+    one-wavefront geometry: the fused tree kernel) and 10x10 k5 (two actions per lane): root N / W / Q / nodes / pi / z"""
+    d = load_golden("synth_mid.json.gz")
+    assert len(d["games"]) == 5
+    for g in d["games"]:
+        _play_and_check_golden({"kind": "mnk", "n": g["n"], "k": g["k"]}, g, form)
+
+
 def test_config4_table_net_games_400_sims_with_eviction(form):
     """BASELINE config 4's per-game settings -- TicTacToe(15, 5), 50 x 8 = 400 sims/move, tau = 1 for 10 plies --
     with the engine as config 4 runs it: eviction on, 4 096 live nodes per tree.  Whole games recorded from the

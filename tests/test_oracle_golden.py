@@ -480,3 +480,13 @@ def test_reference_callers_themselves_produce_the_round4_fixtures():
     assert [(c["uid"], c["result"], c["steps"]) for c in chk["evaluate"]["rounds"]] == \
         [(g["uid"], g["result"], g["steps"]) for g in ev["rounds"]]
     assert chk["evaluate"]["win_ratio"] == ev["win_ratio"]
+
+
+def test_mid_size_boards_whole_games_vs_reference():
+    """whole table-net games recorded from the reference on 6x6 k4, 8x8 k5 (one store, and one per player) and 10x10 k5
+    (tests/golden/make_golden_r5.py mid): the lane geometries between 5x5 and 15x15 -- root N / nodes / pi / z bit exact"""
+    d = load_golden("synth_mid.json.gz")
+    assert {(g["n"], g["k"]) for g in d["games"]} == {(6, 4), (8, 5), (10, 5)}
+    for g in d["games"]:
+        o = Oracle(Oracle.MNK, g["n"], g["k"], n_stores=g["n_stores"])
+        _check_game(o, g, lambda oo: oo.use_synth_net())
