@@ -576,6 +576,22 @@ def test_play_cli_round_robin(capsys):
     wa, la, da = agents[a]
     wb, lb, db = agents[b]
     assert (wa, la, da) == (lb, wb, db) and wa + la + da == 16
+    # the printed lines have the SHAPE of what the reference's play.py printed (tests/golden/play_script_c4.json.gz:
+    # recorded by running that script): the same lines once names and numbers are masked
+    import re
+    ref = load_golden("play_script_c4.json.gz")
+
+    def shape(lines, names):
+        out = []
+        for ln in lines:
+            for k, nm in enumerate(names):
+                ln = ln.replace(nm, "<%d>" % k)
+            out.append(re.sub(r"\d+", "N", ln))
+        return out
+
+    mine = shape(out.strip().splitlines(), [a, b])
+    theirs = shape(ref["stdout"], ref["models"])
+    assert mine[:3] == theirs[:3] and sorted(mine[3:]) == sorted(theirs[3:]), (mine, theirs)
 
 
 def test_play_session_bot_moves():
