@@ -306,7 +306,11 @@ int caro_net_debug_stamps(caro_net* n, uint64_t* stamps_dev);
  * synchronisation.  noise_dev: f64[searches, G, batch, A] or NULL (generated); buffers as for caro_select /
  * caro_expand_backup (G * batch rows); net1 may be NULL when the engine has one net.  With one wavefront per game
  * (batch * lanes-per-descent == 64) the three tree kernels run fused (k_tree), two launches per minibatch, and
- * leaves travel in slot rows (caro_net_forward_slots); otherwise in the dense rows of caro_select. */
+ * leaves travel in slot rows (caro_net_forward_slots); otherwise in the dense rows of caro_select.
+ * A move needs searches >= 2 when its root may be unexpanded: the first minibatch on an unexpanded root only expands it
+ * (lib/mcts.py:123: every descent returns the root itself, nothing is backed up), so after ONE search no edge has been
+ * visited and the policy is 0 / 0 -- the reference raises ZeroDivisionError there (lib/mcts.py:311); caro_policy /
+ * caro_step return NaN rows for such a game instead of trapping. */
 int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch,
                       const double* noise_dev, float* planes_dev, uint64_t* leaf_keys_dev, float* probs_dev,
                       float* values_dev, void* stream);
