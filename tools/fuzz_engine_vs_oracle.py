@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""GPU check beyond the test-suite's fixed configurations: the ENGINE against the ORACLE on randomly drawn ones --
+connect four and m,n,k boards of 3x3 .. 15x15 with any k, searches 2 .. 12, batch 1 .. 16 (non powers of two too), one
+store or one per player, one or two table nets, tau switch 0 .. 8, 1 .. 24 concurrent games with recycling, both launch
+forms (step-wise kernels / the fused path where the geometry allows), eviction on or off -- every finished game must equal
+the oracle's game of the same uid (tests/test_gpu_engine.py::_check_against_oracle: result, steps, boards, players, float64
+pi, z), no overflow.
+
+    python tools/fuzz_engine_vs_oracle.py [configurations] [seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, ROOT)
+from tests.test_gpu_engine import _check_against_oracle  # noqa: E402
+
+
+def main():
+    n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    done = games = 0
+    for i in range(n_cfg):
+        if rng.random() < 0.25:
+            d, cells = {"kind": "c4"}, 42
+        else:
+            n = int(rng.choice([3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 12, 15]))
+            k = int(rng.integers(3 if n > 3 else 3, min(n, 6) + 1))
+            d, cells = {"kind": "mnk", "n": n, "k": k}, n * n
+        B = int(rng.choice([1, 2, 3, 4, 5, 8, 8, 16]))
+        S = int(rng.integers(2, 13))
+        if cells >= 100:  # keep the oracle's share in seconds
+            S, B = min(S, 5), min(B, 8)
+        ns = int(rng.integers(1, 3))
+        two_nets = ns == 2 and rng.random() < 0.5
+        G = int(rng.integers(1, 25 if cells < 100 else 7))
+        n_fin = G + int(rng.integers(0, G + 1))
+        form = "fused" if rng.random() < 0.6 else "stepwise"
+        kw = {}
+        if rng.random() < 0.3:
+            kw["evict"] = True
+        cfg = dict(d=d, G=G, n_finish=n_fin, sbt0=int(rng.integers(0, 9)), S=S, B=B, n_stores=ns, seed=int(rng.integers(1, 1 << 30)),
+                   uid_base=int(rng.integers(0, 1 << 20)), form=form, salts=(0x1111, 0x2222) if two_nets else None, **kw)
+        try:
+            c, ref, g = _check_against_oracle(**cfg)
+        except Exception:
+            print("MISMATCH / ERROR at configuration %d: %r" % (i, cfg), flush=True)
+            raise
+        done += 1
+        games += len(g)
+        if (i + 1) % 10 == 0:
+            print("%d configurations, %d games equal (%.0f s)" % (done, games, time.time() - t0), flush=True)
+    print("engine == oracle on %d random configurations, %d whole games (seed %d)" % (done, games, seed))
+
+
+if __name__ == "__main__":
+    main()
