@@ -2,7 +2,8 @@
 """GPU check beyond the test-suite's fixed configurations: the ENGINE against the ORACLE on randomly drawn ones --
 connect four and m,n,k boards of 3x3 .. 15x15 with any k, searches 2 .. 12, batch 1 .. 16 (non powers of two too), one
 store or one per player, one or two table nets, tau switch 0 .. 8, 1 .. 24 concurrent games with recycling, both launch
-forms (step-wise kernels / the fused path where the geometry allows), eviction on or off -- every finished game must equal
+forms (step-wise kernels / the fused path where the geometry allows), the staggered schedule where one wavefront serves a
+game, eviction on or off -- every finished game must equal
 the oracle's game of the same uid (tests/test_gpu_engine.py::_check_against_oracle: result, steps, boards, players, float64
 pi, z), no overflow.
 
@@ -33,6 +34,8 @@ def main():
             k = int(rng.integers(3 if n > 3 else 3, min(n, 6) + 1))
             d, cells = {"kind": "mnk", "n": n, "k": k}, n * n
         B = int(rng.choice([1, 2, 3, 4, 5, 8, 8, 16]))
+        if rng.random() < 0.35:  # steer a third of the draws onto the one-wavefront geometries (fused k_tree / k_tree_stag)
+            B = 8 if d["kind"] == "c4" else 4 if cells <= 16 else 2 if cells <= 32 else 1
         S = int(rng.integers(2, 13))
         if cells >= 100:  # keep the oracle's share in seconds
             S, B = min(S, 5), min(B, 8)
@@ -42,7 +45,11 @@ def main():
         n_fin = G + int(rng.integers(0, G + 1))
         form = "fused" if rng.random() < 0.6 else "stepwise"
         kw = {}
-        if rng.random() < 0.3:
+        A = 7 if d["kind"] == "c4" else cells
+        lpd = 8 if A == 7 else 16 if A <= 16 else 32 if A <= 32 else 64
+        if form == "fused" and B * lpd == 64 and rng.random() < 0.5:
+            kw.update(stagger=True, searches_hint=S)   # the schedule bench.py runs: every game on its own minibatch clock
+        elif rng.random() < 0.3:
             kw["evict"] = True
         cfg = dict(d=d, G=G, n_finish=n_fin, sbt0=int(rng.integers(0, 9)), S=S, B=B, n_stores=ns, seed=int(rng.integers(1, 1 << 30)),
                    uid_base=int(rng.integers(0, 1 << 20)), form=form, salts=(0x1111, 0x2222) if two_nets else None, **kw)
