@@ -576,6 +576,68 @@ class Leg:
         self.eng.close()
 
 
+def train_loop_record(args, device, headline, games=4096, concurrent=1024):
+    """The number a user of train.py sees (VERDICT r5 task 1): `speed_nodes` of
+    caro_ai_amd.train.self_play -- the reference's self-play phase, train.py:25-59 -- for `games` connect-four games on
+    `concurrent` slots at the headline's 25 x 8 sims/move, on the wall clock of the WHOLE call: HipNet packing and
+    upload, engine construction (4.6 GB of tree tables), the games with their ramp and tail (exactly `games` games:
+    no slot restarts beyond the wanted set), the gather into the replay buffer.  Called twice: on a cold cache
+    (`speed_nodes`: what the first iteration of train.fit pays) and again (`reused`: engine and HipNet restarted in
+    place -- every later iteration)."""
+    from caro_ai_amd import train
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    game = ConnectFour()
+    net, wtag = load_net(game, device, args.weights)
+    rb = train.DeviceReplayBuffer(game, 1 << 18, device)
+    train.release_engines()
+    torch.cuda.synchronize(device)
+    kw = dict(device=str(device), searches=args.searches, batch=args.batch, concurrent=concurrent, stagger=True)
+    calls = []
+    for i in range(2):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        sp = train.self_play(game, rb, net, games, seed=i, uid_base=i * games, **kw)
+        torch.cuda.synchronize(device)
+        sp["seconds_wall"] = time.perf_counter() - t0  # with the closing synchronisation: >= sp["seconds"]
+        sp["speed_nodes_wall"] = sp["nodes"] / sp["seconds_wall"]
+        calls.append(sp)
+    # the same as a STREAM (train.self_play_stream, the CLI's default): slots restart at once, a call takes the first
+    # `games` games that finish, games in flight carry over -- three calls, the first one starts the stream
+    train.release_engines()
+    stream = []
+    for i in range(3):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        sp = train.self_play_stream(game, rb, net, games, device=str(device), searches=args.searches, batch=args.batch,
+                                    concurrent=concurrent, uid_base=(2 + i) * games)
+        torch.cuda.synchronize(device)
+        sp["seconds_wall"] = time.perf_counter() - t0
+        sp["speed_nodes_wall"] = sp["nodes"] / sp["seconds_wall"]
+        stream.append(sp)
+    train.release_engines()
+    torch.cuda.empty_cache()
+    keep = ("speed_nodes_wall", "speed_nodes_play", "nodes", "steps", "games", "rows", "seconds_wall", "seconds_setup",
+            "seconds_play", "seconds_gather", "engine_reused", "passes")
+    cold, warm = ({k: c[k] for k in keep} for c in calls)
+    return {"speed_nodes": cold["speed_nodes_wall"], "unit": "node-expansions/s", "frac_of_headline": cold["speed_nodes_wall"] / headline,
+            "reused": dict(warm, speed_nodes=warm["speed_nodes_wall"], frac_of_headline=warm["speed_nodes_wall"] / headline),
+            "cold": cold,
+            "stream": {"speed_nodes": stream[-1]["speed_nodes_wall"], "frac_of_headline": stream[-1]["speed_nodes_wall"] / headline,
+                       "calls": [{k: c[k] for k in keep} for c in stream],
+                       "what": "train.self_play_stream, three consecutive calls of %d games (the first starts the stream): "
+                               "no call plays a sparse tail, the games in flight at its end finish in the next call" % games},
+            "tail_note": "exact form: the wanted games are played to the end and nothing beyond them is started, so the "
+                         "last passes of a call carry few live games (`passes` against games x mean plies / slots) and "
+                         "each of those passes costs its 25 launch pairs at their small-launch floor; the stream form "
+                         "has no such passes",
+            "games": games, "concurrent": concurrent, "searches": args.searches, "batch": args.batch,
+            "weights": wtag,
+            "what": "caro_ai_amd.train.self_play(n_games=%d, concurrent=%d, searches=%d, batch=%d, stagger=True): "
+                    "node-expansions / wall seconds of the whole call incl. engine construction (cold) or in-place restart "
+                    "(reused), HipNet upload, the games' ramp and tail, and the gather into the device replay buffer; "
+                    "seconds_play = the move loop alone" % (games, concurrent, args.searches, args.batch)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -591,7 +653,7 @@ def main():
     ap.add_argument("--node-cap", type=int, default=0, help="nodes per tree (0 = searches*batch*cells bound)")
     ap.add_argument("--evict", type=int, default=-1,
                     help="drop unreachable nodes after every move (result-neutral); default: on for gomoku15")
-    ap.add_argument("--weights", default=os.path.join(ROOT, "tests", "golden", "weights", "best_026_12000.dat"))
+    ap.add_argument("--weights", default=os.path.join(ROOT, "caro_ai_amd", "data", "weights", "best_026_12000.dat"))
     ap.add_argument("--net", default="hipw", choices=["hipw", "hip", "gemm"],
                     help="inference form of lib/model.py Net: hipw = fused HIP fp32 MFMA kernel, 3x3 convs in Winograd form "
                          "(row form F(2,3); 2-D form F(2x2,3x3) on 13x13 .. 15x15 boards) -- the default and the only form "
@@ -613,6 +675,8 @@ def main():
                     help="skip the config4 (15x15) / config5 (arena) legs that follow the headline loop at N = 1")
     ap.add_argument("--sustained-moves", type=int, default=200,
                     help="N = 1 headline: moves of the `sustained` sub-record that follows the timed loop (0 = skip)")
+    ap.add_argument("--train-loop-games", type=int, default=4096,
+                    help="N = 1 headline: games of the `train_loop` sub-record (train.self_play on --games slots; 0 = skip)")
     ap.add_argument("--config4-warmup", type=int, default=40,
                     help="moves played at full size before config4's timed moves (mid-game measurement)")
     ap.add_argument("--config4-steps", type=int, default=8)
@@ -653,8 +717,20 @@ def main():
         # recycled all along (its own clock, not part of `value`)
         sustained = leg.sustained(args.sustained_moves)
     leg.close()
+    del leg
+    torch.cuda.empty_cache()
 
     extras, extras_rc = {}, 0
+    train_loop = None
+    if world == 1 and headline and args.train_loop_games > 0 and args.net == "hipw" and args.stagger:
+        try:
+            train_loop = train_loop_record(args, device, res["value"], games=args.train_loop_games,
+                                           concurrent=min(args.games, args.train_loop_games))
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            train_loop = {"error": repr(e)}
+            extras_rc = 1
     if world == 1 and headline and not args.no_extra_configs and args.net in NET_KERNEL and args.streams == 1:
         # BASELINE.json configs 5 and 4 at full size (parity of both is tests/ business).  config 4 is measured in
         # MID-GAME: --config4-warmup moves at full size first, so that trees are deep, eviction has work to do and
@@ -669,6 +745,8 @@ def main():
             x.close()
             del x
             torch.cuda.empty_cache()
+            if r["overflows"]:  # the games are no longer the reference's: the leg fails (extras_rc)
+                raise RuntimeError("%s: %d minibatches overflowed the node pool" % (key, r["overflows"]))
             return {k: r[k] for k in keep}
 
         c4 = dict(game_name="gomoku15", G=1024, S=50, B=8, arena=False)
@@ -713,6 +791,7 @@ def main():
         out.update({k: v for k, v in res.items() if k not in out})
         out["dist"] = dist_rec
         out["sustained"] = sustained
+        out["train_loop"] = train_loop
         out["cpu_baseline"] = cpu_line
         out.update(extras)
         out["extras_rc"] = extras_rc
@@ -720,6 +799,10 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    bad = res["overflows"] + (sustained["overflows"] if sustained else 0)
+    if bad:  # a tree ran out of nodes inside the timed games: the number above is not a number of the reference's games
+        print("[bench] %d minibatches overflowed the node pool: exit 3" % bad, file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

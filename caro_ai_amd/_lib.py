@@ -29,6 +29,7 @@ class CaroConfig(C.Structure):
         ("c_puct", C.c_float), ("alpha", C.c_double), ("explore", C.c_double),
         ("seed", C.c_uint64), ("uid_base", C.c_uint64), ("uid_stride", C.c_uint64),
         ("device_id", C.c_int32), ("evict", C.c_int32), ("stagger", C.c_int32), ("stagger_recycle", C.c_int32),
+        ("games_limit", C.c_int64),
     ]
 
 
@@ -52,6 +53,7 @@ _SIGNATURES = {
     "caro_noise_batch": (C.c_int, [C.c_uint64, C.c_int64, C.c_int, C.c_double, _P, _P, _P, _P, _P]),
     "caro_engine_create": (C.c_int, [C.POINTER(CaroConfig), C.POINTER(_P)]),
     "caro_engine_destroy": (None, [_P]),
+    "caro_engine_restart": (C.c_int, [_P, C.POINTER(CaroConfig), _P]),
     "caro_reset_games": (C.c_int, [_P, _P, _P]),
     "caro_set_roots": (C.c_int, [_P, _P, _P, _P]),
     "caro_select": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),

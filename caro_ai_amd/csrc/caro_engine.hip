@@ -62,6 +62,7 @@ struct View {
   float c_puct;
   double alpha, explore;
   uint64_t seed, uid_base, uid_stride;
+  long long games_limit;  // > 0: slot g plays its k-th game only while k * G + g < games_limit (caro_config.games_limit)
   // trees (ntab == 2: two tables per tree, tbl[t] is the live one; see k_evict)
   int32_t* tbl;
   uint64_t* node_key;
@@ -1379,9 +1380,22 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
   constexpr int AP = GEO::AP, KW = GEO::KW;
   __shared__ int s_action;
   __shared__ int s_best;
+  __shared__ int s_refuse;
   __shared__ double s_total;
   Board root = gr.root;
   const int player = gr.player;
+  // A root WITHOUT VISITS (one search on an unexpanded root, lib/mcts.py:123: nothing was backed up): the reference's
+  // get_policy_value divides by zero at tau = 1 (mcts.py:311) and at tau = 0 plays argmax of an all-zero row = action 0.
+  // Here: the ply is refused -- the game stays where it was, the tally every caller checks is bumped -- unless tau = 0
+  // and action 0 is legal (then the reference's move is made).
+  auto refuse = [&]() {
+    if (threadIdx.x == 0) {
+      atomicAdd(v.counters + (size_t)g * C_N + C_OVERFLOW, 1ull);
+      if (actions) actions[g] = -1;
+      if (done_out) done_out[g] = 0;
+      if (result_out) result_out[g] = 0;
+    }
+  };
   const int st_sel = v.n_stores == 2 ? player : 0;
   const int t = g * v.n_stores + st_sel;
   const int tsel = st_sel ? gr.tbl[1] : gr.tbl[0];
@@ -1431,6 +1445,10 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
     const int tot = group_sum_i32<64>(n);
     const int nmax = group_allreduce_i32<64>(n, [](int x, int y) { return x > y ? x : y; });
     const int best = __ffsll((unsigned long long)__ballot(lane < v.A && n == nmax)) - 1;  // first maximum
+    if (tot == 0 && (tau == 1 || !R::legal(v.gp, root, 0))) {  // uniform: every lane holds the same tot
+      refuse();
+      return 0;
+    }
     double pa = 0.0;
     if (lane < v.A) pa = tau == 0 ? (lane == best ? 1.0 : 0.0) : (double)n / (double)tot;  // mcts.py:305-311
     if (lane < v.A) v.h_pi[hi * v.A + lane] = pa;
@@ -1462,8 +1480,13 @@ __device__ __forceinline__ int step_body(const View& v, int g, GameRegs<GEO>& gr
     }
     s_best = tau == 0 ? best : -1;
     s_total = (double)tot;
+    s_refuse = tot == 0 && (tau == 1 || !R::legal(v.gp, root, 0));
   }
   block_sync<ONE>();
+  if (s_refuse) {
+    refuse();
+    return 0;
+  }
   for (int a = threadIdx.x; a < AP; a += block_threads<ONE>()) {
     double p = 0.0;
     if (a < v.A) p = s_best >= 0 ? (a == s_best ? 1.0 : 0.0) : (double)s_n[a] / s_total;  // mcts.py:305-311
@@ -1590,6 +1613,14 @@ __global__ void k_evict(View v) {
 }
 
 // ------------------------------------------------------------------ reset / drain
+// caro_config.games_limit: slot g's k-th game (uid = uid_base + g + k * uid_stride) belongs to the wanted set while
+// k * G + g < games_limit.  (A 64-bit division on a path a game takes once, when it ends.)
+__device__ __forceinline__ bool game_wanted(const View& v, int g, uint64_t uid) {
+  if (v.games_limit <= 0) return true;
+  const long long k = (long long)((uid - v.uid_base - (uint64_t)g) / v.uid_stride);
+  return k * (long long)v.G + g < v.games_limit;
+}
+
 template <class GEO>
 __device__ __forceinline__ void reset_game(const View& v, int g, uint64_t uid, int first) {
   using R = typename GEO::R;
@@ -1616,7 +1647,7 @@ __device__ __forceinline__ void reset_game(const View& v, int g, uint64_t uid, i
     v.ply[g] = 0;
     v.step[g] = 0;
     v.uid[g] = uid;
-    v.done[g] = 0;
+    v.done[g] = game_wanted(v, g, uid) ? 0 : 2;  // beyond the wanted set: the slot never starts (2 = drained, finished)
     v.result[g] = 0;
     v.final_r[g] = 0;
   }
@@ -1663,7 +1694,7 @@ __device__ __forceinline__ bool park_and_restart(const View& v, int g, GameRegs<
     v.pk_flag[g] = 1;
   }
   block_sync<true>();  // the live record has been read by every thread
-  if (!v.stag_recycle) {
+  if (!v.stag_recycle || !game_wanted(v, g, uid + v.uid_stride)) {
     if (threadIdx.x == 0) v.done[g] = 2;  // no restart asked for: parked, the slot stays finished
     gr.done = 2;
     return false;
@@ -1894,6 +1925,7 @@ __global__ void k_drain_copy(View v, uint64_t* __restrict__ states, int32_t* __r
   const int n = v.ply[g];
   const int off = v.dr_off[g];
   const int r = v.final_r[g];
+  const uint64_t uid0 = v.uid[g];  // read by every thread BEFORE the barrier below: thread 0 rewrites it in reset_game
   // reversed(game_history), result alternating from the last mover (utils.py:101-106)
   for (int idx = threadIdx.x; idx < n * v.A; idx += blockDim.x) {
     const int j = idx / v.A, a = idx % v.A;
@@ -1909,14 +1941,14 @@ __global__ void k_drain_copy(View v, uint64_t* __restrict__ states, int32_t* __r
   }
   if (threadIdx.x == 0 && games) {
     int64_t* rec = games + (size_t)v.dr_gidx[g] * 4;
-    rec[0] = (int64_t)v.uid[g];
+    rec[0] = (int64_t)uid0;
     rec[1] = v.first[g];
     rec[2] = v.result[g];
     rec[3] = v.step[g];
   }
   __syncthreads();
-  if (recycle) {
-    reset_game<GEO>(v, g, v.uid[g] + v.uid_stride, -1);
+  if (recycle && game_wanted(v, g, uid0 + v.uid_stride)) {
+    reset_game<GEO>(v, g, uid0 + v.uid_stride, -1);
   } else if (threadIdx.x == 0) {
     v.done[g] = 2;  // drained, stays finished
   }
@@ -2321,6 +2353,44 @@ int caro_noise_batch(uint64_t seed, int64_t M, int A, double alpha, const uint64
 
 // ---- engine
 static int reset_games_impl(caro_engine* h, const int32_t* first_player_dev, void* stream);
+// the part of a configuration that does not shape memory: what a run on the engine is keyed by (create and restart)
+static void apply_run_params(caro_engine* h, const caro_config* cfg) {
+  View& v = h->v;
+  v.sbt0 = cfg->steps_before_tau_0;
+  v.first_mode = cfg->first_player_mode;
+  v.c_puct = cfg->c_puct;
+  v.alpha = cfg->alpha;
+  v.explore = cfg->explore;
+  v.seed = cfg->seed;
+  v.uid_base = cfg->uid_base;
+  v.uid_stride = cfg->uid_stride ? cfg->uid_stride : (uint64_t)cfg->n_games;
+  v.games_limit = cfg->games_limit > 0 ? (long long)cfg->games_limit : 0;
+  if (cfg->stagger > 0) {
+    v.stag_S = cfg->stagger;
+    v.stag_recycle = cfg->stagger_recycle ? 1 : 0;
+  }
+}
+// everything a fresh engine starts from, enqueued on `stream`: games at the initial position, empty trees (every key
+// table cleared, the first one live), zero counters, no pending minibatch, fresh clocks, nothing parked
+static int fresh_state(caro_engine* h, hipStream_t st) {
+  View& v = h->v;
+  const size_t T = (size_t)v.G * v.n_stores, G = (size_t)v.G;
+  HIPCHK(hipMemsetAsync(v.counters, 0, sizeof(unsigned long long) * C_N * G, st));
+  HIPCHK(hipMemsetAsync(v.leaf_count, 0, sizeof(int32_t) * 4, st));
+  HIPCHK(hipMemsetAsync(h->rows, 0, sizeof(int32_t) * 8, st));
+  HIPCHK(hipMemsetAsync(v.g_nleaf, 0, sizeof(int32_t) * G, st));
+  HIPCHK(hipMemsetAsync(v.g_pack, 0, sizeof(int32_t) * G, st));
+  h->rows_par = 0;
+  h->stag_batch = 0;
+  const int rc = reset_games_impl(h, nullptr, st);
+  if (rc) return rc;
+  if (v.stag_S) {
+    HIPCHK(hipMemsetAsync(v.dirty, 0, sizeof(int32_t) * T, st));
+    hipLaunchKernelGGL(k_stag_init, dim3((v.G + 255) / 256), dim3(256), 0, st, v);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
 int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   if (!cfg || !out) return fail(CARO_E_INVAL, "null argument");
   const Variant var = pick_variant(cfg->game_kind, cfg->n);
@@ -2372,16 +2442,9 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   v.maxply = v.HW;
   v.maxd = v.HW;
   v.maxB = cfg->max_batch;
-  v.sbt0 = cfg->steps_before_tau_0;
-  v.first_mode = cfg->first_player_mode;
   v.ntab = (cfg->evict || cfg->stagger > 0) ? 2 : 1;  // second key table: eviction's target / the clean table a restarted slot moves to
   v.etab = cfg->evict ? 2 : 1;                          // second copy of the action rows: eviction only
-  v.c_puct = cfg->c_puct;
-  v.alpha = cfg->alpha;
-  v.explore = cfg->explore;
-  v.seed = cfg->seed;
-  v.uid_base = cfg->uid_base;
-  v.uid_stride = cfg->uid_stride ? cfg->uid_stride : (uint64_t)cfg->n_games;
+  apply_run_params(h, cfg);
   v.cap = cfg->node_cap > 0 ? cfg->node_cap : 4096;
   // packing limits of the minibatch records: path_rec.x = node slot (24 bits) | action << 24 (8 bits), d_rec.x holds
   // the path length and the leaf rank in 8 bits each -- a table of more than 2^24 slots would alias nodes silently
@@ -2433,26 +2496,33 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
     DA(v.ph_key, G * v.maxply * KW);
     DA(v.ph_player, G * v.maxply);
     DA(v.ph_pi, G * v.maxply * v.A);
-    v.stag_S = cfg->stagger;
-    v.stag_recycle = cfg->stagger_recycle ? 1 : 0;
   }
 #undef DA
-  HIPCHK(hipMemset(v.counters, 0, sizeof(unsigned long long) * C_N * G));
-  HIPCHK(hipMemset(v.leaf_count, 0, sizeof(int32_t) * 4));
-  HIPCHK(hipMemset(h->rows, 0, sizeof(int32_t) * 8));
-  HIPCHK(hipMemset(v.g_nleaf, 0, sizeof(int32_t) * G));
-  HIPCHK(hipMemset(v.g_pack, 0, sizeof(int32_t) * G));
   HIPCHK(hipHostMalloc((void**)&h->pinned, 64, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&h->pinned64, 128, hipHostMallocDefault));
   *out = h;
-  rc = reset_games_impl(h, nullptr, nullptr);
+  rc = fresh_state(h, nullptr);
   if (rc) { caro_engine_destroy(h); *out = nullptr; return rc; }
-  if (v.stag_S) {
-    HIPCHK(hipMemset(v.dirty, 0, sizeof(int32_t) * T));
-    hipLaunchKernelGGL(k_stag_init, dim3((v.G + 255) / 256), dim3(256), 0, 0, v);
-  }
   HIPCHK(hipDeviceSynchronize());
   return 0;
+}
+
+int caro_engine_restart(caro_engine* h, const caro_config* cfg, void* stream) {
+  if (!h || !cfg) return fail(CARO_E_INVAL, "null argument");
+  const caro_config& o = h->cfg;
+  if (cfg->game_kind != o.game_kind || cfg->n != o.n || cfg->k != o.k || cfg->n_games != o.n_games ||
+      cfg->n_stores != o.n_stores || cfg->n_nets != o.n_nets || cfg->max_batch != o.max_batch ||
+      cfg->node_cap != o.node_cap || (cfg->evict != 0) != (o.evict != 0) || cfg->device_id != o.device_id ||
+      (cfg->stagger > 0) != (o.stagger > 0))
+    return fail(CARO_E_INVAL, "caro_engine_restart: the configuration differs from the engine's in a field that shapes its "
+                              "memory (game, n_games, n_stores, n_nets, max_batch, node_cap, evict, device, staggered or not)");
+  if (cfg->stagger < 0) return fail(CARO_E_INVAL, "stagger must be >= 0");
+  if (h->drain_pending) return fail(CARO_E_STATE, "caro_engine_restart with a drain pending (caro_drain_tuples_end first)");
+  if (h->select_pending) return fail(CARO_E_STATE, "caro_engine_restart with a pending caro_select");
+  HIPCHK(hipSetDevice(o.device_id));
+  h->cfg = *cfg;
+  apply_run_params(h, cfg);
+  return fresh_state(h, (hipStream_t)stream);
 }
 
 void caro_engine_destroy(caro_engine* h) {

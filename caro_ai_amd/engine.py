@@ -53,12 +53,14 @@ def torch_evaluator(net, form="gemm"):
 
 class SelfPlayEngine:
     VIEW_LIMIT_BYTES = 16 << 20  # drains whose staging block is larger hand out copies of the finished rows (drain_end)
+    DEFAULT_CAP_LIMIT = 1 << 16  # largest node_cap chosen without being asked (15 x 15: 4 KB per node and slot)
+    EVICT_DEFAULT_CAP = 1 << 13  # default cap of LIVE nodes with eviction on, where the no-eviction bound is above the limit
 
     def __init__(self, game, n_games, net1=None, net2=None, evaluators=None, n_stores=1, max_batch=None,
                  node_cap=None, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, first_player_mode=2,
                  c_puct=cfg.C_PUCT, alpha=cfg.ALPHA, explore=cfg.EXPLORE, seed=0, uid_base=0, uid_stride=None,
                  device="cuda:0", searches_hint=cfg.MCTS_SEARCHES, inference="hipw", evict=False, stagger=False,
-                 stagger_recycle=True):
+                 stagger_recycle=True, games_limit=0):
         if not torch.cuda.is_available():
             raise _lib.CaroError("SelfPlayEngine needs a GPU (torch.cuda.is_available() is False); "
                                  "there is no CPU fallback")
@@ -85,7 +87,7 @@ class SelfPlayEngine:
         self.n_nets = len(self.evaluators)
         assert self.n_nets in (1, 2)
         if node_cap is None:
-            node_cap = min(int(searches_hint) * self.max_batch * self.HW + 64, 1 << 16)
+            node_cap = self.default_node_cap(searches_hint, self.max_batch, self.HW, evict)
         c = _lib.CaroConfig()
         c.game_kind, c.n, c.k = game.kind, game.n, game.k
         c.n_games, c.n_stores, c.n_nets = self.G, n_stores, self.n_nets
@@ -105,6 +107,7 @@ class SelfPlayEngine:
             raise _lib.CaroError("stagger=True needs device-side evaluators (the fused HIP net or HashNet)")
         c.stagger = self.stag_S if self.stagger else 0
         c.stagger_recycle = 1 if stagger_recycle else 0
+        c.games_limit = int(games_limit or 0)
         self.stagger_recycle = bool(stagger_recycle)
         self.cfg = c
         self.n_stores = n_stores
@@ -128,10 +131,56 @@ class SelfPlayEngine:
         self._prof = False
         self._drain_open = False
 
+    @classmethod
+    def default_node_cap(cls, searches, max_batch, cells, evict=False):
+        """node_cap when the caller names none.  A tree never holds more than searches x batch new nodes per move over
+        at most `cells` moves (lib/mcts.py:248-287: one minibatch adds at most `batch` nodes): that bound is the
+        default.  Where it is larger than a default tree may be (15 x 15: 4 KB per node and slot) a smaller cap would
+        let a long game overflow and silently leave the reference's games, so -- without eviction -- the constructor
+        REFUSES instead of clamping; with eviction (node_cap bounds the LIVE nodes) the default is EVICT_DEFAULT_CAP
+        and an overflow, should one happen, is an error in every caller of this package."""
+        bound = int(searches) * int(max_batch) * int(cells) + 64
+        if bound <= cls.DEFAULT_CAP_LIMIT:
+            return bound
+        if not evict:
+            raise _lib.CaroError(
+                "SelfPlayEngine: %d searches x %d descents x %d cells needs up to %d nodes per tree, more than the %d a "
+                "default tree holds; pass evict=True (unreachable nodes are dropped after every move, result-neutral: "
+                "node_cap then bounds the LIVE nodes) or an explicit node_cap"
+                % (searches, max_batch, cells, bound, cls.DEFAULT_CAP_LIMIT))
+        return cls.EVICT_DEFAULT_CAP
+
     def close(self):
         if getattr(self, "h", None):
             self.L.caro_engine_destroy(self.h)
             self.h = None
+
+    RUN_FIELDS = ("seed", "uid_base", "uid_stride", "games_limit", "steps_before_tau_0", "first_player_mode", "c_puct",
+                  "alpha", "explore", "stagger_recycle")
+
+    def restart(self, evaluators=None, searches=None, **run):
+        """A new run on this engine in place of close() + a new engine (caro_engine_restart): every game back at the
+        initial position, trees empty, counters zero, fresh minibatch clocks -- what a fresh engine of the same
+        configuration starts from, so it plays the same games bit for bit -- with the tree tables kept.  `run` may
+        reset any of RUN_FIELDS; `searches` the staggered mode's minibatches per move; `evaluators` the nets."""
+        bad = set(run) - set(self.RUN_FIELDS)
+        assert not bad, "restart() cannot change %s: these shape the engine's memory" % sorted(bad)
+        if self._drain_open:
+            self.flush()
+        c = self.cfg
+        for k, val in run.items():
+            setattr(c, k, (1 if val else 0) if k == "stagger_recycle" else val)
+        if searches is not None and self.stagger:
+            self.stag_S = int(searches)
+            c.stagger = self.stag_S
+        self.stagger_recycle = bool(c.stagger_recycle)
+        if evaluators is not None:
+            evaluators = list(evaluators)
+            assert len(evaluators) == self.n_nets
+            assert all(getattr(e, "device_counts", False) for e in evaluators) == self.async_net
+            self.evaluators = evaluators
+        _lib.check(self.L.caro_engine_restart(self.h, C.byref(c), self._stream()))
+        self.net_rows = self.net_calls = 0
 
     def __del__(self):
         try:

@@ -34,6 +34,12 @@ class ConnectFour(PackedGame):
     def from_key(self, key):
         return int(np.asarray(key, dtype=np.uint64).reshape(-1)[0])
 
+    def to_keys(self, states):
+        return np.array([int(s) for s in states], dtype=np.uint64).reshape(-1, 1)
+
+    def from_keys(self, keys):
+        return np.asarray(keys, dtype=np.uint64).reshape(-1).tolist()
+
     # list form <-> int, for callers that used the reference's codec (:94-155)
     @staticmethod
     def bits_to_int(bits):

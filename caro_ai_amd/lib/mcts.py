@@ -139,7 +139,8 @@ class MCTS:
     def _weights_version(net):
         """changes whenever a parameter or batch-norm buffer is written in place (optimizer step, load_state_dict)
         or replaced (`.to()`): tensor version counters + storage addresses"""
-        return tuple((t._version, t.data_ptr()) for t in net.state_dict(keep_vars=True).values())
+        from caro_ai_amd.net_hip import weights_version
+        return weights_version(net)
 
     def _fused_net(self, net, device):
         """the HipNet of `net` if this call may take the fused path, else None"""

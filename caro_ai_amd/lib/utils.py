@@ -120,78 +120,78 @@ def play_game(game, mcts_stores, replay_buffer: Union[collections.deque, None], 
 
 def play_games(game, n_games, replay_buffer, net1, net2=None, steps_before_tau_0=10, mcts_searches=10,
                mcts_batch_size=8, n_stores=None, concurrent=None, seed=0, uid_base=0, device="cuda:0",
-               first_player_mode=2, return_stats=False):
+               first_player_mode=2, return_stats=False, node_cap=None):
     """Play the `n_games` games with uids uid_base .. uid_base + n_games - 1 on the HIP engine, `concurrent` at a time.
 
     net2 given -> arena: player 0 is net1, player 1 is net2, one tree per player (play.py:47 semantics,
     n_stores=2); otherwise self-play with one shared tree per game (train.py:43-47).
     Returns the list of net1 results ordered by uid (which games are played, and how each one goes, depends on
     the uids and the seed only -- not on `concurrent`); with return_stats=True also a dict with steps, counters
-    and timing.  When n_games is not a multiple of `concurrent`, slots that run ahead may start up to
-    concurrent - 1 games beyond the wanted range: they are played while the last wanted games finish, their results
-    and tuples are dropped, but stats['counters'] / 'speed_nodes' include their work."""
+    and timing.  Exactly the wanted games are played (the engine's games_limit: a slot whose next uid lies beyond the
+    range stays finished).  Raises CaroError if a tree overflowed its node pool."""
+    from caro_ai_amd import _lib
     from caro_ai_amd.engine import SelfPlayEngine
     arena = net2 is not None and net2 is not net1
     if n_stores is None:
         n_stores = 2 if arena else 1
     G = int(concurrent or min(n_games, 1024))
     G = max(1, min(G, n_games))
+    # boards whose per-game node bound (searches x batch x cells) is beyond a default tree: unreachable nodes are dropped
+    # after every move (result-neutral), the default cap then bounds the LIVE nodes -- and an overflow raises, below
+    hw = game.obs_shape[1] * game.obs_shape[2]
+    evict = mcts_searches * mcts_batch_size * hw + 64 > SelfPlayEngine.DEFAULT_CAP_LIMIT
     # One generation of games on a geometry with one wavefront per game (connect four, batch 8: play.py's arena):
     # the engine's staggered mode without restarts -- every game on its own minibatch clock, the same games, evener
-    # launches.  Several generations keep the lock-step engine, whose drain decides slot by slot whether to restart.
+    # launches.  Several generations keep the lock-step engine, whose drain restarts the slots.
     A = game.action_space
     lpd = 8 if A == 7 else 16 if A <= 16 else 32 if A <= 32 else 64
-    stagger = G == n_games and mcts_batch_size * lpd == 64
-    # the bookkeeping below (slot g plays uids uid_base + g, + G, ...) is that of an engine made here, fresh
+    stagger = G == n_games and mcts_batch_size * lpd == 64 and not evict
+    # slot g plays uids uid_base + g, + G, + 2G, ... while they lie inside the wanted range (games_limit): no game
+    # beyond it is ever started
     engine = SelfPlayEngine(game, G, net1=net1, net2=net2 if arena else None, n_stores=n_stores,
                             max_batch=mcts_batch_size, steps_before_tau_0=steps_before_tau_0, seed=seed,
                             uid_base=uid_base, first_player_mode=first_player_mode, device=device,
-                            searches_hint=mcts_searches, stagger=stagger, stagger_recycle=False)
-    t0 = time.time()
-    c0 = engine.counters()
-    last_uid = uid_base + n_games - 1
-    outcome = {}  # uid -> (net1 result, steps)
+                            searches_hint=mcts_searches, stagger=stagger, stagger_recycle=False, evict=evict,
+                            games_limit=n_games, node_cap=node_cap)
+    try:
+        t0 = time.time()
+        outcome = {}  # uid -> (net1 result, steps)
 
-    def consume(d):
-        """tuples of the wanted games -> the caller's deque, in the reference's record format"""
-        recs = d["games"].cpu().numpy()
-        plies = recs[:, 3] + 1
-        keep = np.repeat(recs[:, 0] <= last_uid, plies)
-        states = game.from_keys(d["states"].cpu().numpy().view(np.uint64)[keep])
-        players = d["players"].cpu().numpy()[keep].tolist()
-        pis = d["pi"].cpu().numpy()[keep].tolist()
-        zs = d["z"].cpu().numpy()[keep].tolist()
-        replay_buffer.extend(zip(states, players, pis, zs))
+        def consume(d):
+            """tuples of the drained games -> the caller's deque, in the reference's record format (whole arrays at
+            once: PackedGame.from_keys, tolist)"""
+            states = game.from_keys(d["states"].cpu().numpy().view(np.uint64))
+            players = d["players"].cpu().numpy().tolist()
+            pis = d["pi"].cpu().numpy().tolist()
+            zs = d["z"].cpu().numpy().tolist()
+            replay_buffer.extend(zip(states, players, pis, zs))
 
-    # slot g plays uids uid_base + g, + G, + 2G, ... (a drained slot restarts with its next uid when `recycle`)
-    slot_uid = [uid_base + g for g in range(G)]
-    waiting = set(range(uid_base, uid_base + n_games))  # wanted games without a result yet
-    while waiting:
-        engine.search(mcts_searches, mcts_batch_size)
-        engine.step()
-        # keep recycling while some wanted game has not been handed to its slot yet; slots that run ahead of the
-        # others may then start a few games beyond the wanted range: they are played but not reported
-        recycle = not stagger and any(slot_uid[(u - uid_base) % G] < u for u in waiting)
-        d = engine.drain(recycle=recycle)
-        if int(d["games"].shape[0]):
-            for uid, _first, result, steps in d["games"].cpu().numpy().tolist():
-                if uid in waiting:
-                    waiting.discard(uid)
+        while len(outcome) < n_games:
+            engine.search(mcts_searches, mcts_batch_size)
+            engine.step()
+            d = engine.drain(recycle=not stagger)
+            if int(d["games"].shape[0]):
+                for uid, _first, result, steps in d["games"].cpu().numpy().tolist():
+                    assert uid_base <= uid < uid_base + n_games and uid not in outcome, uid
                     outcome[uid] = (int(result), int(steps))
-                if recycle:
-                    slot_uid[(uid - uid_base) % G] = uid + G
-            if replay_buffer is not None:
-                consume(d)
-        elif not recycle and engine.live_games() == 0:
-            break
+                if replay_buffer is not None:
+                    consume(d)
+            elif engine.live_games() == 0:
+                break
+        c1 = engine.counters()
+        dt = time.time() - t0
+    finally:
+        engine.close()
+    if c1["overflows"]:
+        raise _lib.CaroError("play_games: %d minibatches overflowed the node pool (node_cap=%d, eviction %s) or plies were "
+                             "refused on a root without visits: the games are not the reference's"
+                             % (c1["overflows"], engine.cfg.node_cap, "on" if evict else "off"))
+    if len(outcome) != n_games:
+        raise _lib.CaroError("play_games: %d of %d games finished" % (len(outcome), n_games))
     results = [outcome[u][0] for u in sorted(outcome)]
     steps = [outcome[u][1] for u in sorted(outcome)]
     if not return_stats:
-        engine.close()
         return results
-    c1 = engine.counters()
-    dt = time.time() - t0
-    stats = {"steps": steps, "seconds": dt, "counters": {k: c1[k] - c0[k] for k in c1},
-             "speed_nodes": (c1["expansions"] - c0["expansions"]) / dt, "speed_steps": sum(steps) / dt}
-    engine.close()
+    stats = {"steps": steps, "seconds": dt, "counters": dict(c1),
+             "speed_nodes": c1["expansions"] / dt, "speed_steps": sum(steps) / dt}
     return results, stats

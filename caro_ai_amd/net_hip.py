@@ -195,6 +195,36 @@ class HipNet:
         return probs, values
 
 
+def weights_version(net):
+    """changes whenever a parameter or batch-norm buffer of `net` is written in place (optimizer step,
+    load_state_dict, NetWrapper.sync) or replaced (`.to()`): tensor version counters + storage addresses"""
+    return tuple((t._version, t.data_ptr()) for t in net.state_dict(keep_vars=True).values())
+
+
+_HIPNETS = {}  # (id(net), device, mode) -> (weights version, HipNet), most recently used last
+HIPNET_CACHE = 4
+
+
+def hipnet_for(net: Net, device="cuda:0", mode="f32w") -> HipNet:
+    """The `HipNet` of `net` as its weights are NOW, built once per weight version: callers that run the same net
+    again and again (train.self_play with the best net between two promotions, train.py:185-217) do not pack and
+    upload it again.  The cache only drops its reference when an entry goes stale or falls out; an engine that
+    still launches on a HipNet keeps it alive."""
+    key = (id(net), str(torch.device(device)), mode)
+    ver = weights_version(net)
+    hit = _HIPNETS.pop(key, None)
+    if hit is None or hit[0] != ver:
+        hit = (ver, HipNet(net, device, mode=mode))
+    _HIPNETS[key] = hit
+    while len(_HIPNETS) > HIPNET_CACHE:
+        _HIPNETS.pop(next(iter(_HIPNETS)))
+    return hit[1]
+
+
+def release_hipnets():
+    _HIPNETS.clear()
+
+
 class HashNet:
     """The table evaluator of include/caro_hip.h (`caro_net_create_hash`): priors and value are exact integer-hash
     functions of the leaf planes.  Same device-side interface as `HipNet` (leaf counts read on the device), so an

@@ -52,6 +52,8 @@ def parse_args(argv=None):
     ap.add_argument("-r", "--rounds", type=int, default=2, help="Count of rounds to perform for every pair")
     ap.add_argument("--cuda", default=False, action="store_true", help="Enable CUDA")
     ap.add_argument("--seed", type=int, default=0, help="key of the generated noise / move uniforms")
+    ap.add_argument("--node-cap", type=int, default=0,
+                    help="nodes per tree (default: searches x batch x cells, which cannot overflow; an overflow ends the run)")
     game_provider.add_game_argument(ap)
     return ap.parse_args(argv)
 
@@ -63,7 +65,7 @@ def load_checkpoint(game, path, device):
     return net.to(device).eval()
 
 
-def meet(game, first, second, rounds, seed, uid_base, device):
+def meet(game, first, second, rounds, seed, uid_base, device, node_cap=None):
     """`rounds` games `first` (player 0) vs `second`; this rank plays its share, every rank gets the total"""
     rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
     lo, n = parallel.shard_rounds(rounds, rank, world)
@@ -72,7 +74,7 @@ def meet(game, first, second, rounds, seed, uid_base, device):
         mine = utils.play_games(game, n, None, first, second, steps_before_tau_0=0,
                                 mcts_searches=cfg.PLAY_MCTS_SEARCHES, mcts_batch_size=cfg.PLAY_MCTS_BATCH_SIZE,
                                 concurrent=min(n, 1024), seed=seed, uid_base=uid_base + lo, device=device,
-                                first_player_mode=2)
+                                first_player_mode=2, node_cap=node_cap)
     return Tally(*parallel.allreduce_counts(Tally.of(mine).as_tuple(), device))
 
 
@@ -89,7 +91,7 @@ def main(argv=None):
     for k, (i, j) in enumerate(pairings):
         (name_i, net_i), (name_j, net_j) = agents[i], agents[j]
         started = time.time()
-        tally = meet(game, net_i, net_j, args.rounds, args.seed, k * args.rounds, device)
+        tally = meet(game, net_i, net_j, args.rounds, args.seed, k * args.rounds, device, args.node_cap or None)
         say("%s vs %s -> %s" % (name_i, name_j, tally))
         if rank == 0:
             sys.stderr.write("Speed %.2f games/s\n" % (args.rounds / (time.time() - started)))

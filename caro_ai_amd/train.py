@@ -21,6 +21,7 @@ gradients are all-reduced, train_neural_net).
     python -m caro_ai_amd.train -n run -g 0 --cuda --games 256 --iterations 50
 """
 import argparse
+import collections
 import os
 import sys
 import time
@@ -151,12 +152,208 @@ def staggered_ok(game, batch):
     return batch * lpd == 64
 
 
-def _self_play_loop(eng, game, n_games, G, searches, batch, stagger, restarts, st, slot_gen, last_gen, take):
-    """the moves of self_play until the wanted games have finished (separate so that self_play can close its engine,
-    and end the rank, on any failure)"""
-    if stagger:
-        # every pass of `searches` launches is one ply per game on average; a game has at most HW plies and sits out
-        # fewer than `searches` launches at the start: a bound on the passes that a healthy run never reaches
+# The engines of self_play, kept between calls (the reference builds its MCTS store once, train.py:185, and plays every
+# self-play call on it): a call whose shape -- game, slots, batch, node cap, schedule, device -- has been seen before
+# restarts the engine in place (caro_engine_restart: trees cleared, not re-allocated; 4.6 GB for 1024 connect-four
+# slots) and plays, bit for bit, what a fresh engine plays.  Most recently used last; the oldest is closed.
+_ENGINES = collections.OrderedDict()
+ENGINE_CACHE = 2
+
+
+def release_engines():
+    """close the cached self-play engines and drop the cached HipNets (frees their device memory)"""
+    from caro_ai_amd import net_hip
+    while _ENGINES:
+        _ENGINES.popitem()[1].close()
+    net_hip.release_hipnets()
+
+
+def _engine_for(game, G, batch, searches, device, stagger, run, hip, reuse, node_cap=None):
+    """(engine, reused?) ready to play a run keyed by `run` (SelfPlayEngine.RUN_FIELDS) with the net `hip`"""
+    from caro_ai_amd.engine import SelfPlayEngine
+    hw = game.obs_shape[1] * game.obs_shape[2]
+    # (boards whose no-overflow bound is beyond a default tree run with eviction, as lib.utils.play_games does)
+    evict = not node_cap and searches * batch * hw + 64 > SelfPlayEngine.DEFAULT_CAP_LIMIT
+    cap = int(node_cap) if node_cap else SelfPlayEngine.default_node_cap(searches, batch, hw, evict)
+    stagger = bool(stagger) and not evict
+    key = (type(game).__name__, game.kind, game.n, game.k, G, batch, cap, evict, stagger, str(torch.device(device)))
+    eng = _ENGINES.pop(key, None) if reuse else None
+    if eng is not None and eng.h:
+        eng.restart(evaluators=[hip], searches=searches, **run)
+        _ENGINES[key] = eng
+        return eng, True
+    eng = SelfPlayEngine(game, G, evaluators=[hip], max_batch=batch, node_cap=cap, device=device,
+                         searches_hint=searches, stagger=stagger, evict=evict, **run)
+    if reuse:
+        _ENGINES[key] = eng
+        while len(_ENGINES) > ENGINE_CACHE:
+            _ENGINES.popitem(last=False)[1].close()
+    return eng, False
+
+
+def _forget_engine(eng):
+    for k in [k for k, e in _ENGINES.items() if e is eng]:
+        del _ENGINES[k]
+    try:
+        eng.close()
+    except Exception:  # (a close that fails after a device error must not mask the error that brought us here)
+        pass
+
+
+def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0,
+                     searches=cfg.MCTS_SEARCHES, batch=cfg.MCTS_BATCH_SIZE, concurrent=None, node_cap=None):
+    """self_play as a STREAM: the engine is never stopped between calls.  Every slot restarts the moment its game ends
+    (uid += stride, in the tree kernel) and a call returns as soon as n_games games have FINISHED since the previous
+    call; the games then in flight are not thrown away -- they finish inside the next call and reach the replay buffer
+    there.  Between two promotions train.py plays every self-play game with the same best net (train.py:44,185-217),
+    so a game started during one iteration and finished during the next is the same game the reference would have
+    played; every started game is consumed exactly once, none is dropped, and the GPU never runs the sparse tail of
+    a generation -- the pipeline is bench.py's, the rate bench.py's.
+    What changes against `self_play`: WHEN a game's tuples arrive (a long game may land one iteration later), not
+    which games are played or how.  When the net's weights have changed since the stream was started (a promotion),
+    the games in flight belong to the old net: the stream is restarted (they are dropped, at most one game per slot).
+    Needs the staggered geometry (one wavefront per game).  Returns what self_play returns; `nodes` / `speed_nodes`
+    count the node-expansions of this call's launches (incl. the part of the in-flight games played in it)."""
+    from caro_ai_amd import net_hip
+    t_call = time.time()
+    rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
+    if not staggered_ok(game, batch):
+        raise _lib.CaroError("self_play_stream needs the one-wavefront-per-game geometry (connect four with batch 8, ...)")
+    G = max(1, int(concurrent or n_games))
+    stride = world * G
+    hip = net_hip.hipnet_for(net, device)
+    hw = game.obs_shape[1] * game.obs_shape[2]
+    from caro_ai_amd.engine import SelfPlayEngine
+    cap = int(node_cap) if node_cap else SelfPlayEngine.default_node_cap(searches, batch, hw)
+    key = ("stream", type(game).__name__, game.kind, game.n, game.k, G, batch, cap, str(torch.device(device)))
+    eng = _ENGINES.pop(key, None)
+    ss = getattr(eng, "_stream_state", None) if eng is not None and eng.h else None
+    reused = ss is not None and ss["hip"] is hip and ss["searches"] == searches
+    if not reused:
+        base = uid_base + rank * G
+        if ss is not None:  # keep uids unique across restarts: beyond anything the old stream may have started
+            base = max(base, ss["base"] + (ss["passes"] // 4 + 2) * stride)
+        run = dict(seed=seed, uid_base=base, uid_stride=stride, games_limit=0, stagger_recycle=True,
+                   steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0)
+        if eng is not None and eng.h:
+            eng._drain_open and eng.flush()
+            eng.restart(evaluators=[hip], searches=searches, **run)
+        else:
+            eng = SelfPlayEngine(game, G, evaluators=[hip], max_batch=batch, node_cap=cap, device=device,
+                                 searches_hint=searches, stagger=True, **run)
+        ss = {"hip": hip, "searches": searches, "base": base, "passes": 0,
+              "c": dict.fromkeys(("expansions", "overflows", "plies", "finished"), 0)}
+        eng._stream_state = ss
+    _ENGINES[key] = eng
+    while len(_ENGINES) > ENGINE_CACHE:
+        _ENGINES.popitem(last=False)[1].close()
+    t_ready = time.time()
+    st = {"finished": 0, "rows": 0}
+    records = []
+    gatherer = parallel.TupleGatherer(every=1 << 30, pi_dtype=torch.float32)
+
+    def take(d):
+        if d is None or not int(d["games"].shape[0]):
+            return
+        st["finished"] += int(d["games"].shape[0])
+        st["rows"] += int(d["z"].shape[0])
+        records.append(d["games"])
+        gatherer.push(d)
+
+    try:
+        max_passes = (hw + 4) * (-(-n_games // G)) + searches + 8
+        passes = 0
+        # (no flush at the end: the last enqueued pass keeps the GPU busy while the host goes on, its rows are handed
+        # out by the first move() of the next call)
+        while st["finished"] < n_games and passes <= max_passes:
+            take(eng.move(searches, batch, recycle=True))
+            passes += 1
+        ss["passes"] += passes
+        t_played = time.time()
+        c = eng.counters()
+        if c["overflows"] > ss["c"]["overflows"]:
+            raise _lib.CaroError("self_play_stream: %d minibatches overflowed the node pool (node_cap=%d)"
+                                 % (c["overflows"] - ss["c"]["overflows"], eng.cfg.node_cap))
+        if st["finished"] < n_games:
+            raise _lib.CaroError("self_play_stream: %d of %d games finished after %d passes" % (st["finished"], n_games, passes))
+        nodes = c["expansions"] - ss["c"]["expansions"]
+        ss["c"] = {k: c[k] for k in ss["c"]}
+        recs = torch.cat(records).cpu().numpy()
+        if len(np.unique(recs[:, 0])) != len(recs):
+            raise _lib.CaroError("self_play_stream: a game was drained twice")
+        steps = int(recs[:, 3].sum())
+    except BaseException:
+        _forget_engine(eng)
+        if parallel.is_dist():
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(13)
+        raise
+    try:
+        out = gatherer.flush()
+        if out is not None:
+            replay_buffer.extend(out)
+    except BaseException:
+        _forget_engine(eng)
+        raise
+    dt = time.time() - t_call
+    return {"speed_steps": steps / dt, "speed_nodes": nodes / dt, "steps": steps, "nodes": nodes,
+            "games": st["finished"], "games_dropped": 0, "rows": st["rows"], "seconds": dt,
+            "seconds_setup": t_ready - t_call, "seconds_play": t_played - t_ready,
+            "seconds_gather": time.time() - t_played, "engine_reused": reused, "passes": passes,
+            "speed_nodes_play": nodes / max(t_played - t_ready, 1e-9)}
+
+
+def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0, searches=cfg.MCTS_SEARCHES,
+              batch=cfg.MCTS_BATCH_SIZE, concurrent=None, stagger=False, reuse=True, node_cap=None):
+    """Play n_games (per rank) with the (best) net against itself, tuples appended on the device.
+    Returns speed_steps, speed_nodes, steps, nodes (train.py:49-58) on the wall clock of the WHOLE call -- engine
+    construction or restart, weight upload, the games, the tuple exchange --, plus where the time went.
+
+    WHICH games: slot g of this rank plays uids uid_base + rank*G + g (+ k * world * G for its k-th restart), and the
+    games played are exactly the first n_games of that sequence (local index k*G + g < n_games; the engine's
+    `games_limit`): a slot whose next game would lie beyond them stays finished, so no game outside the wanted set is
+    ever started, every counted node-expansion belongs to a wanted game, and the replay buffer never holds a
+    length-biased "first to finish" sample.  The same set whether the engine runs lock-step or staggered.
+    stagger=True (the CLI's choice where the geometry allows): the engine's staggered mode -- every game on its own
+    minibatch clock; each game is the one the lock-step form plays for the same uid, only the ORDER in which games
+    reach the replay buffer differs.
+    reuse=True: the engine (and the HipNet, while the weights do not change) is kept for the next call of the same
+    shape and restarted in place; a reused engine plays the games of a fresh one bit for bit
+    (tests/test_gpu_stagger.py::test_reused_self_play_engine_plays_the_fresh_engines_games).
+    node_cap: nodes per tree (default: searches x batch x cells, which cannot overflow).
+    Raises CaroError if a tree overflowed its node pool (the games would no longer be the reference's)."""
+    from caro_ai_amd import net_hip
+    t_call = time.time()
+    rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
+    G = max(1, min(int(concurrent or n_games), int(n_games)))
+    stagger = bool(stagger) and staggered_ok(game, batch)
+    restarts = n_games > G
+    base, stride = uid_base + rank * G, world * G
+    run = dict(seed=seed, uid_base=base, uid_stride=stride, games_limit=n_games, stagger_recycle=restarts,
+               steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0)
+    hip = net_hip.hipnet_for(net, device)
+    eng, reused = _engine_for(game, G, batch, searches, device, stagger, run, hip, reuse, node_cap)
+    t_ready = time.time()
+    st = {"finished": 0, "rows": 0}
+    records = []
+    gatherer = parallel.TupleGatherer(every=1 << 30, pi_dtype=torch.float32)
+
+    def take(d):
+        """the tuples of one drain (every drained game is a wanted one: games_limit).  Nothing here waits for the
+        GPU -- the next move is already enqueued on this stream, and a synchronising read would hold the host until
+        that move is over: counts come from shapes, the game records are looked at once, after the loop"""
+        if d is None or not int(d["games"].shape[0]):
+            return
+        st["finished"] += int(d["games"].shape[0])
+        st["rows"] += int(d["z"].shape[0])
+        records.append(d["games"])
+        gatherer.push(d)
+
+    try:
+        # one pass = `searches` launches = one ply per game (staggered: on average; a game sits out fewer than
+        # `searches` launches at the start): a bound on the passes that a healthy run never reaches
         hw = game.obs_shape[1] * game.obs_shape[2]
         max_passes = (hw + 4) * (-(-n_games // G)) + 8
         passes = 0
@@ -164,95 +361,53 @@ def _self_play_loop(eng, game, n_games, G, searches, batch, stagger, restarts, s
             take(eng.move(searches, batch, recycle=restarts))  # host-pipelined: hands out the previous pass's rows
             passes += 1
             if passes > max_passes:
-                raise _lib.CaroError("self_play: %d of %d games finished after %d passes" % (st["finished"], n_games, passes))
-        take(eng.flush())
-    else:
-        while st["finished"] < n_games:
-            eng.search(searches, batch)
-            eng.step()
-            # restart drained slots while some slot still has a wanted generation to begin
-            d = eng.drain(recycle=bool(restarts and (slot_gen < last_gen).any()))
-            ng = int(d["games"].shape[0])
-            take(d)
-            if not ng and eng.live_games() == 0:
                 break
-
-
-def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0, searches=cfg.MCTS_SEARCHES,
-              batch=cfg.MCTS_BATCH_SIZE, concurrent=None, stagger=False):
-    """Play n_games (per rank) with the (best) net against itself, tuples appended on the device.
-    Returns speed_steps, speed_nodes, steps, nodes (train.py:49-58).
-
-    WHICH games: slot g of this rank plays uids uid_base + rank*G + g (+ k * world * G for its k-th restart), and the
-    games wanted are the first n_games of that sequence (local index k*G + g < n_games) -- the same set whether the
-    engine runs lock-step or staggered, whatever finishes first.  With G == n_games (the default) every slot plays
-    exactly its own uid to the end and nothing restarts.  With fewer slots than games the slots restart; slots that
-    run ahead may start games beyond the wanted set while the last wanted ones finish: those are played but their
-    tuples are DROPPED, so the replay buffer never holds a length-biased "first to finish" sample.
-    stagger=True (the CLI's choice where the geometry allows): the engine's staggered mode -- every game on its own
-    minibatch clock; each game is the one the lock-step form plays for the same uid, only the ORDER in which games
-    reach the replay buffer differs."""
-    from caro_ai_amd.engine import SelfPlayEngine
-    rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
-    G = max(1, min(int(concurrent or n_games), int(n_games)))
-    stagger = bool(stagger) and staggered_ok(game, batch)
-    restarts = n_games > G
-    base, stride = uid_base + rank * G, world * G
-    eng = SelfPlayEngine(game, G, net1=net, max_batch=batch, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0, seed=seed,
-                         device=device, searches_hint=searches, uid_base=base, uid_stride=stride,
-                         stagger=stagger, stagger_recycle=restarts)
-    t0 = time.time()
-    st = {"finished": 0, "steps": 0, "dropped": 0}
-    slot_gen = np.zeros(G, dtype=np.int64)                  # generation each slot is playing (lock-step bookkeeping)
-    last_gen = (n_games - 1 - np.arange(G)) // G             # last wanted generation of each slot
-    gatherer = parallel.TupleGatherer(every=1 << 30, pi_dtype=torch.float32)
-
-    def take(d):
-        """keep the tuples of the wanted games of one drain"""
-        if d is None or not int(d["games"].shape[0]):
-            return
-        recs = d["games"]
+        take(eng.flush())
+        t_played = time.time()
+        c = eng.counters()
+        if c["overflows"]:
+            raise _lib.CaroError("self_play: %d minibatches overflowed the node pool (node_cap=%d) or plies were refused "
+                                 "on a root without visits: the games are not the reference's" % (c["overflows"], eng.cfg.node_cap))
+        if st["finished"] < n_games:
+            raise _lib.CaroError("self_play: %d of %d games finished after %d passes" % (st["finished"], n_games, passes))
+        recs = torch.cat(records).cpu().numpy() if records else np.zeros((0, 4), np.int64)
         off = recs[:, 0] - base
         k, g = off // stride, off % stride
-        want = (off >= 0) & (g < G) & (k * G + g < n_games)
-        nwant = int(want.sum().item())
-        st["finished"] += nwant
-        st["dropped"] += int(recs.shape[0]) - nwant
-        st["steps"] += int(recs[want, 3].sum().item())
-        np.maximum.at(slot_gen, g[want].cpu().numpy(), k[want].cpu().numpy() + 1)
-        if nwant == int(recs.shape[0]):
-            gatherer.push(d)
-        elif nwant:
-            keep = torch.repeat_interleave(want, recs[:, 3] + 1)  # a game of s steps holds s + 1 rows
-            gatherer.push({f: d[f][keep] for f in ("states", "players", "pi", "z")})
-
-    try:
-        _self_play_loop(eng, game, n_games, G, searches, batch, stagger, restarts, st, slot_gen, last_gen, take)
+        if not ((off >= 0) & (g < G) & (k * G + g < n_games)).all() or len(np.unique(recs[:, 0])) != n_games:
+            raise _lib.CaroError("self_play: the engine drained games outside the wanted set")
+        steps = int(recs[:, 3].sum())
     except BaseException:
-        # the engine goes whatever happens (its trees are gigabytes).  Under several ranks the error must END this rank:
-        # the peers are on their way to the collective in gatherer.flush() and would wait there for the backend's
-        # timeout; a rank that exits non-zero is what the launcher's fail-fast path (bench.py / torchrun) acts on.
-        eng.close()
+        # the engine goes whatever happens (its trees are gigabytes, and its state is unknown).  Under several ranks the
+        # error must END this rank: the peers are on their way to the collective in gatherer.flush() and would wait
+        # there for the backend's timeout; a rank that exits non-zero is what the launcher's fail-fast path acts on.
+        _forget_engine(eng)
         if parallel.is_dist():
             import traceback
             traceback.print_exc()
             sys.stderr.flush()
             os._exit(13)
         raise
-    # multi-GPU: the loop above is driven by rank-local counts, so the exchange is ONE collective at the end, when every
-    # rank has left its loop
-    out = gatherer.flush()
-    if out is not None:
-        replay_buffer.extend(out)
-    c = eng.counters()
-    dt = time.time() - t0
-    eng.close()
-    return {"speed_steps": st["steps"] / dt, "speed_nodes": c["expansions"] / dt, "steps": st["steps"],
-            "nodes": c["expansions"], "games": st["finished"], "games_dropped": st["dropped"]}
+    try:
+        # multi-GPU: the loop above is driven by rank-local counts, so the exchange is ONE collective at the end, when
+        # every rank has left its loop
+        out = gatherer.flush()
+        if out is not None:
+            replay_buffer.extend(out)
+    except BaseException:
+        _forget_engine(eng)
+        raise
+    if not reuse:
+        eng.close()
+    dt = time.time() - t_call
+    return {"speed_steps": steps / dt, "speed_nodes": c["expansions"] / dt, "steps": steps,
+            "nodes": c["expansions"], "games": st["finished"], "games_dropped": 0, "rows": st["rows"],
+            "seconds": dt, "seconds_setup": t_ready - t_call, "seconds_play": t_played - t_ready,
+            "seconds_gather": time.time() - t_played, "engine_reused": reused, "passes": passes,
+            "speed_nodes_play": c["expansions"] / max(t_played - t_ready, 1e-9)}
 
 
 def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="cuda:0", seed=0,
-             reference_stores=False, counts=False):
+             reference_stores=False, counts=False, node_cap=None):
     """challenger (net1) vs champion (net2): `rounds` games, 20 x 16 sims, tau = 0 from move 0, one tree per
     player; returns challenger_win / (wins + losses + draws)  (train.py:120-149).
     With several ranks each plays a contiguous share of the rounds (round = game uid, so the set of games is the
@@ -270,14 +425,16 @@ def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="c
     (`lib.utils.play_game`: the opener by np.random.choice(2), one Dirichlet row per descent and one choice per ply
     from numpy's global stream, exactly the reference's draws), trees on the GPU.  Sequential by construction (round
     r searches on what rounds < r left behind), so only rank 0 plays and the counters are shared.  Pinned against
-    rounds recorded from the reference: tests/test_gpu_shim.py::test_evaluate_with_reference_stores_*."""
+    rounds recorded from the reference: tests/test_gpu_shim.py::test_evaluate_with_reference_stores_*.
+    Either form raises (CaroError / MemoryError) if a tree overflowed its node pool (`node_cap`: default = cannot)."""
     rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
     if reference_stores:
         from caro_ai_amd.lib import mcts as mcts_mod
         from caro_ai_amd.lib.utils import play_game
         res = []
         if rank == 0:
-            stores = [mcts_mod.MCTS(game, tree_device=device), mcts_mod.MCTS(game, tree_device=device)]
+            stores = [mcts_mod.MCTS(game, tree_device=device, node_cap=node_cap),
+                      mcts_mod.MCTS(game, tree_device=device, node_cap=node_cap)]
             for _ in range(rounds):
                 r, _ = play_game(game, stores, None, challenger, champion, steps_before_tau_0=0, mcts_searches=20,
                                  mcts_batch_size=16, device=device)
@@ -290,7 +447,7 @@ def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="c
     res = []
     if n:
         res = play_games(game, n, None, challenger, champion, steps_before_tau_0=0, mcts_searches=20,
-                         mcts_batch_size=16, concurrent=n, seed=seed, uid_base=lo, device=device)
+                         mcts_batch_size=16, concurrent=n, seed=seed, uid_base=lo, device=device, node_cap=node_cap)
     wins, losses, draws = parallel.allreduce_counts((res.count(1), res.count(-1), res.count(0)), device)
     ratio = wins / max(1, wins + losses + draws)
     return (ratio, (wins, losses, draws)) if counts else ratio  # counts=True: + (wins, losses, draws) of the challenger
@@ -318,7 +475,13 @@ def parse_args(argv=None):
     p.add_argument("--cuda", default=False, action="store_true", help="Enable CUDA (the HIP engine needs it)")
     game_provider.add_game_argument(p)
     p.add_argument("--games", type=int, default=256, help="self-play games per iteration (reference: PLAY_EPISODES=1)")
+    p.add_argument("--concurrent", type=int, default=0,
+                   help="game slots on the GPU (default: one per game, at most 1024); fewer slots than games: slots restart")
     p.add_argument("--iterations", type=int, default=0, help="stop after this many iterations (0 = run for ever)")
+    p.add_argument("--exact-self-play", action="store_true",
+                   help="every iteration plays exactly its own --games games to the end (the GPU runs the sparse tail "
+                        "of the last generation); default: self-play as a stream -- slots restart at once, an iteration "
+                        "takes the first --games games that finish, games in flight carry over")
     p.add_argument("--saves", default="saves")
     p.add_argument("--reference-evaluate", action="store_true",
                    help="arena gate with the reference's store semantics: one pair of MCTS stores reused by all "
@@ -330,25 +493,44 @@ def parse_args(argv=None):
 
 
 def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, reference_evaluate=False, ddp=False,
-        sample_seed=None, stop=None, log=print):
+        sample_seed=None, stop=None, log=print, concurrent=None, stream=False):
     """The reference's training loop (train.py:165-217): self-play with the best net -> replay buffer -> TRAIN_ROUNDS SGD
     steps -> every EVALUATE_EVERY_STEP iterations the arena gate (challenger = the net being trained against the best
     net; promoted when its win ratio exceeds BEST_NET_WIN_RATIO: `NetWrapper.sync`, `best_%03d_%05d.dat`).
     `games` self-play games per iteration (reference: PLAY_EPISODES = 1), `iterations` 0 = for ever.
     sample_seed: seed of the replay sampling (None: torch's global generator, as the reference); stop(history) -> True
-    ends the loop early.  Returns the history: per trained iteration the three losses, per evaluation (iteration, win
-    ratio, promoted), the number of promotions, the best net wrapper."""
+    ends the loop early (several ranks: rank 0 decides, the others follow).  `concurrent`: game slots per rank (default:
+    one per game).  stream=True: self-play as a stream (`self_play_stream`: slots restart at once, an iteration takes
+    the first `games` games that finish, games in flight carry over to the next iteration -- no sparse tail; where the
+    geometry has no staggered mode the exact form is used).  Returns the history: per trained iteration the three losses, per evaluation (iteration, win
+    ratio, promoted), the number of promotions, the best net wrapper, and per iteration the seconds each phase took
+    (`phases`: self_play -- with its own setup / play / gather split --, train, broadcast, evaluate)."""
     rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
     writer = writer or _NullWriter()
     best_net = NetWrapper(net)
     optimizer = optim.SGD(net.parameters(), lr=cfg.LEARNING_RATE, momentum=0.9)
     replay_buffer = DeviceReplayBuffer(game, cfg.REPLAY_BUFFER, device)
     hist = {"loss_total": [], "loss_value": [], "loss_policy": [], "evaluations": [], "promotions": 0,
-            "best_net": best_net, "speed_nodes": [], "iterations": 0}
+            "best_net": best_net, "speed_nodes": [], "iterations": 0, "phases": []}
     step_idx = best_idx = 0
+
+    def clock():
+        if str(device).startswith("cuda"):
+            torch.cuda.synchronize(device)
+        return time.time()
+
     while iterations == 0 or step_idx < iterations:
-        sp = self_play(game, replay_buffer, best_net.target_model, games, device=device, seed=step_idx,
-                       uid_base=step_idx * games * world, stagger=True)
+        t0 = clock()
+        if stream and staggered_ok(game, cfg.MCTS_BATCH_SIZE):
+            sp = self_play_stream(game, replay_buffer, best_net.target_model, games, device=device, seed=0,
+                                  uid_base=step_idx * games * world, concurrent=concurrent)
+        else:
+            sp = self_play(game, replay_buffer, best_net.target_model, games, device=device, seed=step_idx,
+                           uid_base=step_idx * games * world, stagger=True, concurrent=concurrent)
+        ph = {"self_play": clock() - t0, "self_play_setup": sp["seconds_setup"], "self_play_play": sp["seconds_play"],
+              "self_play_gather": sp["seconds_gather"], "engine_reused": sp["engine_reused"], "nodes": sp["nodes"],
+              "train": 0.0, "broadcast": 0.0, "evaluate": 0.0}
+        hist["phases"].append(ph)
         step_idx += 1
         hist["iterations"] = step_idx
         hist["speed_nodes"].append(sp["speed_nodes"])
@@ -359,6 +541,7 @@ def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, re
                 step_idx, sp["steps"], sp["nodes"], sp["speed_steps"], sp["speed_nodes"], best_idx, len(replay_buffer)))
         if len(replay_buffer) < cfg.MIN_REPLAY_TO_TRAIN:
             continue
+        t0 = clock()
         gen = None
         if (ddp and world > 1) or sample_seed is not None:
             gen = torch.Generator(device=replay_buffer.device)
@@ -371,9 +554,13 @@ def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, re
             for k, v in losses.items():
                 writer.add_scalar(k, v, step_idx)
                 hist[k].append(float(v))
+        ph["train"] = clock() - t0
+        t0 = clock()
         # (ddp: the parameters are already identical; the batch-norm running statistics are each rank's own: rank 0's go out)
         parallel.broadcast_weights(net)
+        ph["broadcast"] = clock() - t0
         if step_idx % cfg.EVALUATE_EVERY_STEP == 0:
+            t0 = clock()
             win_ratio = evaluate(game, net, best_net.target_model, rounds=cfg.EVALUATION_ROUNDS, device=device,
                                  seed=step_idx, reference_stores=reference_evaluate)
             if rank == 0 and log:
@@ -389,8 +576,14 @@ def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, re
                 hist["promotions"] = best_idx
                 if rank == 0 and saves_path:
                     torch.save(net.state_dict(), os.path.join(saves_path, "best_%03d_%05d.dat" % (best_idx, step_idx)))
-        if stop is not None and stop(hist):
-            break
+            ph["evaluate"] = clock() - t0
+        if stop is not None:
+            # the losses live on rank 0 only, so rank 0 decides and every rank hears it: a rank-local decision would
+            # leave the others in the next collective
+            flag = torch.tensor([1.0 if (rank == 0 and stop(hist)) else 0.0], dtype=torch.float64, device=device)
+            parallel.allreduce_max(flag)
+            if flag.item() > 0:
+                break
     return hist
 
 
@@ -406,7 +599,8 @@ def main(argv=None):
     net = Net(input_shape=game.obs_shape, actions_n=game.action_space).to(device)
     parallel.broadcast_weights(net)
     fit(game, net, device, args.games, iterations=args.iterations, saves_path=saves_path, writer=writer,
-        reference_evaluate=args.reference_evaluate, ddp=args.ddp, log=lambda m: print(m, flush=True))
+        reference_evaluate=args.reference_evaluate, ddp=args.ddp, log=lambda m: print(m, flush=True),
+        concurrent=args.concurrent or min(args.games, 1024), stream=not args.exact_self_play)
     writer.close()
 
 

@@ -66,6 +66,12 @@ typedef struct caro_config {
   int32_t stagger;            /* > 0: staggered mode with this many minibatches (mcts_searches) per move -- every game
                                  on its own minibatch clock, see caro_search_staggered; 0: lock-step */
   int32_t stagger_recycle;    /* staggered mode: a finished game's slot restarts in-kernel (uid += uid_stride) */
+  int64_t games_limit;        /* > 0: the engine plays exactly the games with local index k * n_games + g < games_limit
+                                 (slot g, its k-th game; uid = uid_base + g + k * uid_stride): a slot whose next game
+                                 would lie beyond that stays finished instead of restarting, in either schedule, and
+                                 slots g >= games_limit never start.  This is train.py:41-47's `for _ in
+                                 range(PLAY_EPISODES)` as a property of the engine: no game outside the wanted set is
+                                 ever started, so counters and tuples belong to the wanted games only.  0: no limit */
 } caro_config;
 
 const char* caro_last_error(void);
@@ -108,6 +114,16 @@ int caro_noise_batch(uint64_t seed, int64_t M, int A, double alpha, const uint64
 /* replaces MCTS.__init__ (lib/mcts.py:27-37) for every tree of every game */
 int caro_engine_create(const caro_config* cfg, caro_engine** out);
 void caro_engine_destroy(caro_engine* h);
+/* A NEW RUN on an existing engine, in place of destroy + create (train.py:185-193 builds its store once and plays
+ * every self-play call on it; here the gigabytes of tree tables are kept and only cleared): every game restarts from
+ * the initial position with empty trees, zero counters, fresh minibatch clocks and no parked games -- the state
+ * caro_engine_create leaves behind, so a restarted engine plays bit for bit what a fresh engine of the same
+ * configuration plays.  `cfg` must agree with the engine in everything that shapes its memory (game_kind, n, k,
+ * n_games, n_stores, n_nets, max_batch, node_cap, evict, device_id, staggered or not); taken afresh from it are
+ * seed, uid_base, uid_stride, games_limit, steps_before_tau_0, first_player_mode, c_puct, alpha, explore, stagger
+ * (the number of minibatches per move) and stagger_recycle.  Works on lock-step and staggered engines; refuses
+ * (CARO_E_STATE) while a drain or a select is pending.  Enqueues on `stream`, does not synchronise. */
+int caro_engine_restart(caro_engine* h, const caro_config* cfg, void* stream);
 /* (re)start every game from the initial position with an empty tree: utils.py:58-73 / MCTS.clear (mcts.py:39-43).
  * first_player_dev: i32[G] or NULL (use first_player_mode). */
 int caro_reset_games(caro_engine* h, const int32_t* first_player_dev, void* stream);
@@ -177,7 +193,11 @@ int caro_drain_tuples_begin(caro_engine* h, int64_t cap, uint64_t* states_dev, i
 int caro_drain_tuples_end(caro_engine* h, int64_t* n_tuples, int64_t* n_games);
 
 /* counters[8] (host array): sims, levels, expansions, terminals, dropped
- * duplicates, node-pool overflows, plies, finished games.  Synchronises. */
+ * duplicates, overflows, plies, finished games.  Synchronises.
+ * `overflows` counts every event after which the engine's games may no longer be the reference's: a minibatch whose
+ * new nodes did not fit node_cap (its leaves are dropped), and a ply REFUSED because the root had no visits (one
+ * search on an unexpanded root: lib/mcts.py:311 divides by zero there; the game is left where it was).  Every caller
+ * in this package treats a non-zero value as an error. */
 int caro_counters(caro_engine* h, int64_t counters[8], void* stream);
 /* HIP-event timing of the path's kernels on the stream they are launched on (bench.py's live
  * roofline).  Kinds: 0 select, 1 scan+encode, 2 expand+backup, 3 step, 4 net forward (bracketed by the
@@ -309,8 +329,10 @@ int caro_net_debug_stamps(caro_net* n, uint64_t* stamps_dev);
  * leaves travel in slot rows (caro_net_forward_slots); otherwise in the dense rows of caro_select.
  * A move needs searches >= 2 when its root may be unexpanded: the first minibatch on an unexpanded root only expands it
  * (lib/mcts.py:123: every descent returns the root itself, nothing is backed up), so after ONE search no edge has been
- * visited and the policy is 0 / 0 -- the reference raises ZeroDivisionError there (lib/mcts.py:311); caro_policy /
- * caro_step return NaN rows for such a game instead of trapping. */
+ * visited and the policy is 0 / 0 -- the reference raises ZeroDivisionError there (lib/mcts.py:311); caro_policy
+ * returns NaN rows for such a game, and caro_step / the staggered ply REFUSE the ply (the game stays where it was,
+ * actions_dev = -1, counters[5] is bumped) when tau = 1 or when action 0 -- the reference's argmax of an all-zero
+ * row at tau = 0 -- is not a legal move. */
 int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch,
                       const double* noise_dev, float* planes_dev, uint64_t* leaf_keys_dev, float* probs_dev,
                       float* values_dev, void* stream);

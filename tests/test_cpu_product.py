@@ -28,8 +28,59 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_layout_matches_header():
     from caro_ai_amd import _lib
-    assert C.sizeof(_lib.CaroConfig) == 104
+    assert C.sizeof(_lib.CaroConfig) == 112
     assert _lib.CaroConfig.alpha.offset == 48 and _lib.CaroConfig.seed.offset == 64
+    assert _lib.CaroConfig.stagger_recycle.offset == 100 and _lib.CaroConfig.games_limit.offset == 104
+
+
+def test_default_node_cap_is_the_no_overflow_bound_or_refused():
+    """VERDICT r5 task 3: the default cap is searches x batch x cells (+ slack) -- it cannot overflow -- and where that is
+    beyond a default tree the constructor refuses (no silent clamp) unless eviction is on"""
+    from caro_ai_amd import _lib
+    from caro_ai_amd.engine import SelfPlayEngine as E
+    assert E.default_node_cap(25, 8, 42) == 25 * 8 * 42 + 64
+    assert E.default_node_cap(100, 8, 42) == 100 * 8 * 42 + 64
+    assert E.default_node_cap(10, 8, 225) == 10 * 8 * 225 + 64
+    with pytest.raises(_lib.CaroError, match="evict=True"):
+        E.default_node_cap(50, 8, 225)  # 90 064 nodes of 4 KB: round 5 clamped this to 65 536 without a word
+    assert E.default_node_cap(50, 8, 225, evict=True) == E.EVICT_DEFAULT_CAP
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 8, 10, 11, 12, 15])
+def test_array_conversions_equal_the_per_state_codec(n):
+    """f3 (VERDICT r5 task 4): to_keys / from_keys over whole arrays == the per-state to_key / from_key, on random boards
+    incl. leading zeros (tokens of player 0 in the first cells), the empty and the full board"""
+    import random
+    import time
+    from caro_ai_amd.lib.game._packed import PackedGame
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    g = TicTacToe(n, min(n, 5))
+    rnd = random.Random(n)
+    states = [int("".join(rnd.choice("012") for _ in range(n * n))) for _ in range(400)]
+    states += [g.initial_state, int("0" * (n * n)), int("1" * (n * n)), int("0" * (n * n - 1) + "1")]
+    t0 = time.perf_counter()
+    keys = g.to_keys(states)
+    back = g.from_keys(keys)
+    dt = (time.perf_counter() - t0) / len(states)
+    assert back == states
+    assert np.array_equal(keys, PackedGame.to_keys(g, states)) and PackedGame.from_keys(g, keys) == states
+    assert keys.dtype == np.uint64 and keys.shape == (len(states), g.key_words)
+    assert g.to_keys([]).shape == (0, g.key_words) and g.from_keys(np.zeros((0, g.key_words), np.uint64)) == []
+    assert dt < 40e-6  # both ways; measured 2.7 us at 15 x 15 (the per-bit loops: 140 us)
+    with pytest.raises(AssertionError):
+        g.to_keys([int("1" + "0" * (n * n))])  # more digits than cells
+
+
+def test_connect_four_array_conversions():
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    g = ConnectFour()
+    s, states = g.initial_state, []
+    for i in range(20):
+        states.append(s)
+        s, _ = g.move(s, i % 7, i & 1)
+    keys = g.to_keys(states)
+    assert keys.shape == (20, 1) and keys.dtype == np.uint64 and g.from_keys(keys) == states
+    assert all(isinstance(x, int) for x in g.from_keys(keys))
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

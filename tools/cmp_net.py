@@ -20,7 +20,7 @@ for name, shape, A, sizes in (("c4", (2, 6, 7), 7, (1, 5, 6, 7, 100, 256, 600, 1
                               ("g15", (2, 15, 15), 225, (1, 3, 300))):
     net = Net(shape, A)
     if name == "c4":
-        net.load_state_dict(torch.load("tests/golden/weights/best_026_12000.dat", map_location="cpu"))
+        net.load_state_dict(torch.load("caro_ai_amd/data/weights/best_026_12000.dat", map_location="cpu"))
     else:
         with torch.no_grad():
             for prm in net.parameters(): prm.mul_(1.5)

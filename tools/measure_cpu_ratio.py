@@ -56,7 +56,7 @@ def time_port(seconds, base=0):
     from oracle.oracle import Oracle
     o = Oracle(Oracle.C4)
     net = Net((2, 6, 7), 7)
-    net.load_state_dict(torch.load(os.path.join(ROOT, "tests/golden/weights/best_026_12000.dat"), map_location="cpu"))
+    net.load_state_dict(torch.load(os.path.join(ROOT, "caro_ai_amd/data/weights/best_026_12000.dat"), map_location="cpu"))
     net.eval()
 
     def fn(planes, states, players):

@@ -19,7 +19,7 @@ import time
 import numpy as np
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-WEIGHTS = os.path.join(ROOT, "tests", "golden", "weights", "best_026_12000.dat")
+WEIGHTS = os.path.join(ROOT, "caro_ai_amd", "data", "weights", "best_026_12000.dat")
 
 
 def run(Session, game, n_moves, seed, after=None, **kw):

@@ -12,11 +12,11 @@ from caro_ai_amd.lib.model import Net
 from caro_ai_amd.net_hip import HipNet
 arena = "--arena" in sys.argv
 g = ConnectFour()
-net = Net(g.obs_shape, 7); net.load_state_dict(torch.load("tests/golden/weights/best_026_12000.dat", map_location="cpu"))
+net = Net(g.obs_shape, 7); net.load_state_dict(torch.load("caro_ai_amd/data/weights/best_026_12000.dat", map_location="cpu"))
 G, S, B = (512, 100, 8) if arena else (1024, 25, 8)
 evs = [HipNet(net, "cuda:0")]
 if arena:
-    net2 = Net(g.obs_shape, 7); net2.load_state_dict(torch.load("tests/golden/weights/best_025_10600.dat", map_location="cpu"))
+    net2 = Net(g.obs_shape, 7); net2.load_state_dict(torch.load("caro_ai_amd/data/weights/best_025_10600.dat", map_location="cpu"))
     evs.append(HipNet(net2, "cuda:0"))
 eng = SelfPlayEngine(g, G, evaluators=evs, max_batch=B, seed=0, stagger=True, searches_hint=S,
                      **({"n_stores": 2, "first_player_mode": 2, "steps_before_tau_0": 0} if arena else {}))

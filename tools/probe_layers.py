@@ -9,7 +9,7 @@ from caro_ai_amd.net_hip import HipNet
 L = _lib.load()
 L.caro_exp_read_lst.argtypes = [C.c_void_p]
 L.caro_exp_read_pst.argtypes = [C.c_void_p]
-net = Net((2, 6, 7), 7); net.load_state_dict(torch.load("tests/golden/weights/best_026_12000.dat", map_location="cpu"))
+net = Net((2, 6, 7), 7); net.load_state_dict(torch.load("caro_ai_amd/data/weights/best_026_12000.dat", map_location="cpu"))
 hn = HipNet(net, "cuda:0", mode="f32w")
 names = ["main loop", "output transform", "barrier (inputs read)", "K-split exchange", "bias+leaky+write", "vmcnt+barrier"]
 for rows in [int(a) for a in sys.argv[1:]] or [200, 717, 1434]:

@@ -8,7 +8,7 @@ from caro_ai_amd.lib.game.connect_four import ConnectFour
 from caro_ai_amd.lib.model import Net
 from caro_ai_amd.net_hip import HipNet
 g = ConnectFour()
-net = Net(g.obs_shape, 7); net.load_state_dict(torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "weights", "best_026_12000.dat"), map_location="cpu"))
+net = Net(g.obs_shape, 7); net.load_state_dict(torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "caro_ai_amd", "data", "weights", "best_026_12000.dat"), map_location="cpu"))
 G, S, B = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), 25, 8
 CAP = int(sys.argv[2]) if len(sys.argv) > 2 else None
 eng = SelfPlayEngine(g, G, evaluators=[HipNet(net, "cuda:0")], max_batch=B, seed=0, stagger=True, searches_hint=S, node_cap=CAP)
