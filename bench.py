@@ -267,6 +267,23 @@ def dist_record(world, device, value_local, want_world):
     return rec
 
 
+def run_selfcheck(device, engine=True, fault=None):
+    """--selfcheck: caro_ai_amd.parallel.selfcheck before any timed work -- every collective of the run once, with
+    predictable contents, and a 16-games-per-rank engine whose gathered tuples must equal the same uids played on rank 0
+    alone.  A failure ends EVERY rank with exit code 4 and the failing check's name on stderr (the launcher then reports
+    4); returns the record that goes into the JSON line."""
+    from caro_ai_amd import parallel
+    fault = fault or os.environ.get("CARO_SELFCHECK_FAULT") or None
+    rank = int(os.environ.get("RANK", "0"))
+    try:
+        rec = parallel.selfcheck(device, engine_check=parallel.engine_selfcheck(device) if engine else None, fault=fault,
+                                 log=(lambda m: print(m, file=sys.stderr, flush=True)) if rank == 0 else None)
+    except parallel.SelfcheckError as e:
+        print("[bench] selfcheck FAILED (rank %d): %s" % (rank, e), file=sys.stderr, flush=True)
+        sys.exit(4)
+    return rec
+
+
 # ------------------------------------------------------------------ one timed configuration
 class Leg:
     """One BASELINE.json configuration: engine + nets + the move loop."""
@@ -680,6 +697,10 @@ def main():
     ap.add_argument("--config4-warmup", type=int, default=40,
                     help="moves played at full size before config4's timed moves (mid-game measurement)")
     ap.add_argument("--config4-steps", type=int, default=8)
+    ap.add_argument("--selfcheck", action="store_true",
+                    help="before the timed loop: every collective of the run once with predictable contents, distinct GPUs per "
+                         "rank, and a small engine whose gathered tuples must equal the same games played on rank 0 alone "
+                         "(caro_ai_amd.parallel.selfcheck); any mismatch ends all ranks with exit code 4 and the check's name")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -706,6 +727,7 @@ def main():
     # one rank per GPU; CARO_SHARE_GPU=1 maps every rank to cuda:0 (rehearsal of the N > 1 path on a 1-GPU box)
     device = torch.device("cuda", 0 if os.environ.get("CARO_SHARE_GPU") else local_rank)
     torch.cuda.set_device(device)
+    selfcheck = run_selfcheck(device) if args.selfcheck else None
 
     leg = Leg(args, args.game, args.games, args.searches, args.batch, args.arena, rank, world, device,
               evict=args.evict, node_cap=args.node_cap)
@@ -790,6 +812,7 @@ def main():
                "dtype": "f32"}
         out.update({k: v for k, v in res.items() if k not in out})
         out["dist"] = dist_rec
+        out["selfcheck"] = selfcheck
         out["sustained"] = sustained
         out["train_loop"] = train_loop
         out["cpu_baseline"] = cpu_line

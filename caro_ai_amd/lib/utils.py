@@ -166,7 +166,12 @@ def play_games(game, n_games, replay_buffer, net1, net2=None, steps_before_tau_0
             zs = d["z"].cpu().numpy().tolist()
             replay_buffer.extend(zip(states, players, pis, zs))
 
-        while len(outcome) < n_games:
+        # every pass is one ply of every live game (staggered: on average, after at most `searches` launches of waiting):
+        # a bound no healthy run reaches -- a run whose trees overflow can stop making plies (a root whose expansion was
+        # dropped has no visits, its ply is refused) and must end in the error below, not spin
+        moves_left = (hw + 4) * (-(-n_games // G)) + mcts_searches + 8
+        while len(outcome) < n_games and moves_left > 0:
+            moves_left -= 1
             engine.search(mcts_searches, mcts_batch_size)
             engine.step()
             d = engine.drain(recycle=not stagger)

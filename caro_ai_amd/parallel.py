@@ -224,10 +224,14 @@ class TupleGatherer:
         keep = torch.cat([torch.arange(r * m, r * m + c, device=dev) for r, c in enumerate(counts)])
         allb = allb[keep]
         tot = allb.shape[0]
-        return {"states": allb[:, :8 * KW].contiguous().view(torch.int64).reshape(tot, KW).to(out_dev),
-                "players": allb[:, 8 * KW:8 * KW + 4].contiguous().view(torch.int32).reshape(tot).to(out_dev),
-                "z": allb[:, 8 * KW + 4:8 * KW + 8].contiguous().view(torch.int32).reshape(tot).to(out_dev),
-                "pi": allb[:, 8 * KW + 8:].contiguous().view(self.pi_dtype).reshape(tot, A).to(out_dev)}
+        def field(lo, hi, dtype, shape):
+            # (reshape(-1) first: a ONE-row slice counts as contiguous as it is and keeps the record stride, which a
+            # view as a wider type refuses -- found by selfcheck() on the RCCL group)
+            return allb[:, lo:hi].contiguous().reshape(-1).view(dtype).reshape(shape).to(out_dev)
+        return {"states": field(0, 8 * KW, torch.int64, (tot, KW)),
+                "players": field(8 * KW, 8 * KW + 4, torch.int32, (tot,)),
+                "z": field(8 * KW + 4, 8 * KW + 8, torch.int32, (tot,)),
+                "pi": field(8 * KW + 8, rec, self.pi_dtype, (tot, A))}
 
 
 def allreduce_grads(params):
@@ -316,3 +320,271 @@ def visible_gpu_count(root=None, env=None):
     n = narrow(n, "ROCR_VISIBLE_DEVICES")
     hip = "HIP_VISIBLE_DEVICES" if "HIP_VISIBLE_DEVICES" in env else "CUDA_VISIBLE_DEVICES"
     return narrow(n, hip)
+
+
+# ------------------------------------------------------------------ first-contact checklist of a multi-GPU node, as code
+class SelfcheckError(RuntimeError):
+    """a check of parallel.selfcheck failed; `.check` names it"""
+
+    def __init__(self, check, detail):
+        super().__init__("%s: %s" % (check, detail))
+        self.check = check
+
+
+def _synthetic_rows(rank, n, KW, A):
+    """n replay rows whose content is a function of (rank, row) alone: every rank can compute every other rank's"""
+    i = torch.arange(n, dtype=torch.int64)
+    states = (i[:, None] * 1000003 + rank * 7919 + torch.arange(KW, dtype=torch.int64)[None, :] * 104729) * 2654435761
+    pi = ((i[:, None] * 31 + torch.arange(A)[None, :] * 17 + rank * 13) % 97).to(torch.float32) / 97.0
+    return {"states": states, "players": ((i + rank) % 2).to(torch.int32), "pi": pi,
+            "z": ((i + rank) % 3 - 1).to(torch.int32)}
+
+
+def selfcheck(device="cpu", engine_check=None, fault=None, KW=1, A=7, log=None, force=False):
+    """What a first run on a real multi-GPU node can still trip over, exercised ONCE before any timed work (the
+    reference has no distributed code; everything below is this package's own N > 1 layer, which so far has only run
+    over gloo and on a one-rank RCCL group): every collective the run will issue, at the dtypes and shapes it will use,
+    each with contents every rank can predict, so a wrong answer is caught and NAMED instead of showing up as a hang or
+    as wrong tuples an hour later.
+
+      identity               all_gather_object of (host, device, PCI bus id, uuid): the ranks sit on distinct GPUs
+                             (unless CARO_SHARE_GPU says the sharing is deliberate)
+      header_all_gather      the int64[3] count / shape message of TupleGatherer.flush
+      payload_all_gather     TupleGatherer's byte-packed uint8 payload, with ZERO rows on some ranks, through the class itself
+      empty_flush            a flush with no rows anywhere (returns None on every rank)
+      gather_tuples          the per-field form (one int64 + one float32 all_gather_into_tensor)
+      allreduce_float64      SUM and MAX of float64 (bench.py's totals and max-over-ranks time)
+      allreduce_counts       int64 SUM (arena W / L / D)
+      broadcast_weights      the flat uint8 weight broadcast: every rank ends with rank 0's state_dict bit for bit
+      allreduce_grads        the one flat float32 gradient bucket of the data-parallel step
+      engine_tuples          (GPU) `engine_check(rank, world)` plays this rank's shard of world x 16 table-net games and
+                             returns its tuples; they are exchanged with TupleGatherer and compared, as a multiset of rows,
+                             with the same uids played by rank 0 ALONE (results must not depend on the sharding)
+
+    Every check ends with an all-reduce of its pass / fail flag, so all ranks leave together: SelfcheckError(check,
+    detail) on every rank if any rank saw a mismatch or an exception.  `fault` = name of a check to sabotage on the last
+    rank (its own contribution is corrupted): the failure path of the tests.  Returns {"checks": [...], "seconds": s}.
+    World size 1: the collectives degenerate to local copies; force=True issues them all the same on an initialised
+    one-rank group (what a 1-GPU box can show of RCCL: tests/test_parallel_gloo.py's nccl worker)."""
+    import socket
+    import time as _time
+    t_start = _time.time()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    on = world > 1 or (force and dist.is_available() and dist.is_initialized())
+    dev = torch.device(device)
+    coll_dev = torch.device("cpu") if (on and dist.get_backend() == "gloo") else dev
+    last = world - 1
+    done = []
+
+    def verdict(name, ok, detail=""):
+        """collective: 1.0 if any rank failed"""
+        flag = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=coll_dev)
+        if on:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if flag.item() > 0:
+            raise SelfcheckError(name, detail or "failed on another rank")
+        done.append(name)
+        if log:
+            log("[selfcheck] %s ok" % name)
+
+    def run(name, fn):
+        ok, detail = True, ""
+        try:
+            r = fn(fault == name and rank == last)
+            if r is not None and r is not True:
+                ok, detail = False, str(r)
+        except SelfcheckError:
+            raise
+        except Exception as e:  # a collective that raises on this rank: report it under the check's name
+            ok, detail = False, "%s: %s" % (type(e).__name__, e)
+        verdict(name, ok, detail)
+
+    # -- identity
+    def identity(bad):
+        mine = {"rank": rank, "host": socket.gethostname(), "device": str(dev), "pci_bus_id": None, "uuid": None,
+                "payload": list(range(rank + 1))}
+        if dev.type == "cuda":
+            p = torch.cuda.get_device_properties(dev)
+            mine["pci_bus_id"], mine["uuid"] = getattr(p, "pci_bus_id", None), str(getattr(p, "uuid", "")) or None
+        if bad:
+            mine["payload"] = [-1]
+        allr = [None] * world
+        if on:
+            dist.all_gather_object(allr, mine)
+        else:
+            allr = [mine]
+        for r, m in enumerate(allr):
+            if m["rank"] != r or m["payload"] != list(range(r + 1)):
+                return "all_gather_object returned %r in slot %d" % (m, r)
+        ident = [(m["host"], m["device"], m["pci_bus_id"], m["uuid"]) for m in allr]
+        if dev.type == "cuda" and len(set(ident)) != world and not os.environ.get("CARO_SHARE_GPU"):
+            return "two ranks on one GPU: %s" % ident
+    run("identity", identity)
+
+    counts = [(r * 3 + 1) % 5 for r in range(world)]  # rows per rank: some ranks have none
+    if world > 1:
+        counts[0] = 0
+
+    # -- the count / shape header
+    def header(bad):
+        head = torch.tensor([counts[rank] + (1 if bad else 0), KW, A], dtype=torch.int64, device=coll_dev)
+        heads = torch.zeros(world * 3, dtype=torch.int64, device=coll_dev)
+        if on:
+            dist.all_gather_into_tensor(heads, head)
+        else:
+            heads.copy_(head)
+        want = torch.tensor([[c, KW, A] for c in counts], dtype=torch.int64).reshape(-1)
+        if not torch.equal(heads.cpu(), want):
+            return "int64 all_gather_into_tensor gave %s, expected %s" % (heads.cpu().tolist(), want.tolist())
+    run("header_all_gather", header)
+
+    def expect_rows():
+        parts = [_synthetic_rows(r, counts[r], KW, A) for r in range(world)]
+        return {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+
+    def same_rows(got, want, what):
+        if got is None:
+            return "%s returned no rows, expected %d" % (what, int(want["z"].shape[0]))
+        for k in ("states", "players", "pi", "z"):
+            g = got[k].cpu()
+            if g.shape != want[k].shape or not torch.equal(g, want[k].to(g.dtype)):
+                return "%s: field %r differs (shape %s vs %s)" % (what, k, tuple(g.shape), tuple(want[k].shape))
+
+    # -- the byte-packed payload, through the product class
+    def payload(bad):
+        mine = {k: v.to(dev) for k, v in _synthetic_rows(rank, counts[rank], KW, A).items()}
+        if bad and counts[rank]:
+            mine["pi"] = mine["pi"] + 1.0
+        elif bad:
+            mine = {k: v.to(dev) for k, v in _synthetic_rows(rank, 1, KW, A).items()}
+        tg = TupleGatherer(every=1)
+        return same_rows(tg.push(mine), expect_rows(), "TupleGatherer")
+    run("payload_all_gather", payload)
+
+    def empty(bad):
+        tg = TupleGatherer(every=1)
+        d = {k: v.to(dev) for k, v in _synthetic_rows(rank, 1 if bad else 0, KW, A).items()}
+        out = tg.push(d)
+        if out is not None:
+            return "a flush without rows returned %d rows" % int(out["z"].shape[0])
+    run("empty_flush", empty)
+
+    def per_field(bad):
+        mine = {k: v.to(dev) for k, v in _synthetic_rows(rank, counts[rank], KW, A).items()}
+        if bad:
+            mine["states"] = mine["states"] + 1
+            if not counts[rank]:
+                mine = {k: v.to(dev) for k, v in _synthetic_rows(rank, 2, KW, A).items()}
+        return same_rows(gather_tuples(mine), expect_rows(), "gather_tuples")
+    run("gather_tuples", per_field)
+
+    # -- all-reduces
+    def reduce_f64(bad):
+        t = torch.tensor([rank + 1.0, 2.0 ** -rank, 1e15 + rank], dtype=torch.float64, device=dev)
+        if bad:
+            t = t + 1.0
+        s = allreduce_sum(t.clone()).cpu()
+        m = allreduce_max(t.clone()).cpu()
+        ws = torch.tensor([sum(r + 1.0 for r in range(world)), sum(2.0 ** -r for r in range(world)),
+                           sum(1e15 + r for r in range(world))], dtype=torch.float64)
+        wm = torch.tensor([float(world), 1.0, 1e15 + world - 1], dtype=torch.float64)
+        if not torch.equal(s, ws) or not torch.equal(m, wm):
+            return "float64 all_reduce: SUM %s (expected %s), MAX %s (expected %s)" % (s.tolist(), ws.tolist(), m.tolist(), wm.tolist())
+    run("allreduce_float64", reduce_f64)
+
+    def reduce_counts(bad):
+        got = allreduce_counts((rank + (5 if bad else 0), 2 * rank + 1, 7), dev)
+        want = (sum(range(world)), sum(2 * r + 1 for r in range(world)), 7 * world)
+        if tuple(got) != want:
+            return "int64 all_reduce gave %s, expected %s" % (got, want)
+    run("allreduce_counts", reduce_counts)
+
+    # -- weights and gradients
+    def small_net(seed):
+        torch.manual_seed(seed)
+        net = torch.nn.Sequential(torch.nn.Conv2d(2, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.Flatten(),
+                                  torch.nn.Linear(8 * 9, 5))
+        with torch.no_grad():
+            net[1].running_mean.add_(seed + 0.5)
+            net[1].num_batches_tracked.add_(seed + 3)
+        return net
+
+    def bcast(bad):
+        rng = torch.get_rng_state()
+        net = small_net(100 + rank).to(dev)
+        ref = small_net(100)
+        torch.set_rng_state(rng)
+        broadcast_weights(net)
+        if bad:
+            with torch.no_grad():
+                net[3].bias.add_(1.0)
+        for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
+            if not torch.equal(a.cpu(), b):
+                return "broadcast_weights: tensor %r is not rank 0's" % k
+    run("broadcast_weights", bcast)
+
+    def grads(bad):
+        ps = [torch.nn.Parameter(torch.zeros(n, device=dev)) for n in (5, 64, 3)]
+        for j, p in enumerate(ps):
+            p.grad = torch.full_like(p, float(rank + 1) * (j + 1) + (1.0 if bad else 0.0))
+        allreduce_grads(ps)
+        tot = sum(r + 1.0 for r in range(world))
+        for j, p in enumerate(ps):
+            if not torch.equal(p.grad.cpu(), torch.full((p.numel(),), tot * (j + 1))):
+                return "allreduce_grads: bucket %d holds %s, expected %s" % (j, p.grad.flatten()[:3].tolist(), tot * (j + 1))
+    run("allreduce_grads", grads)
+
+    # -- the engine's tuples: sharded == played alone
+    if engine_check is not None:
+        def engine(bad):
+            mine, alone = engine_check(rank, world)  # this rank's tuples; (rank 0 only) all uids played alone
+            if bad:
+                mine = dict(mine, z=mine["z"] + 1)
+            tg = TupleGatherer(every=1, pi_dtype=torch.float64)
+            allrows = tg.push(mine)
+            if rank != 0:
+                return None
+
+            def multiset(d):
+                n = int(d["z"].shape[0])
+                rec = torch.cat([d["states"].cpu().contiguous().view(torch.uint8).reshape(n, -1),
+                                 d["players"].cpu().to(torch.int32).contiguous().view(torch.uint8).reshape(n, -1),
+                                 d["pi"].cpu().to(torch.float64).contiguous().view(torch.uint8).reshape(n, -1),
+                                 d["z"].cpu().to(torch.int32).contiguous().view(torch.uint8).reshape(n, -1)], dim=1).numpy()
+                return sorted(map(bytes, rec))
+            if allrows is None or multiset(allrows) != multiset(alone):
+                return ("the tuples gathered from %d ranks differ from the same uids played on rank 0 alone (%s vs %d rows)"
+                        % (world, "none" if allrows is None else int(allrows["z"].shape[0]), int(alone["z"].shape[0])))
+        run("engine_tuples", engine)
+    return {"checks": done, "seconds": _time.time() - t_start, "world_size": world,
+            "backend": dist.get_backend() if on else None}
+
+
+def engine_selfcheck(device, games_per_rank=16, searches=4, batch=8, seed=77):
+    """the `engine_check` of selfcheck(): connect four, table net (exact integers: any difference is a real one),
+    `games_per_rank` slots per rank, every slot plays ONE game"""
+    def play(rank, world):
+        from caro_ai_amd.engine import SelfPlayEngine
+        from caro_ai_amd.lib.game.connect_four import ConnectFour
+        from caro_ai_amd.net_hip import HashNet
+        game = ConnectFour()
+
+        def games(G, **uids):
+            eng = SelfPlayEngine(game, G, evaluators=[HashNet(game, device=str(device))], max_batch=batch, seed=seed,
+                                 device=str(device), searches_hint=searches, games_limit=G, steps_before_tau_0=4, **uids)
+            rows = []
+            for _ in range(64):  # (a connect-four game has at most 42 plies)
+                if not eng.live_games():
+                    break
+                eng.search(searches, batch)
+                eng.step()
+                d = eng.drain(recycle=True)
+                if int(d["z"].shape[0]):
+                    rows.append({k: d[k] for k in ("states", "players", "pi", "z")})
+            assert eng.counters()["overflows"] == 0 and eng.live_games() == 0
+            eng.close()
+            return {k: torch.cat([r[k] for r in rows]) for k in rows[0]}
+        mine = games(games_per_rank, **shard(games_per_rank, rank, world))
+        alone = games(games_per_rank * world, uid_base=0, uid_stride=games_per_rank * world) if rank == 0 else None
+        return mine, alone
+    return play

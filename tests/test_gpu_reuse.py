@@ -297,7 +297,9 @@ def test_play_games_fills_a_deque_from_1024_gomoku_games():
     dq = collections.deque()
     by_uid = {}
     t_conv = 0.0
-    while eng.live_games():
+    for _ in range(260):  # (a 15 x 15 game has at most 225 plies)
+        if not eng.live_games():
+            break
         eng.search(S, B)
         eng.step()
         dd = eng.drain(recycle=True)
@@ -367,3 +369,23 @@ def test_self_play_stream_consumes_every_started_game_exactly_once():
     assert not sp["engine_reused"]
     assert next(iter(train._ENGINES.values()))._stream_state["base"] > 1000 + G
     train.release_engines()
+
+
+def test_bench_selfcheck_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 --selfcheck as two gloo ranks sharing the one GPU: the checklist passes (incl. the engine whose
+    gathered tuples equal the same uids played on rank 0 alone) and its record is in the JSON line; with one rank's
+    engine tuples sabotaged every rank ends with exit code 4 and the check's name"""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, CARO_SHARE_GPU="1", CARO_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selfcheck", "--steps", "2", "--warmup", "1",
+           "--games", "64", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["selfcheck"]["checks"][-1] == "engine_tuples" and line["selfcheck"]["world_size"] == 2
+    assert line["n_gpus"] == 2 and line["dist"]["world_size"] == 2
+    r = subprocess.run(cmd, env=dict(env, CARO_SELFCHECK_FAULT="engine_tuples"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 4, (r.returncode, r.stderr[-3000:])
+    assert "selfcheck FAILED" in r.stderr and "engine_tuples:" in r.stderr

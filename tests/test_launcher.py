@@ -102,3 +102,37 @@ def test_self_launch_refuses_more_ranks_than_gpus(tmp_path):
     assert "RC 2" in r.stdout and "never" not in r.stdout
     r = _run_launcher("print('one')", 1, extra_env={"CARO_SHARE_GPU": "", "CARO_KFD_TOPOLOGY": topo})
     assert "RC 0" in r.stdout and "one" in r.stdout
+
+
+# ------------------------------------------------------------------ bench.py --selfcheck (VERDICT r5 task 5)
+_SELFCHECK_CHILD = """
+    import os, sys
+    sys.path.insert(0, %r)
+    os.environ["CARO_DIST_BACKEND"] = "gloo"
+    from caro_ai_amd import parallel
+    import bench
+    parallel.init()
+    rec = bench.run_selfcheck("cpu", engine=False)
+    print("rank", os.environ["RANK"], "checks", ",".join(rec["checks"]), flush=True)
+"""
+
+
+def test_selfcheck_passes_on_three_gloo_ranks():
+    r = _run_launcher(_SELFCHECK_CHILD % ROOT, 3, timeout=180)
+    assert r.returncode == 0, r.stderr
+    assert "RC 0" in r.stdout, (r.stdout, r.stderr)
+    lines = sorted(l for l in r.stdout.splitlines() if l.startswith("rank"))
+    assert len(lines) == 3 and all("payload_all_gather" in l and "broadcast_weights" in l and "allreduce_grads" in l for l in lines)
+
+
+@pytest.mark.parametrize("fault", ["identity", "header_all_gather", "payload_all_gather", "empty_flush", "gather_tuples",
+                                   "allreduce_float64", "allreduce_counts", "broadcast_weights", "allreduce_grads"])
+def test_selfcheck_failure_names_the_collective_and_ends_every_rank(fault):
+    """the failure path: the last rank's contribution to ONE check is sabotaged (CARO_SELFCHECK_FAULT); every rank must
+    leave with exit code 4 -- the launcher reports it -- and the failing check is named on stderr; the checks before it
+    have passed"""
+    r = _run_launcher(_SELFCHECK_CHILD % ROOT, 2, extra_env={"CARO_SELFCHECK_FAULT": fault}, timeout=180)
+    assert r.returncode == 0, r.stderr
+    assert "RC 4" in r.stdout, (r.stdout, r.stderr)
+    assert "selfcheck FAILED" in r.stderr and fault + ":" in r.stderr, r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("rank")]  # nobody got past the check

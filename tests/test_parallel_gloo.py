@@ -274,6 +274,15 @@ def _nccl_worker(port, q):
     got = [None]
     dist.all_gather_object(got, {"rank": 0, "device": "cuda:0", "value": 1.5})
     ok = ok and got == [{"rank": 0, "device": "cuda:0", "value": 1.5}] and dist.get_backend() == "nccl"
+    # bench.py --selfcheck: every check of the checklist, the collectives really issued on the RCCL group (force),
+    # incl. the 16-game engine whose gathered tuples must equal the same games played alone
+    rec = parallel.selfcheck("cuda:0", engine_check=parallel.engine_selfcheck("cuda:0"), force=True)
+    ok = ok and rec["checks"][-1] == "engine_tuples" and len(rec["checks"]) == 10 and rec["backend"] == "nccl"
+    try:
+        parallel.selfcheck("cuda:0", fault="payload_all_gather", force=True)
+        ok = False
+    except parallel.SelfcheckError as e:
+        ok = ok and e.check == "payload_all_gather"
     dist.barrier()
     torch.cuda.synchronize()
     q.put(bool(ok))
