@@ -1885,6 +1885,7 @@ struct caro_net {
   struct HeadRows { void* stream; float* feat; int32_t* rowl; int64_t rows; uint64_t used; } hrows[8];
   int n_hrows;
   uint64_t hrows_clock;  // launches through the table so far: `used` of a slot = the clock of its last launch (LRU)
+  int64_t hrows_evictions;  // times a slot of the table changed its stream (caro_net_stream_evictions)
   int device;
   unsigned long long* dbg_stamps;  // diagnostic (caro_net_debug_stamps): per-workgroup stamps of the slot launches too
 };
@@ -1945,6 +1946,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   n->wpT_dev = nullptr;
   n->n_hrows = 0;
   n->hrows_clock = 0;
+  n->hrows_evictions = 0;
   const size_t pad = (size_t)cnet::TPC * cnet::WCHUNK;  // k_net_forward reads one chunk past the last tap
   if (hipMalloc((void**)&n->dev, (n_floats + pad) * sizeof(float)) != hipSuccess) {
     delete n;
@@ -2011,6 +2013,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
 int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats) {
   if (!n || !ww_host) return nfail(CARO_E_INVAL, "null argument");
   if (n->kind != 0) return nfail(CARO_E_STATE, "not a conv net");
+  if (n->p.ww2) return nfail(CARO_E_STATE, "net is already in another arithmetic mode");
   const int64_t want = (int64_t)cnet::WTAPS * cnet::WCHUNK;
   if (n_floats != want) return nfail(CARO_E_INVAL, "transformed weight image has the wrong size");
   if (hipSetDevice(n->device) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
@@ -2128,6 +2131,8 @@ int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_flo
   return 0;
 }
 
+int64_t caro_net_stream_evictions(const caro_net* n) { return n ? n->hrows_evictions : 0; }
+
 void caro_net_destroy(caro_net* n) {
   if (!n) return;
   if (n->ww_dev) (void)hipFree(n->ww_dev);
@@ -2162,6 +2167,7 @@ int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro
   n->wpT_dev = nullptr;
   n->n_hrows = 0;
   n->hrows_clock = 0;
+  n->hrows_evictions = 0;
   n->p.H = H; n->p.W = W; n->p.HW = H * W; n->p.A = A; n->p.TB = 4;
   *out = n;
   return 0;
@@ -2195,12 +2201,17 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
           hr = &n0->hrows[0];
           for (int k = 1; k < 8; ++k)
             if (n0->hrows[k].used < hr->used) hr = &n0->hrows[k];
-          if (hr->feat) (void)hipFree(hr->feat);
-          if (hr->rowl) (void)hipFree(hr->rowl);
+          // The slot's buffers are KEPT and only re-keyed (they are re-allocated below if the new stream needs more
+          // rows): one device synchronisation -- launches of the old stream may still read them -- instead of a
+          // synchronising hipFree pair + two hipMallocs.  A net used round-robin on more than 8 streams pays this on
+          // every launch: caro_net_stream_evictions() counts them.
+          if (hipDeviceSynchronize() != hipSuccess) return nfail(CARO_E_HIP, "hipDeviceSynchronize failed");
+          n0->hrows_evictions += 1;
+          hr->stream = stream;
         } else {
           hr = &n0->hrows[n0->n_hrows++];
+          hr->stream = stream; hr->feat = nullptr; hr->rowl = nullptr; hr->rows = 0;
         }
-        hr->stream = stream; hr->feat = nullptr; hr->rowl = nullptr; hr->rows = 0;
       }
       hr->used = ++n0->hrows_clock;
       if (hr->rows < need) {

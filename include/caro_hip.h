@@ -276,6 +276,9 @@ int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats
 int caro_net_winograd2d_size(void);
 int caro_net_winograd2d_supported(int H, int W);
 int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_floats);
+/* how often a slot of that (handle, stream) table had to change its stream: 0 while a handle serves at most 8 streams;
+ * every eviction costs a device synchronisation (the slot's rows are re-used, not re-allocated) */
+int64_t caro_net_stream_evictions(const caro_net* n);
 void caro_net_destroy(caro_net* n);
 int caro_net_boards_per_workgroup(const caro_net* n);
 /* rows [row0, row0 + L) of planes_dev f32[max_rows,2,H,W] -> probs_dev f32[.,A] (softmaxed), values_dev f32[.]

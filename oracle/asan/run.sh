@@ -10,6 +10,7 @@ ASAN_SO=$(gcc -print-file-name=libasan.so)
 UBSAN_SO=$(gcc -print-file-name=libubsan.so)
 export LD_PRELOAD="$ASAN_SO:$UBSAN_SO"
 export ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:allocator_may_return_null=1"
+export CARO_UNDER_ASAN=1  # (tests that shorten themselves under the sanitizers look at this)
 export UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1"
 # CARO_ASAN_K narrows the selection further (tests/test_sanitizers.py runs the search / rules part only)
 K="not test_library_exports and not test_config_struct and not test_engine_fails_loudly and not test_winograd2d_predicate and not test_hot_kernels and not test_net_kernel_touches_m0"

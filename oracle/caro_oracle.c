@@ -7,8 +7,10 @@
  * may load it.  Nothing under caro_ai_amd/ links, imports or calls it.
  *
  * Parity status: PINNED.  tests/test_oracle_golden.py checks this file against
- * (a) the reference's own known-answer tests restated in tests/golden/
- * known_answers.json, and (b) vectors recorded by running the reference itself
+ * (a) the reference's own known-answer tests restated as data inside that test
+ * file (the numbers of lib/test_mcts.py:25-38, lib/game/connect_four/
+ * test_connect_four.py:28-191, lib/game/tictactoe/test_tictactoe.py:12-144),
+ * and (b) vectors recorded by running the reference itself
  * in the build container (tests/golden/make_golden.py, outputs committed under
  * tests/golden/).
  *

@@ -320,4 +320,11 @@ def test_large_board_net_serves_more_streams_than_it_has_slots():
             p, v = hn(x)
         st.synchronize()
         assert torch.equal(p, p0) and torch.equal(v, v0)
+    # 1 default stream + 12 + 3 revisits on 8 slots: every launch beyond the eighth stream re-keyed a slot (ADVICE r5:
+    # counted, and the slot's rows are re-used -- one device synchronisation, no free / malloc pair)
+    assert hn.L.caro_net_stream_evictions(hn.h) == 1 + 12 + 3 - 8
+    # the two Winograd forms of a net exclude each other, whichever comes first
+    from caro_ai_amd.net_hip import pack_net_w
+    ww = pack_net_w(net)
+    assert hn.L.caro_net_enable_winograd(hn.h, ww.ctypes.data, ww.size) == -71
     hn.close()

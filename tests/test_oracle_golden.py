@@ -4,6 +4,7 @@
 CPU only.  These tests are what allows the GPU parity tests to trust the oracle.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -440,7 +441,10 @@ def test_arena_32_games_vs_reference(name):
     assert len(d["games"]) == 16
     res = []
     nets = None
-    for g in d["games"]:
+    # under the CPU sanitizers (oracle/asan/run.sh; tests/test_sanitizers.py) the first two games of each set keep the
+    # two-store / two-net paths of the oracle instrumented without the minutes all 32 take there
+    games = d["games"][:2] if os.environ.get("CARO_UNDER_ASAN") else d["games"]
+    for g in games:
         assert g["steps_before_tau_0"] == 0 and g["n_stores"] == 2 and g["first_player"] == g["uid"] & 1
         o = make_oracle(d, 2)
         if nets is None:
@@ -455,7 +459,8 @@ def test_arena_32_games_vs_reference(name):
             n = g["trace"][ply]["N"]
             assert g["pi"][ply].index(1.0) == n.index(max(n)) and sum(g["pi"][ply]) == 1.0
         res.append(r["result"])
-    assert {"wins": res.count(1), "losses": res.count(-1), "draws": res.count(0)} == d["tally"]
+    if len(games) == 16:
+        assert {"wins": res.count(1), "losses": res.count(-1), "draws": res.count(0)} == d["tally"]
 
 
 def test_reference_callers_themselves_produce_the_round4_fixtures():
