@@ -456,7 +456,8 @@ class Leg:
             levels_per_launch = delta["levels"] / n_launches
             achieved = levels_per_launch * bytes_per_level / avg_s / 1e9
             fused = prof.get("compact", (0, 0))[1] == 0
-            tname = ("k_tree_stag" if self.stagger else "k_tree") if fused else "k_select"
+            lpd = 8 if A == 7 else 16 if A <= 16 else 32 if A <= 32 else 64
+            tname = ("k_tree_stag" if self.stagger else "k_tree_mw" if B * lpd > 64 else "k_tree") if fused else "k_select"
             others = {k: (max(v[0] * 1e3 / v[1] - gap_s * 1e6, 0.0) if v[1] else None) for k, v in prof.items()
                       if k not in ("select", "net", "null1", "null2")}
             roofline_tree = {"bound": "hbm", "kernel": tname, "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -72,9 +72,11 @@ _SIGNATURES = {
     "caro_stream_create_partition": (C.c_int, [C.c_int, C.c_int, C.c_int, _P]),
     "caro_stream_destroy": (C.c_int, [_P]),
     "caro_search_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "caro_search_move": (C.c_int, [_P, _P, _P, C.c_int, C.c_int] + [_P] * 10),
     "caro_net_forward_pair": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "caro_net_forward_pair_at": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P]),
     "caro_net_forward_slots": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "caro_net_forward_slot_list": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "caro_net_create_hash": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, _P]),
     "caro_net_forward_stamped": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P]),
     "caro_net_debug_stamps": (C.c_int, [_P, _P]),

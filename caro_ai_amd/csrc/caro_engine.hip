@@ -99,6 +99,8 @@ struct View {
   int32_t* g_tree;
   int32_t* g_class;
   int32_t* g_pack;      // fused form: unique-leaf count | net class << 8 (what the net kernel's row map reads)
+  int32_t* slot_list;   // [2][G * maxB] multi-wave fused form: the slot rows of the launch's leaves per net class, in the
+                        // order the blocks got there (caro_net_forward_slot_list)
   int32_t* leaf_count;  // [4]: L0, L1, batch of the pending minibatch, -
   unsigned long long* counters;  // [G][C_N] per-game tallies (no atomics on the hot path), summed on read
   unsigned long long* counters_sum;  // [C_N]
@@ -305,16 +307,124 @@ __device__ __forceinline__ uint32_t orderable(float f) {
   return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
 }
 
+// The gammas of ONE Dirichlet row by the 64 lanes of a wavefront (the geometries with several actions per lane: one
+// wave = one descent = one row), same values as caro_gamma_small action by action.  Three things cost the plain form
+// (every lane calls caro_gamma_small for its APL actions in turn) most of its time, all of them SIMT effects:
+//   * the rejection loop of an action runs until the last of the 64 lanes has accepted (3-4 rounds against 1.3 on
+//     average), for each of the APL actions anew;
+//   * the full acceptance test (two caro_log) runs for the whole wave whenever ONE lane's candidate misses the squeeze --
+//     8 % of the candidates, i.e. nearly every round;
+//   * the U^(1/alpha) boost (a log, a division, an exp) sits inside that loop.
+// Here the row's actions are a POOL: a lane without work takes the next action not handed out yet, makes candidates for
+// it (the action's own draws j = 0, 1, 2, ... in order: a candidate is a pure function of (key, action, j)), and puts the
+// accepted (v, j) into the row's LDS mailbox; lanes whose candidate misses the squeeze WAIT with it until a dozen have
+// gathered (or nothing else is left to do) and take the full test together.  The wave then runs ~ (A x 1.4 / 64 + a short
+// tail) rounds of candidates, 2-3 full tests, and the boosts as straight-line code per lane afterwards.
+// mail_v / mail_k: AP entries of LDS owned by this wave: the accepted v of every action and the key of the draw that
+// follows its last candidate (the boost's uniform).
+template <int APL>
+__device__ __forceinline__ void gamma_row_pool(uint64_t key, int lane, int A, double alpha, double* mail_v,
+                                               uint64_t* mail_k, double* g) {
+  constexpr uint64_t KA = 0x9E3779B97F4A7C15ULL, KJ = 0xD1B54A32D192ED03ULL;
+  constexpr int FULL_BATCH = 12;
+  const double d = (alpha + 1.0) - 1.0 / 3.0;
+  const double c = 1.0 / caro_sqrt(9.0 * d);
+  int next = 0, remaining = A;  // uniform: first action not handed out yet, actions without a result
+  int a = -1;                   // this lane's action (-1: none)
+  uint32_t j = 0;
+  uint64_t ka = 0;
+  bool pend = false;            // a candidate waits for the full test
+  double px = 0.0, pt3 = 0.0, pu = 0.0;
+  while (remaining > 0) {
+    if (next < A) {  // hand out actions to the lanes without one, in lane order
+      const unsigned long long need = __ballot(a < 0);
+      const int rank = __popcll(need & ((1ull << lane) - 1ull));
+      if (a < 0 && next + rank < A) {
+        a = next + rank;
+        j = 0;
+        ka = caro_mix64(key + KA * (uint64_t)(a + 1));  // from here on ka = the action's key + KJ * j (64-bit multiplies
+      }                                                 // are four quarter-rate instructions each: added up instead)
+      next += __popcll(need);
+      next = next < A ? next : A;
+    }
+    bool acc = false;
+    double vacc = 1.0;  // (the draw bound was hit: v stays 1.0, as in caro_gamma_small)
+    if (a >= 0 && !pend) {
+      if (j + 4 <= CARO_NOISE_MAX_DRAWS) {
+        const double u1 = 2.0 * caro_u01(caro_mix64(ka)) - 1.0;
+        const double u2 = 2.0 * caro_u01(caro_mix64(ka + KJ)) - 1.0;
+        j += 2;
+        ka += 2ull * KJ;
+        const double s = u1 * u1 + u2 * u2;
+        if (s > 0.0 && s < 1.0) {
+          const double x = u1 * caro_sqrt((-2.0 * caro_log(s)) / s);
+          const double t = 1.0 + c * x;
+          if (t > 0.0) {
+            const double t3 = (t * t) * t;
+            const double u = caro_u01(caro_mix64(ka));
+            j += 1;
+            ka += KJ;
+            if (caro_squeeze_accepts(u, x)) {
+              acc = true;
+              vacc = t3;
+            } else {
+              pend = true;
+              px = x; pt3 = t3; pu = u;
+            }
+          }
+        }
+      } else {
+        acc = true;
+      }
+    }
+    const unsigned long long pm = __ballot(pend);
+    if (pm) {
+      const bool more = next < A || __ballot(a >= 0 && !pend && !acc) != 0ull;  // candidates still to be made elsewhere
+      if (__popcll(pm) >= FULL_BATCH || !more) {
+        if (pend) {
+          if (caro_log(pu) < (0.5 * px) * px + d * ((1.0 - pt3) + caro_log(pt3))) {
+            acc = true;
+            vacc = pt3;
+          }
+          pend = false;
+        }
+      }
+    }
+    if (acc) {
+      mail_v[a] = vacc;
+      mail_k[a] = ka;  // = the action's key + KJ * j: the key of draw j, which the boost takes
+      a = -1;
+    }
+    remaining -= __popcll(__ballot(acc));
+  }
+  asm volatile("" ::: "memory");  // one wave: its LDS accesses complete in program order
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < APL; ++i) {
+    const int ai = lane * APL + i;
+    double gi = 0.0;
+    if (ai < A) {
+      const double ub = caro_u01(caro_mix64(mail_k[ai]));
+      gi = (d * mail_v[ai]) * caro_exp(caro_log(ub) / alpha);
+    }
+    g[i] = gi;
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();  // the mailbox may be written again (the wave's next row)
+}
+
 // One Dirichlet row of caro_noise.h for the LPD lanes of a descent group:
 // lane l holds actions l*APL .. l*APL+APL-1.  Per-lane adjacent tree, then the
 // xor butterfly: the balanced adjacent-pair tree sum of the spec.
+// `mail`: LDS of the calling wave for gamma_row_pool (APL > 1 only): AP doubles followed by AP uint64
 template <int LPD, int APL>
-__device__ __forceinline__ void noise_group(uint64_t key, int l, int A, double alpha, double* out) {
+__device__ __forceinline__ void noise_group(uint64_t key, int l, int A, double alpha, double* out, double* mail = nullptr) {
   double g[APL];
-#pragma unroll
-  for (int j = 0; j < APL; ++j) {
-    const int a = l * APL + j;
-    g[j] = a < A ? caro_gamma_small(key, (uint32_t)a, alpha) : 0.0;
+  if constexpr (APL == 1) {
+    g[0] = l < A ? caro_gamma_small(key, (uint32_t)l, alpha) : 0.0;
+  } else {
+    static_assert(LPD == 64, "several actions per lane: one wavefront per row");
+    gamma_row_pool<APL>(key, l, A, alpha, mail, reinterpret_cast<uint64_t*>(mail + LPD * APL), g);
   }
   double s;
   if constexpr (APL == 1) s = g[0];
@@ -522,6 +632,14 @@ __device__ __forceinline__ bool descend_level(const View& v, Descent<GEO>& d, in
 // on block arrival order.  (k_encode produces DENSE rows for the step-wise form instead.)
 // `helper_nz` (fused kernels): the block's noise wave writes this minibatch's Dirichlet rows to LDS ([B][AP] doubles
 // at helper_nz, then the flag behind them); the tree wave picks them up here instead of generating them.
+// dynamic LDS of the kernels that generate Dirichlet rows in line on a geometry with several actions per lane: one
+// mailbox of gamma_row_pool per wavefront (descent)
+extern __shared__ double caro_dyn_lds[];
+template <class GEO>
+static inline size_t mail_bytes(int B) {
+  return GEO::APL > 1 ? (size_t)((B * GEO::LPD + 63) / 64) * (2 * GEO::AP) * sizeof(double) : 0;
+}
+
 template <class GEO, bool ONE = false>
 __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& gr, int B, int mb_index,
                                             const double* __restrict__ noise, int32_t* __restrict__ rows,
@@ -590,7 +708,9 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
     for (int j = 0; j < APL; ++j) nz[j] = helper_nz[b * AP + l * APL + j];
   } else {
     const uint64_t key = caro_noise_key(v.seed, gr.uid, (uint32_t)gr.ply, (uint32_t)(mb_index * B + b));
-    noise_group<LPD, APL>(key, l, A, v.alpha, nz);
+    // (several actions per lane: the row's gammas go through an LDS mailbox of the descent's wave, gamma_row_pool --
+    // dynamic LDS, mail_bytes<GEO>(B) at the launch)
+    noise_group<LPD, APL>(key, l, A, v.alpha, nz, APL > 1 ? caro_dyn_lds + (tid >> 6) * (2 * AP) : nullptr);
   }
   if (v.dbg) st_noise = __builtin_amdgcn_s_memtime();
 
@@ -770,9 +890,15 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
       atomicAdd(ctr + C_DROPPED, (unsigned long long)__popcll(m_drop));
       if (rows) {
         const int cls = v.n_nets == 2 ? player0 : 0;
-        if (nleaf) atomicAdd(rows + cls, nleaf);
         v.g_off[g] = g * B;
         v.g_pack[g] = nleaf | (cls << 8);
+        if (nleaf) {
+          // (this form keeps the add's return value: where the game's rows stand in the launch's list of leaves -- any
+          // order serves the one-board-per-workgroup net kernel, caro_net_forward_slot_list)
+          const int at = atomicAdd(rows + cls, nleaf);
+          int32_t* sl = v.slot_list + (size_t)cls * v.G * B;
+          for (int j = 0; j < nleaf; ++j) sl[at + j] = g * B + j;
+        }
       }
     }
   }
@@ -1016,45 +1142,51 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
   }
   block_sync<ONE>();
   CARO_XS(1)  // the preloaded round has arrived, leaves published
-  const bool single_wave = ONE || blockDim.x == 64;
+  // the block's first wavefront as a whole (the sections below that talk across lanes by readlane / ballot); the other
+  // wavefronts of a multi-wave block skip those sections (no barrier sits inside them)
+  const bool whole_wave = ONE || blockDim.x >= 64;
+  const bool wave0 = whole_wave && lane < 64;
   if (!overflow) {
     // _create_node.  The reference inserts the leaves one after another (first-seen order): a leaf whose home slot is
     // free and not taken by an earlier leaf of this minibatch lands in its home slot, anything else walks the probe
-    // sequence.  Slot choice = sequential insertion.  The common case -- every leaf meets a free home slot of its own
-    // -- needs no sequence at all: each leaf's lane writes its key.  Otherwise lane 0 places them one by one.
-    bool all_fast = false;
-    if (single_wave) {
+    // sequence.  Which slot a node gets carries no meaning (node id = slot; every lookup walks the probe sequence from
+    // the home slot to the first empty one), so: the leaves that meet a free home slot of their own -- nearly all --
+    // are placed by their own lanes at once, and lane 0 then inserts the few others one by one behind them (a
+    // wavefront's accesses to one address stay in order: its probes see the keys just written).
+    if (wave0) {
       bool clash = false;
       for (int bb = 0; bb < B; ++bb) {  // bb is uniform: readlane, not a trip through the LDS crossbar
         const int ob = __builtin_amdgcn_readlane((int)is_leaf, bb);
         const uint32_t oh = (uint32_t)__builtin_amdgcn_readlane((int)(my_home & 0x7fffffffu), bb);
         clash = clash || (bb < lane && ob && oh == (my_home & 0x7fffffffu));
       }
-      all_fast = __ballot(is_leaf && ((my_home >> 31) == 0u || clash)) == 0ull;
-    }
-    if (all_fast) {
-      if (is_leaf) {
+      const bool fast = is_leaf && (my_home >> 31) != 0u && !clash;
+      if (fast) {
         uint64_t* k = v.node_key + (tb + (my_home & 0x7fffffffu)) * KW;
 #pragma unroll
         for (int w = KW - 1; w >= 0; --w) k[w] = brd.w[w];
         s_node[lane] = (int)(my_home & 0x7fffffffu);
       }
-    } else if (lane == 0) {
+      const unsigned long long slow = __ballot(is_leaf && !fast);
+      if (slow) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0)
+          for (unsigned long long m = slow; m; m &= m - 1ull) {
+            const int b = __ffsll(m) - 1;
+            Board lb;
+#pragma unroll
+            for (int w = 0; w < KW; ++w) lb.w[w] = s_brd[b][w];
+            s_node[b] = insert_key<R>(v, t, lb);
+          }
+      }
+    } else if (!whole_wave && lane == 0) {  // a block of less than one wavefront (tiny boards, small batches)
       for (int b = 0; b < B; ++b) {
         if (s_node[b] == -2) continue;
-        bool fast = s_free[b] != 0;
-        for (int bb = 0; bb < b && fast; ++bb) fast = !(s_node[bb] >= 0 && (uint32_t)s_node[bb] == s_home[b]);
         Board lb;
 #pragma unroll
         for (int w = 0; w < KW; ++w) lb.w[w] = s_brd[b][w];
-        if (fast) {
-          uint64_t* k = v.node_key + (tb + s_home[b]) * KW;
-#pragma unroll
-          for (int w = KW - 1; w >= 0; --w) k[w] = lb.w[w];
-          s_node[b] = (int)s_home[b];
-        } else {
-          s_node[b] = insert_key<R>(v, t, lb);
-        }
+        s_node[b] = insert_key<R>(v, t, lb);
       }
     }
     if (lane == 0) {
@@ -1152,7 +1284,8 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
   CARO_XS(5)  // rows of the new nodes written
   // ---- the owners' writes
   const int n = total;
-  if (single_wave && n <= 128) {
+  if (whole_wave && n <= 128) {
+    if (wave0) {
     // One wavefront, at most two entries per lane (j0 = lane, j1 = lane + 64).  The entries of one edge are found by
     // matching: the first entry not grouped yet is broadcast, a ballot marks its equals (bit = entry index), the lane
     // holding that first entry becomes the owner and keeps the two masks.  One round per DISTINCT edge, a few scalar
@@ -1218,6 +1351,7 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
       row1[4 * a1 + 1] = __float_as_uint(w);
       row1[4 * a1 + 2] = __float_as_uint(w / (float)cnt);
     }
+    }
   } else
   for (int j = lane; j < n; j += block_threads<ONE>()) {
     const int node = e_node[j], a = e_act[j];
@@ -1267,7 +1401,8 @@ __device__ __forceinline__ void noise_wave(const View& v, int B, int go, uint64_
   if (go) {
     double nz[APL];
     const uint64_t key = caro_noise_key(v.seed, uid, ply, (uint32_t)(mb * B + b));
-    noise_group<LPD, APL>(key, l, v.A, v.alpha, nz);
+    __shared__ double s_mail[APL > 1 ? 2 * AP : 1];  // (several actions per lane: LPD = 64, this wave is one row)
+    noise_group<LPD, APL>(key, l, v.A, v.alpha, nz, s_mail);
 #pragma unroll
     for (int j = 0; j < APL; ++j) s_nz[b * AP + l * APL + j] = nz[j];
   }
@@ -1566,13 +1701,11 @@ __global__ void k_step(View v, const double* __restrict__ uniforms, int32_t* __r
 // old table is cleared on the way, and the tables swap roles.  Result-neutral: the reference keeps the dead
 // nodes in its dict but can never reach them.  n_created (= len(MCTS)) keeps counting every node ever made.
 template <class GEO>
-__global__ void k_evict(View v) {
+__device__ __forceinline__ void evict_body(const View& v, int g, const typename GEO::R::Board& root, int done) {
   using R = typename GEO::R;
   using Board = typename R::Board;
   constexpr int AP = GEO::AP, KW = GEO::KW;
-  const int g = blockIdx.x;
   __shared__ int s_cnt;
-  const Board root = load_board<R>(v.root + (size_t)g * KW);
   for (int st = 0; st < v.n_stores; ++st) {
     const int t = g * v.n_stores + st;
     const int live = v.tbl[t];
@@ -1588,7 +1721,7 @@ __global__ void k_evict(View v) {
       if (k[0] == EMPTY_KEY) continue;
       const Board b = load_board<R>(k);
       k[0] = EMPTY_KEY;  // the old table ends up empty
-      if (!v.done[g] && R::contains(v.gp, b, root)) {
+      if (!done && R::contains(v.gp, b, root)) {
         uint32_t j = home_slot<R>(v, t, b);
         for (int it = 0; it < v.hcap; ++it) {  // claim a slot: all inserted keys are distinct
           unsigned long long* w0 = (unsigned long long*)(nkeys + (size_t)j * KW);
@@ -1609,6 +1742,71 @@ __global__ void k_evict(View v) {
       v.tbl[t] = 1 - live;
     }
     __syncthreads();
+  }
+}
+
+template <class GEO>
+__global__ void k_evict(View v) {
+  const int g = blockIdx.x;
+  evict_body<GEO>(v, g, load_board<typename GEO::R>(v.root + (size_t)g * GEO::KW), v.done[g]);
+}
+
+// The fusion of k_tree for geometries with SEVERAL wavefronts per game (batch x lanes per descent a multiple of 64
+// above 64: 15 x 15 with 8 descents = 8 waves): one block = one game does expand + backup of minibatch i - 1 (the first
+// wavefront talks across its lanes, the whole block writes the new nodes' rows), a block barrier, the descents of
+// minibatch i (one wavefront each) and the NN planes of the unique leaves into the game's slot rows: two launches per
+// minibatch (this + the net) instead of four, same protocol as k_tree (+ the list of the leaves' slot rows, slot_list).
+// do_step (the closing launch of a move, do_select = 0): the ply itself (step_body = k_step's code, lib/utils.py:80-99)
+// and, with eviction on, k_evict's work for this game follow the last backup in the same block -- one launch per move
+// instead of three.
+template <class GEO>
+__global__ void k_tree_mw(View v, int B, int mb_index, const double* __restrict__ noise, const float* __restrict__ probs,
+                          const float* __restrict__ values, float* __restrict__ planes, uint64_t* __restrict__ leaf_keys,
+                          int32_t* __restrict__ rows_cur, int32_t* __restrict__ rows_next, int do_expand, int do_select,
+                          int do_step, const double* __restrict__ uniforms, int32_t* __restrict__ actions,
+                          int32_t* __restrict__ done_out, int32_t* __restrict__ result_out) {
+  constexpr int AP = GEO::AP;
+  const int g = blockIdx.x;
+  if (g == 0 && threadIdx.x == 0) {
+    rows_next[0] = 0;
+    rows_next[1] = 0;
+    rows_next[2] = B;
+    rows_cur[2] = B;
+  }
+  const unsigned long long t0 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  GameRegs<GEO> gr = load_game<GEO>(v, g);
+  const ExpandPre<GEO> pre = expand_preload<GEO, false>(v, g, B, g * B, probs, values);
+  if (do_expand) {
+    expand_body<GEO, false>(v, gr, B, pre, g * B, probs);
+    __syncthreads();  // the block's own tree updates are visible to its descents (and to the ply)
+  }
+  const unsigned long long t1 = v.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  // (Generating the descents' Dirichlet rows BESIDE the first wavefront's expand + backup -- they do not depend on the
+  // tree -- was built and measured: 113 us per launch, and 120 us with the first wavefront's row in front of the barrier as
+  // well, against 99 us like this.  The kernel is bound by the arithmetic of those rows; with two blocks per compute unit
+  // one block's latency phase (expand + backup, the descents) is what the other block's arithmetic runs under, and rows
+  // generated at the top make both blocks compute at the same time.  NOTES, round 6.)
+  if (do_select) select_body<GEO, false>(v, gr, B, mb_index, noise, rows_cur, planes, leaf_keys);
+  if (do_step) {
+    __shared__ double s_pi[AP];
+    __shared__ int s_n[AP];
+    if (gr.done) {
+      if (threadIdx.x == 0) {
+        if (actions) actions[g] = -1;
+        if (done_out) done_out[g] = 1;
+        if (result_out) result_out[g] = v.result[g];
+      }
+    } else {
+      step_body<GEO>(v, g, gr, uniforms, s_pi, s_n, actions, done_out, result_out);
+    }
+    if (v.etab == 2) {
+      __syncthreads();
+      evict_body<GEO>(v, g, gr.root, gr.done);
+    }
+  }
+  if (v.dbg && threadIdx.x == 0) {
+    v.dbg[(size_t)g * 8 + (do_select ? 6 : 5)] = t1 - t0;
+    if (do_select) v.dbg[(size_t)g * 8 + 7] = __builtin_amdgcn_s_memtime() - t0;
   }
 }
 
@@ -2180,7 +2378,8 @@ __global__ void k_noise(uint64_t seed, long long M, int A, double alpha, const u
   const long long mm = m < M ? m : M - 1;  // keep whole groups active for the shuffles
   const uint64_t key = caro_noise_key(seed, uid[mm], ply[mm], sim[mm]);
   double nz[APL];
-  noise_group<LPD, APL>(key, l, A, alpha, nz);
+  __shared__ double s_mail[APL > 1 ? 2 * GEO::AP : 1];  // one wave per block
+  noise_group<LPD, APL>(key, l, A, alpha, nz, s_mail);
   if (m < M)
     for (int j = 0; j < APL; ++j) {
       const int a = l * APL + j;
@@ -2482,6 +2681,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
   DA(v.d_rec, G * v.maxB);
   DA(v.d_key, G * v.maxB * KW);
   DA(v.g_nleaf, G); DA(v.g_off, G); DA(v.g_tree, G); DA(v.g_class, G); DA(v.g_pack, G);
+  DA(v.slot_list, 2 * G * v.maxB);
   DA(v.leaf_count, 4);
   DA(v.counters, G * C_N);
   DA(v.counters_sum, C_N);
@@ -2569,8 +2769,8 @@ int caro_select(caro_engine* h, int batch, int mb_index, const double* noise, fl
   const int lpd = variant_lpd(h->var);
   hipStream_t st = (hipStream_t)stream;
   const int p0 = prof_begin(h, PK_SELECT, st);
-  DISPATCH(h->var, hipLaunchKernelGGL(k_select<GEO>, dim3(h->v.G), dim3(batch * lpd), 0, st, h->v, batch, mb_index,
-                                      noise));
+  DISPATCH(h->var, hipLaunchKernelGGL(k_select<GEO>, dim3(h->v.G), dim3(batch * lpd), mail_bytes<GEO>(batch), st, h->v,
+                                      batch, mb_index, noise));
   prof_end(h, p0, st);
   const int p1 = prof_begin(h, PK_COMPACT, st);
   DISPATCH(h->var, hipLaunchKernelGGL(k_encode<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, planes, leaf_keys));
@@ -2603,8 +2803,9 @@ int caro_expand_backup(caro_engine* h, const float* probs, const float* values, 
 
 // MCTS.search_batch (lib/mcts.py:162-176) for every game with the fused HIP net(s): `searches` minibatches of
 // select -> net forward (leaf count read on device) -> expand+backup, enqueued back to back from C.
-int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch, const double* noise,
-                      float* planes, uint64_t* leaf_keys, float* probs, float* values, void* stream) {
+static int search_batch_impl(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch, const double* noise,
+                             float* planes, uint64_t* leaf_keys, float* probs, float* values, void* stream, int with_step,
+                             const double* uniforms, int32_t* actions, int32_t* done, int32_t* result) {
   if (!h || !net0 || !planes || !probs || !values) return fail(CARO_E_INVAL, "null argument");
   if (h->v.n_nets == 2 && !net1) return fail(CARO_E_INVAL, "engine has two nets, net1 is null");
   if (searches < 1) return fail(CARO_E_INVAL, "searches must be >= 1");
@@ -2614,8 +2815,11 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
   if (h->v.stag_S) return fail(CARO_E_STATE, "caro_search_batch: the engine runs in staggered mode (per-game clocks, pending minibatches, parked games); use caro_search_staggered / caro_drain_parked_begin");
   if (h->select_pending) return fail(CARO_E_STATE, "caro_search_batch with a pending caro_select");
   hipStream_t st = (hipStream_t)stream;
-  // one 64-lane wavefront per game: the fused tree kernel (k_tree), two launches per minibatch
-  const bool fused = h->fused_ok && batch * variant_lpd(h->var) == 64;
+  // one 64-lane wavefront per game: the fused tree kernel (k_tree), two launches per minibatch; several whole
+  // wavefronts per game: the same fusion as k_tree_mw
+  const int bthreads = batch * variant_lpd(h->var);
+  const bool fused1 = h->fused_ok && bthreads == 64;
+  const bool fused = h->fused_ok && bthreads >= 64 && bthreads % 64 == 0;
   for (int mb = 0; mb < searches; ++mb) {
     // HIP-event timing is SAMPLED: an event pair per kernel costs ~8 % of the step.  Every 12th minibatch of a
     // counter that runs across moves: 12 is coprime to the usual 25 / 20 / 100 searches per move, so every
@@ -2629,9 +2833,17 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
       h->rows_par ^= 1;
       counts = cur;
       const int p1 = prof_begin(h, PK_SELECT, st);
-      DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, mb,
-                                          noise ? noise + (size_t)mb * noise_stride : nullptr, probs, values, planes,
-                                          leaf_keys, cur, nxt, mb > 0 ? 1 : 0, 1));
+      if (fused1) {
+        DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, mb,
+                                            noise ? noise + (size_t)mb * noise_stride : nullptr, probs, values, planes,
+                                            leaf_keys, cur, nxt, mb > 0 ? 1 : 0, 1));
+      } else {
+        DISPATCH(h->var, hipLaunchKernelGGL(k_tree_mw<GEO>, dim3(h->v.G), dim3(bthreads), mail_bytes<GEO>(batch), st,
+                                            h->v, batch, mb, noise ? noise + (size_t)mb * noise_stride : nullptr, probs,
+                                            values, planes, leaf_keys, cur, nxt, mb > 0 ? 1 : 0, 1, 0,
+                                            (const double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                                            (int32_t*)nullptr));
+      }
       prof_end(h, p1, st);
       if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree launch failed"); }
     } else {
@@ -2639,9 +2851,9 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
       if (rc) { h->prof_gate = 1; return rc; }
     }
     const int p0 = prof_begin(h, PK_NET, st);
-    if (fused)
-      rc = caro_net_forward_slots(net0, h->v.n_nets == 2 ? net1 : nullptr, planes, counts, h->v.g_pack, h->v.G, batch,
-                                  probs, values, stream);
+    if (fused)  // (the multi-wave kernel also lists its leaves' slot rows: one-board-per-workgroup net forms take them)
+      rc = caro_net_forward_slot_list(net0, h->v.n_nets == 2 ? net1 : nullptr, planes, counts, h->v.g_pack,
+                                      fused1 ? nullptr : h->v.slot_list, h->v.G, batch, probs, values, stream);
     else if (h->v.n_nets == 2)
       rc = caro_net_forward_pair_at(net0, net1, planes, counts, -1, max_rows, probs, values, stream);
     else rc = caro_net_forward(net0, planes, counts, 0, max_rows, probs, values, stream);
@@ -2655,13 +2867,36 @@ int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int search
     int32_t* nxt = h->rows + 4 * (h->rows_par ^ 1);
     h->rows_par ^= 1;
     const int p1 = prof_begin(h, PK_EXPAND, st);
-    DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, searches,
-                                        (const double*)nullptr, probs, values, planes, leaf_keys, cur, nxt, 1, 0));
+    if (fused1) {
+      DISPATCH(h->var, hipLaunchKernelGGL(k_tree<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, searches,
+                                          (const double*)nullptr, probs, values, planes, leaf_keys, cur, nxt, 1, 0));
+    } else {
+      // several wavefronts per game: the ply and the eviction of a caro_search_move ride in this closing launch
+      DISPATCH(h->var, hipLaunchKernelGGL(k_tree_mw<GEO>, dim3(h->v.G), dim3(bthreads), 0, st, h->v, batch, searches,
+                                          (const double*)nullptr, probs, values, planes, leaf_keys, cur, nxt, 1, 0,
+                                          with_step ? 1 : 0, uniforms, actions, done, result));
+      if (with_step) with_step = 0;  // done
+    }
     prof_end(h, p1, st);
     if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree launch failed"); }
   }
   h->prof_gate = 1;
-  return 0;
+  return with_step ? caro_step(h, uniforms, actions, done, result, stream) : 0;
+}
+
+int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch, const double* noise,
+                      float* planes, uint64_t* leaf_keys, float* probs, float* values, void* stream) {
+  return search_batch_impl(h, net0, net1, searches, batch, noise, planes, leaf_keys, probs, values, stream, 0, nullptr,
+                           nullptr, nullptr, nullptr);
+}
+
+// search_batch + the ply: caro_search_batch followed by caro_step, with the ply (and the eviction) inside the search's
+// closing launch where the geometry has the multi-wave fused kernel
+int caro_search_move(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch, const double* noise,
+                     const double* uniforms, float* planes, uint64_t* leaf_keys, float* probs, float* values,
+                     int32_t* actions, int32_t* done, int32_t* result, void* stream) {
+  return search_batch_impl(h, net0, net1, searches, batch, noise, planes, leaf_keys, probs, values, stream, 1, uniforms,
+                           actions, done, result);
 }
 
 // ---- staggered mode (see k_tree_stag)

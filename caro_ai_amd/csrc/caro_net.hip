@@ -1572,13 +1572,17 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w2(NetParams p0, NetParam
                                                             float* __restrict__ probs, float* __restrict__ values,
                                                             unsigned long long* __restrict__ stamps,
                                                             const int32_t* __restrict__ gpack, int gG, int gB,
-                                                            float* __restrict__ featbuf, int32_t* __restrict__ rowlist) {
+                                                            float* __restrict__ featbuf, int32_t* __restrict__ rowlist,
+                                                            const int32_t* __restrict__ slist) {
   __shared__ __attribute__((aligned(256))) float lds[LDS_FLOATS];  // trunk_w2d XORs granule bits into LDS addresses
   float* act = lds;
   float* wbuf = lds + ACT;
-  // slot form: this thread's share of the games' leaf counts is requested beside the launch's totals (tile_rows_pre)
-  const int gcpt = gpack ? (gG + NT - 1) / NT : 0;
-  const bool gpre = gpack && gcpt <= GP_PRE;
+  // slot form: this thread's share of the games' leaf counts is requested beside the launch's totals (tile_rows_pre).
+  // slist (caro_net_forward_slot_list): the slot row of every dense board comes from the producer's list instead -- one
+  // board per workgroup leaves no tile to fill, so no workgroup needs the prefix sum over the G leaf counts (1.2 us of
+  // each workgroup: 37 us of a 7 600-board launch), and which dense index a board got does not touch its arithmetic
+  const int gcpt = gpack && !slist ? (gG + NT - 1) / NT : 0;
+  const bool gpre = gpack && !slist && gcpt <= GP_PRE;
   int gv[GP_PRE];
 #pragma unroll
   for (int u = 0; u < GP_PRE; ++u) {
@@ -1599,6 +1603,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w2(NetParams p0, NetParam
     board0 = second ? (int)blockIdx.x - L0 : (int)blockIdx.x;
   }
   if (board0 >= L) return;
+  const int listed = slist ? slist[(second ? gG * gB : 0) + board0] : 0;  // (requested here, used behind conv_in's weights)
   const NetParams p = second ? p1 : p0;
   unsigned long long t_c0 = 0, t_r0 = 0;  // diagnostic only (stamps == nullptr in every product launch)
   if (stamps) {
@@ -1624,7 +1629,10 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_w2(NetParams p0, NetParam
   static_assert(2 * (WCH / 4 / NT) == 8, "s_waitcnt vmcnt(8) below counts 2 chunks x WCH / 4 / NT transfers per thread");
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // conv_in's weights have arrived; the 2 x 4 chunk transfers may be on their way
   int* smap = reinterpret_cast<int*>(win + 1536);
-  if (gpre) tile_rows_pre(gv, gcpt, gmine, gB, second ? 1 : 0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
+  if (slist) {
+    if (tid == 0) smap[0] = listed;
+    __syncthreads();
+  } else if (gpre) tile_rows_pre(gv, gcpt, gmine, gB, second ? 1 : 0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
   else tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);
   conv_in_mfma<true>(p, planes, smap, act, win, R, tid);
   const int slot_v = tid < nb ? smap[tid] : 0;
@@ -2177,7 +2185,7 @@ int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro
 // gpack != null: slot rows (caro_net_forward_slots), otherwise dense rows.
 static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev, int which,
                       int row1, int64_t max_rows, float* probs_dev, float* values_dev, const int32_t* gpack, int G,
-                      int B, unsigned long long* stamps, void* stream) {
+                      int B, unsigned long long* stamps, void* stream, const int32_t* slist = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   if (n0->kind == 1) {
     const int64_t waves = gpack ? (int64_t)G * B : max_rows;
@@ -2225,7 +2233,7 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
       }
       hipLaunchKernelGGL(cnet::k_net_forward_w2, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B,
-                         hr->feat, hr->rowl);
+                         hr->feat, hr->rowl, slist);
       if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "net kernel launch failed");
       const unsigned hgrid = (unsigned)((max_rows + cnet::HB - 1) / cnet::HB) + (which == 2 ? 1u : 0u);
       hipLaunchKernelGGL(cnet::k_net_heads, dim3(hgrid), dim3(cnet::NT), 0, st, n0->p, n1->p, counts_dev, which, row1,
@@ -2288,6 +2296,24 @@ int caro_net_forward_slots(caro_net* n0, caro_net* n1, const float* planes_dev, 
     if (int rc = pair_ok(n0, n1)) return rc;
   return net_launch(n0, n1 ? n1 : n0, planes_dev, counts_dev, n1 ? 2 : 0, -1, (int64_t)n_games * batch, probs_dev,
                     values_dev, gpack_dev, n_games, batch, nullptr, stream);
+}
+
+/* caro_net_forward_slots with the dense order of the leaves GIVEN: slot_list_dev i32[2][n_games * batch], entry
+ * [c][i] = slot row of the i-th leaf of net class c, i < counts_dev[c], in ANY order (the fused multi-wave tree kernel
+ * appends each game's rows when the game's block gets there).  Used by the kernels that serve one board per workgroup
+ * (the 2-D Winograd form: a board's arithmetic does not depend on its dense index); the other forms ignore the list and
+ * keep the game-order map they compute from gpack_dev -- their tiles hold several boards, and which boards share a tile
+ * must stay a function of the games' states.  slot_list_dev == NULL: caro_net_forward_slots. */
+int caro_net_forward_slot_list(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
+                               const int32_t* gpack_dev, const int32_t* slot_list_dev, int n_games, int batch,
+                               float* probs_dev, float* values_dev, void* stream) {
+  if (!n0 || !planes_dev || !counts_dev || !gpack_dev || !probs_dev || !values_dev)
+    return nfail(CARO_E_INVAL, "null argument");
+  if (n_games < 1 || batch < 1 || batch > 255) return nfail(CARO_E_INVAL, "bad slot geometry");
+  if (n1)
+    if (int rc = pair_ok(n0, n1)) return rc;
+  return net_launch(n0, n1 ? n1 : n0, planes_dev, counts_dev, n1 ? 2 : 0, -1, (int64_t)n_games * batch, probs_dev,
+                    values_dev, gpack_dev, n_games, batch, nullptr, stream, n0->p.ww2 ? slot_list_dev : nullptr);
 }
 
 /* diagnostic: same launch, and per workgroup (total cycles, 100 MHz ticks, cycles at trunk start, at trunk end) into stamps_dev u64[4*grid] */

@@ -342,13 +342,26 @@ class SelfPlayEngine:
         self.drain_begin(recycle, cap)
         return self.drain_end()
 
+    def search_step(self, searches, batch):
+        """search() + step() (generated noise and move uniforms): one C call, caro_search_move, for a lock-step engine
+        with device-side evaluators -- where several wavefronts serve a game the ply and the eviction ride in the
+        search's closing launch"""
+        if self.async_net and not self.stagger:
+            nets = [e.h for e in self.evaluators] + [None]
+            _lib.check(self.L.caro_search_move(self.h, nets[0], nets[1], searches, batch, None, None, _ptr(self.planes),
+                                               _ptr(self.leaf_keys), _ptr(self._probs), _ptr(self._values), None, None,
+                                               None, self._stream()))
+            self.net_calls += searches * self.n_nets
+        else:
+            self.search(searches, batch)
+            self.step()
+
     def move(self, searches, batch, recycle=True):
         """One move of every game with the host loop software-pipelined: search + ply + the drain kernels of THIS
         move are enqueued, and only then the totals of the PREVIOUS move's drain are waited for -- while the GPU is
         busy with this move's search -- so nothing on the host sits between two moves on the GPU.  Returns the
         tuples of the previous move (None on the first call); flush() hands out the last ones."""
-        self.search(searches, batch)
-        self.step()
+        self.search_step(searches, batch)
         out = self.drain_end() if self._drain_open else None
         self.drain_begin(recycle)
         self._drain_open = True
@@ -524,8 +537,7 @@ class StreamedSelfPlay:
             with torch.cuda.stream(st):
                 if getattr(e, "_primed", False):
                     outs.append(e.drain(recycle=recycle))
-                e.search(searches, batch)
-                e.step()
+                e.search_step(searches, batch)
                 e._primed = True
         if not outs:
             return None

@@ -296,6 +296,16 @@ int caro_net_forward_slots(caro_net* n0, caro_net* n1, const float* planes_dev, 
                            const int32_t* gpack_dev, int n_games, int batch, float* probs_dev, float* values_dev,
                            void* stream);
 
+/* The same with the dense order of the leaves GIVEN by the producer: slot_list_dev i32[2][n_games * batch], entry
+ * [c][i] = slot row of the i-th leaf of net class c (i < counts_dev[c]), in any order -- the multi-wave fused tree kernel
+ * of caro_search_batch appends a game's rows when its block gets there.  Only the net forms that serve ONE board per
+ * workgroup use it (2-D Winograd, 12x12 .. 15x15: a board's arithmetic does not depend on its dense index, and no
+ * workgroup has to derive the map from gpack_dev any more); every other form ignores the list and keeps the game-order
+ * map, so which boards share a tile stays a function of the games' states.  slot_list_dev may be NULL. */
+int caro_net_forward_slot_list(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev,
+                               const int32_t* gpack_dev, const int32_t* slot_list_dev, int n_games, int batch,
+                               float* probs_dev, float* values_dev, void* stream);
+
 /* Table evaluator with the same launch interface as the conv net (leaf counts read on device, dense or slot
  * rows): an exact integer-hash "net" for checking the SEARCH bit for bit -- it stands where lib/mcts.py:212-218
  * calls the net.  With x = the 2*H*W input planes of a row, mix64 = the splitmix64 finaliser of caro_noise.h:
@@ -329,7 +339,8 @@ int caro_net_debug_stamps(caro_net* n, uint64_t* stamps_dev);
  * synchronisation.  noise_dev: f64[searches, G, batch, A] or NULL (generated); buffers as for caro_select /
  * caro_expand_backup (G * batch rows); net1 may be NULL when the engine has one net.  With one wavefront per game
  * (batch * lanes-per-descent == 64) the three tree kernels run fused (k_tree), two launches per minibatch, and
- * leaves travel in slot rows (caro_net_forward_slots); otherwise in the dense rows of caro_select.
+ * leaves travel in slot rows (caro_net_forward_slots); with several whole wavefronts per game (a multiple of 64 above
+ * 64) the same fusion runs as k_tree_mw; otherwise (less than one wavefront) in the dense rows of caro_select.
  * A move needs searches >= 2 when its root may be unexpanded: the first minibatch on an unexpanded root only expands it
  * (lib/mcts.py:123: every descent returns the root itself, nothing is backed up), so after ONE search no edge has been
  * visited and the policy is 0 / 0 -- the reference raises ZeroDivisionError there (lib/mcts.py:311); caro_policy
@@ -339,6 +350,15 @@ int caro_net_debug_stamps(caro_net* n, uint64_t* stamps_dev);
 int caro_search_batch(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch,
                       const double* noise_dev, float* planes_dev, uint64_t* leaf_keys_dev, float* probs_dev,
                       float* values_dev, void* stream);
+
+/* One whole move of play_game's loop body (lib/utils.py:76-99: search_batch, get_policy_value, the sampled move,
+ * game.move, win / draw) for every live game: caro_search_batch followed by caro_step, arguments as for those two.
+ * Where several wavefronts serve a game (batch x lanes per descent a multiple of 64 above 64: the 15 x 15 board with 8
+ * descents) the ply -- and, with caro_config.evict, the eviction that follows it -- runs inside the search's closing
+ * tree launch: one launch per move instead of three.  Results are those of the two calls. */
+int caro_search_move(caro_engine* h, caro_net* net0, caro_net* net1, int searches, int batch, const double* noise_dev,
+                     const double* uniforms_dev, float* planes_dev, uint64_t* leaf_keys_dev, float* probs_dev,
+                     float* values_dev, int32_t* actions_dev, int32_t* done_dev, int32_t* result_dev, void* stream);
 
 /* ---- staggered mode: every game on its own minibatch clock (the hot path of bench.py / train.self_play) ----
  * In lock-step all games reach a move together, and the launches right after a move carry far more new leaves
