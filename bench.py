@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
-PMC_FILE = os.path.join("profiles", "pmc_r05.json")
+PMC_FILE = os.path.join("profiles", "pmc_r06.json")
 CPU_RATIO_FILE = os.path.join("profiles", "cpu_ratio_r03.json")
 NET_KERNEL = {"hip": "k_net_forward", "hipw": "k_net_forward_w"}
 
@@ -64,7 +64,7 @@ def host_cores():
 
 def pmc_status():
     """(commit the PMC passes were taken on, None | why the counters may not be quoted).  The committed PMC file
-    carries the SHA-256 of the kernel sources it was measured on (tools/profile_r05.sh); counters of other sources
+    carries the SHA-256 of the kernel sources it was measured on (tools/profile_r06.sh); counters of other sources
     are not quoted: a kernel change without a new PMC pass must not carry stale numbers."""
     try:
         d = json.load(open(os.path.join(ROOT, PMC_FILE)))
@@ -84,7 +84,7 @@ def pmc_status():
 
 def load_pmc(section=None):
     """HBM bytes per launch and MFMA-busy fraction from the committed PMC passes (separate rocprofv3 --pmc runs of
-    this command, tools/profile_r05.sh), by kernel; section = None (headline) | "config5" | "config4".  Empty when
+    this command, tools/profile_r06.sh), by kernel; section = None (headline) | "config5" | "config4".  Empty when
     the kernel sources are not the ones the passes were taken on (pmc_status)."""
     if pmc_status()[1] is not None:
         return {}
@@ -431,7 +431,7 @@ class Leg:
         # FLOPs of one leaf through lib/model.py Net (2 x MAC): conv_in, 5 residual 3x3 convs, 1x1 heads, FC heads
         flops_per_leaf = 2.0 * (HW * 64 * 18 + 5 * HW * 64 * 576 + HW * 3 * 64 + 20 * HW + 20 + 2 * HW * A)
         traffic_note = ("HBM bytes per launch from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                        "configuration, tools/profile_r05.sh, corrected as MI355X_MICROARCH.md prescribes: read side "
+                        "configuration, tools/profile_r06.sh, corrected as MI355X_MICROARCH.md prescribes: read side "
                         "x2); not measured in this run" % PMC_FILE)
         kernel_us = 0.0
         roofline = roofline_tree = None
@@ -782,22 +782,23 @@ def main():
             extras["config5"] = {"error": repr(e)}
             extras_rc = 1
         try:
-            # config 4 twice.  (1) ONE stream, HIP events on: its launches do not overlap, so `roofline` / `roofline_tree`
-            # / `kernel_ms_per_step` price single launches.  (2) the games as two engines of 512 on two streams (no CU
-            # mask), events off: a 15x15 net launch is 30 rounds of workgroups, the last one partly filled, and the other
-            # half's tree-side kernels run there -- this is the leg's `value`.  One board per net workgroup: a game's bits
-            # do not depend on the split (tests/test_gpu_tuples.py::test_gomoku15_games_do_not_depend_on_the_stream_split).
+            # config 4 twice.  (1) ONE stream, HIP events on: this is the leg's `value` -- the form BASELINE's configuration
+            # names and every earlier round's one-stream figure compares with -- and its launches do not overlap, so
+            # `roofline` / `roofline_tree` / `kernel_ms_per_step` price single launches.  (2) the same games as two engines
+            # of 512 on two streams (no CU mask), events off: a 15x15 net launch is 30 rounds of workgroups, the last one
+            # partly filled, and the other half's tree kernels run there -- reported beside it as `two_streams` (ADVICE r5:
+            # a scheduling change, not to be read as a kernel speed-up).  One board per net workgroup: a game's bits do not
+            # depend on the split (tests/test_gpu_tuples.py::test_gomoku15_games_do_not_depend_on_the_stream_split).
             one = side_leg("config4", c4, args.config4_steps, args.config4_warmup, not args.no_profile)
             two = side_leg("config4-2streams", dict(c4, streams=2, stream_mask=0), args.config4_steps,
                            args.config4_warmup, False)
-            for k in ("roofline", "roofline_tree", "live_nodes"):
-                two[k] = one[k]
-            two["kernel_ms_per_step"] = None  # (two streams: the launches of the halves overlap; see single_stream)
-            two["single_stream"] = {"value": one["value"], "ms_per_step": one["ms_per_step"],
-                                    "kernel_ms_per_step": one["kernel_ms_per_step"],
-                                    "note": "the same configuration on one stream, in this run: roofline, roofline_tree "
-                                            "and live_nodes of this leg are measured there (its launches do not overlap)"}
-            extras["config4"] = two
+            one["two_streams"] = {"value": two["value"], "unit": two["unit"], "ms_per_step": two["ms_per_step"],
+                                  "streams_per_gpu": 2, "games_finished": two["games_finished"],
+                                  "overflows": two["overflows"],
+                                  "note": "the same 1024 games as two engines of 512 on two HIP streams, in this run: one "
+                                          "half's tree kernels run in the partly filled last round of the other half's net "
+                                          "launch; bit-identical per game"}
+            extras["config4"] = one
         except Exception as e:
             import traceback
             traceback.print_exc()

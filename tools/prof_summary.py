@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 runs of tools/profile_r02.sh (gpurun_out/prof_r02/) into profiles/.
+"""Summarise the rocprofv3 runs of tools/profile_r06.sh (gpurun_out/prof_r06/) into profiles/.
 
-    python tools/prof_summary.py gpurun_out/prof_r02 r02_a
-    python tools/prof_summary.py gpurun_out/prof_r03 r03_a pmc_r03.json     (tools/profile_r03.sh: + configs 5 and 4)
+    python tools/prof_summary.py gpurun_out/prof_r06 r06_a pmc_r06.json
 
 bench.py plays a 16-game copy of its configuration before the clock starts (first-use costs); its small launches
 are in the traces too.  Only the launches of the full-size engine are summarised: per kernel, the dispatches with
@@ -18,7 +17,7 @@ import os
 import sys
 from collections import defaultdict
 
-SHORT = ["k_tree_stag", "k_tree", "k_net_heads", "k_net_forward_w2", "k_net_forward_w", "k_net_forward", "k_select", "k_expand_backup", "k_encode",
+SHORT = ["k_tree_stag", "k_tree_mw", "k_tree", "k_net_heads", "k_net_forward_w2", "k_net_forward_w", "k_net_forward", "k_select", "k_expand_backup", "k_encode",
          "k_step", "k_drain_copy", "k_drain_scan", "k_evict", "k_net_hash"]
 
 
@@ -46,28 +45,35 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     root = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     # ---- kernel trace of the --stats run
-    recs = []
-    for r in rows(os.path.join(src, "stats"), "*kernel_trace.csv"):
-        k = short(r["Kernel_Name"])
-        if k:
-            recs.append({"k": k, "g": r["Grid_Size_X"], "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
-                         "t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"])})
-    recs = full_size(recs, "g")
-    per = defaultdict(list)
-    for r in recs:
-        per[r["k"]].append(r["ns"])
-    total = sum(sum(v) for v in per.values())
-    span = (max(r["t1"] for r in recs) - min(r["t0"] for r in recs)) if recs else 0
-    out = os.path.join(root, "profiles", tag + "_kernel_stats.csv")
-    with open(out, "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "
-                "--no-extra-configs --no-profile; launches of the full-size engine only (largest grid per kernel); "
-                "busy = sum of kernel time / span first..last launch = %.3f\n" % (total / span if span else 0))
-        f.write("kernel,calls,total_us,avg_us,min_us,max_us,share\n")
-        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
-            f.write("%s,%d,%.1f,%.2f,%.2f,%.2f,%.4f\n" % (k, len(v), sum(v) / 1e3, sum(v) / len(v) / 1e3, min(v) / 1e3,
-                                                          max(v) / 1e3, sum(v) / total))
-    print(open(out).read())
+    def stats(sub, out_tag):
+        recs = []
+        for r in rows(os.path.join(src, sub), "*kernel_trace.csv"):
+            k = short(r["Kernel_Name"])
+            if k:
+                recs.append({"k": k, "g": r["Grid_Size_X"], "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+                             "t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"])})
+        if not recs:
+            return
+        recs = full_size(recs, "g")
+        per = defaultdict(list)
+        for r in recs:
+            per[r["k"]].append(r["ns"])
+        total = sum(sum(v) for v in per.values())
+        span = (max(r["t1"] for r in recs) - min(r["t0"] for r in recs)) if recs else 0
+        cmd_file = os.path.join(src, sub + ".cmd")  # the command line as the profile script ran it
+        cmd = open(cmd_file).read().strip() if os.path.exists(cmd_file) else "rocprofv3 --kernel-trace --stats -- python3 bench.py ..."
+        out = os.path.join(root, "profiles", out_tag + "_kernel_stats.csv")
+        with open(out, "w") as f:
+            f.write("# %s; launches of the full-size engine only (largest grid per kernel); "
+                    "busy = sum of kernel time / span first..last launch = %.3f\n" % (cmd, total / span if span else 0))
+            f.write("kernel,calls,total_us,avg_us,min_us,max_us,share\n")
+            for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+                f.write("%s,%d,%.1f,%.2f,%.2f,%.2f,%.4f\n" % (k, len(v), sum(v) / 1e3, sum(v) / len(v) / 1e3, min(v) / 1e3,
+                                                              max(v) / 1e3, sum(v) / total))
+        print(open(out).read())
+
+    stats("stats", tag)
+    stats("stats_config4", tag + "_config4")
     # ---- counters
     pmc_name = sys.argv[3] if len(sys.argv) > 3 else "pmc_r02.json"
 
@@ -123,7 +129,7 @@ def main():
     for extra in ("config5", "config4"):  # profile_r03.sh: the same three passes on BASELINE configs 5 and 4
         if os.path.isdir(os.path.join(src, extra + "_fetch")):
             out_json[extra] = section(extra + "_")
-    # what the passes were taken on (tools/profile_r05.sh leaves the kernel sources' hashes beside the counters), and
+    # what the passes were taken on (tools/profile_r06.sh leaves the kernel sources' hashes beside the counters), and
     # the commit that holds exactly those sources -- bench.py refuses to quote the counters once the sources differ
     sha_file = os.path.join(src, "source_sha256.json")
     if os.path.exists(sha_file):
@@ -132,7 +138,7 @@ def main():
         from source_sha import source_sha256
         out_json["source_sha256"] = json.load(open(sha_file))
         same = out_json["source_sha256"] == source_sha256(root)
-        clean = subprocess.run(["git", "-C", root, "diff", "--quiet", "HEAD", "--", "caro_ai_amd/csrc"]).returncode == 0
+        clean = subprocess.run(["git", "-C", root, "diff", "--quiet", "HEAD", "--", "caro_ai_amd/csrc", "include"]).returncode == 0
         head = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
         out_json["pmc_source_head"] = head if (same and clean) else None
         print("PMC passes taken on the sources of commit", out_json["pmc_source_head"])

@@ -1,18 +1,21 @@
 #!/bin/bash
-# Round-4 profiles on the GPU box (one gpurun call): kernel-trace stats of the driver's bench command, and the PMC
-# passes (HBM bytes, MFMA busy), each in its own rocprofv3 run as the pool requires -- this round at the driver's
-# --steps 20 --warmup 5 for the headline, and the same three passes on BASELINE configs 5 and 4.
-# Output: gpurun_out/<dir>/ ; summarise with  python tools/prof_summary.py gpurun_out/<dir> r04_x pmc_r04.json
+# Profiles on the GPU box (one gpurun call): kernel-trace stats of the driver's bench command, and the PMC passes (HBM
+# bytes, MFMA busy), each in its own rocprofv3 run as the pool requires -- at the driver's --steps 20 --warmup 5 for the
+# headline, and the same three passes on BASELINE configs 5 and 4 (+ a kernel-trace pass of config 4: its tree kernel).
+# Output: gpurun_out/<dir>/ ; summarise with  python tools/prof_summary.py gpurun_out/<dir> r06_a pmc_r06.json
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/${1:-prof_r04}
+OUT=$ROOT/gpurun_out/${1:-prof_r06}
 WHAT=${2:-all}   # "stats": the kernel-trace pass of the headline only
 mkdir -p $OUT
+# what is profiled: bench.py quotes the counters of pmc_r06.json only while the kernel sources still hash to this
+python3 $ROOT/tools/source_sha.py > $OUT/source_sha256.json
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra-configs --sustained-moves 0 --no-profile"
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra-configs --sustained-moves 0 --train-loop-games 0 --no-profile"
 H="--steps 20 --warmup 5"
 C5="--arena --games 512 --searches 100 --steps 3 --warmup 2"
 C4="--game gomoku15 --searches 50 --steps 2 --warmup 1"
+echo "rocprofv3 --kernel-trace --stats -- $B $H" | sed "s#$ROOT/##g" > $OUT/stats.cmd  # (what the summary's header quotes)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B $H > $OUT/stats.json 2> $OUT/stats.err
 echo stats done
 if [ "$WHAT" = "stats" ]; then exit 0; fi
@@ -28,5 +31,8 @@ run_pmc() {  # $1 prefix, $2.. bench arguments
 run_pmc pmc $H
 run_pmc config5 $C5
 run_pmc config4 $C4
+echo "rocprofv3 --kernel-trace --stats -- $B $C4" | sed "s#$ROOT/##g" > $OUT/stats_config4.cmd
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_config4 -- $B $C4 > $OUT/stats_config4.json 2> $OUT/stats_config4.err
+echo config4 stats done
 find $OUT -name "*_agent_info.csv" -delete
 du -sh $OUT
