@@ -6,11 +6,11 @@ OUT=$ROOT/gpurun_out/${1:-tools_smoke}
 mkdir -p $OUT
 cd $ROOT
 : > $OUT/tools_smoke.txt
-for t in "$@"; do :; done
 for t in probe_clock.py probe_clock15.py probe_engine_net.py probe_grid.py \
          probe_leaves.py probe_netloop.py probe_select.py probe_select15.py probe_small.py probe_stag.py \
          measure_dup_leaves.py measure_move_latency.py measure_train_step.py cmp_net.py bench_noise.py; do
-  timeout -k 5 150 python tools/$t > $OUT/smoke_$t.log 2>&1
+  a=""; if [ $t = cmp_net.py ]; then a=$OUT/cmp_net.npz; fi
+  timeout -k 5 150 python tools/$t $a > $OUT/smoke_$t.log 2>&1
   echo "$t rc=$?" >> $OUT/tools_smoke.txt
 done
 cat $OUT/tools_smoke.txt
