@@ -608,6 +608,13 @@ def train_loop_record(args, device, headline, games=4096, concurrent=1024):
     net, wtag = load_net(game, device, args.weights)
     rb = train.DeviceReplayBuffer(game, 1 << 18, device)
     train.release_engines()
+    # (first-use costs of this process -- torch's cat / index kernels behind the gather and the replay ring, code objects --
+    # are taken by a 16-game call on a throw-away engine, as the headline's prewarm does; construction of the real engine
+    # and of its HipNet stay inside the cold call)
+    train.self_play(game, train.DeviceReplayBuffer(game, 4096, device), net, 16, device=str(device), searches=2,
+                    batch=args.batch, stagger=True, reuse=False)
+    from caro_ai_amd import net_hip
+    net_hip.release_hipnets()
     torch.cuda.synchronize(device)
     kw = dict(device=str(device), searches=args.searches, batch=args.batch, concurrent=concurrent, stagger=True)
     calls = []

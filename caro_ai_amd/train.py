@@ -435,10 +435,19 @@ def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="c
         if rank == 0:
             stores = [mcts_mod.MCTS(game, tree_device=device, node_cap=node_cap),
                       mcts_mod.MCTS(game, tree_device=device, node_cap=node_cap)]
-            for _ in range(rounds):
-                r, _ = play_game(game, stores, None, challenger, champion, steps_before_tau_0=0, mcts_searches=20,
-                                 mcts_batch_size=16, device=device)
-                res.append(r)
+            # eval-mode batch-norm during search (declared deviation Q9; it also lets the stores take the fused one-call
+            # search of lib/mcts.py); the nets get their training flags back
+            modes = [(n, n.training) for n in (challenger, champion)]
+            try:
+                for n, _ in modes:
+                    n.eval()
+                for _ in range(rounds):
+                    r, _ = play_game(game, stores, None, challenger, champion, steps_before_tau_0=0, mcts_searches=20,
+                                     mcts_batch_size=16, device=device)
+                    res.append(r)
+            finally:
+                for n, was in modes:
+                    n.train(was)
         wins, losses, draws = parallel.allreduce_counts((res.count(1), res.count(-1), res.count(0)), device)
         ratio = wins / max(1, wins + losses + draws)
         return (ratio, (wins, losses, draws)) if counts else ratio
@@ -485,18 +494,26 @@ def parse_args(argv=None):
     p.add_argument("--saves", default="saves")
     p.add_argument("--reference-evaluate", action="store_true",
                    help="arena gate with the reference's store semantics: one pair of MCTS stores reused by all "
-                        "rounds, rounds played one after another (default: independent rounds, concurrent, sharded)")
+                        "rounds, rounds played one after another (the default in a single process)")
+    p.add_argument("--sharded-evaluate", action="store_true",
+                   help="arena gate as independent rounds with fresh trees, concurrent and sharded over the ranks (the "
+                        "default under several ranks; a declared deviation from the reference's evaluate)")
     p.add_argument("--ddp", action="store_true",
                    help="several ranks: every rank trains on its share of each batch, gradients all-reduced "
                         "(default: rank 0 trains, the weights are broadcast)")
     return p.parse_args(argv)
 
 
-def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, reference_evaluate=False, ddp=False,
+def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, reference_evaluate=None, ddp=False,
         sample_seed=None, stop=None, log=print, concurrent=None, stream=False):
     """The reference's training loop (train.py:165-217): self-play with the best net -> replay buffer -> TRAIN_ROUNDS SGD
     steps -> every EVALUATE_EVERY_STEP iterations the arena gate (challenger = the net being trained against the best
     net; promoted when its win ratio exceeds BEST_NET_WIN_RATIO: `NetWrapper.sync`, `best_%03d_%05d.dat`).
+    reference_evaluate: the gate with the REFERENCE's evaluate semantics (train.py:134-141: one pair of stores reused by
+    all 20 rounds, the opener from np.random.choice(2), rounds one after another; `evaluate(reference_stores=True)`) --
+    the default (None) in a single process, where it costs ~2 s every EVALUATE_EVERY_STEP = 100 iterations; False (and
+    the default under several ranks): independent rounds with fresh trees, concurrent and sharded over the ranks, a
+    declared deviation whose promote / keep decision can differ for the same nets.
     `games` self-play games per iteration (reference: PLAY_EPISODES = 1), `iterations` 0 = for ever.
     sample_seed: seed of the replay sampling (None: torch's global generator, as the reference); stop(history) -> True
     ends the loop early (several ranks: rank 0 decides, the others follow).  `concurrent`: game slots per rank (default:
@@ -506,6 +523,8 @@ def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, re
     ratio, promoted), the number of promotions, the best net wrapper, and per iteration the seconds each phase took
     (`phases`: self_play -- with its own setup / play / gather split --, train, broadcast, evaluate)."""
     rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
+    if reference_evaluate is None:
+        reference_evaluate = world == 1
     writer = writer or _NullWriter()
     best_net = NetWrapper(net)
     optimizer = optim.SGD(net.parameters(), lr=cfg.LEARNING_RATE, momentum=0.9)
@@ -599,7 +618,8 @@ def main(argv=None):
     net = Net(input_shape=game.obs_shape, actions_n=game.action_space).to(device)
     parallel.broadcast_weights(net)
     fit(game, net, device, args.games, iterations=args.iterations, saves_path=saves_path, writer=writer,
-        reference_evaluate=args.reference_evaluate, ddp=args.ddp, log=lambda m: print(m, flush=True),
+        reference_evaluate=True if args.reference_evaluate else False if args.sharded_evaluate else None, ddp=args.ddp,
+        log=lambda m: print(m, flush=True),
         concurrent=args.concurrent or min(args.games, 1024), stream=not args.exact_self_play)
     writer.close()
 

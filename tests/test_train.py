@@ -118,6 +118,34 @@ def test_short_training_run_end_to_end(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_fit_with_the_cli_defaults_stream_self_play_and_the_references_gate(monkeypatch):
+    """what `python -m caro_ai_amd.train` runs by default on one GPU (round 6): self-play as a stream (the engine is
+    kept running between iterations; connect four has the staggered geometry) and the arena gate with the reference's
+    evaluate semantics (one pair of stores for all rounds, train.py:134-141)"""
+    from caro_ai_amd import train
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    monkeypatch.setattr(cfg, "MIN_REPLAY_TO_TRAIN", 300)
+    monkeypatch.setattr(cfg, "EVALUATE_EVERY_STEP", 2)
+    monkeypatch.setattr(cfg, "EVALUATION_ROUNDS", 3)
+    monkeypatch.setattr(cfg, "BATCH_SIZE", 64)
+    monkeypatch.setattr(cfg, "TRAIN_ROUNDS", 2)
+    train.release_engines()
+    g = ConnectFour()
+    torch.manual_seed(3)
+    net = Net(g.obs_shape, g.action_space).to("cuda:0")
+    np.random.seed(5)
+    h = train.fit(g, net, "cuda:0", games=64, iterations=4, concurrent=32, stream=True, sample_seed=2, log=None)
+    assert h["iterations"] == 4 and len(h["evaluations"]) == 2 and len(h["loss_total"]) == 4
+    ph = h["phases"]
+    assert [p["engine_reused"] for p in ph][1] is True       # the second iteration continues the first one's engine
+    assert all(p["nodes"] > 0 and p["self_play"] > 0 for p in ph) and ph[1]["evaluate"] > 0 and ph[0]["evaluate"] == 0
+    assert net.training  # the gate ran the nets in eval mode and gave the training flag back
+    assert all(0.0 <= r <= 1.0 for _, r, _ in h["evaluations"])
+    train.release_engines()
+
+
+@pytest.mark.gpu
 def test_evaluate_ratio_and_device_planes():
     from caro_ai_amd import train
     from caro_ai_amd.lib.game.connect_four import ConnectFour
@@ -218,7 +246,7 @@ def test_training_loop_learns_connect4_and_passes_the_real_gate(monkeypatch):
     monkeypatch.setattr(cfg, "EVALUATE_EVERY_STEP", 4)   # the reference's 100 is paced for one game per iteration
     net, initial = _fresh(g, 0)
     fell = lambda h: len(h["loss_total"]) >= 8 and float(np.mean(h["loss_total"][-3:])) < 0.8 * h["loss_total"][0]
-    h = train.fit(g, net, "cuda:0", games=128, iterations=160, sample_seed=7, log=None,
+    h = train.fit(g, net, "cuda:0", games=128, iterations=160, sample_seed=7, log=None, reference_evaluate=False,
                   stop=lambda h: h["promotions"] >= 1 and fell(h))
     print("iterations %d, promotions %d, loss %.3f -> %.3f, evaluations %s"
           % (h["iterations"], h["promotions"], h["loss_total"][0], float(np.mean(h["loss_total"][-3:])), h["evaluations"]))
@@ -254,7 +282,8 @@ def test_training_loop_learns_tictactoe():
         seen.append((h["iterations"], first, last, w, l, d))
         return last < 0.8 * first and w >= 2 * l and w - l >= 6
 
-    h = train.fit(g, net, "cuda:0", games=128, iterations=180, sample_seed=11, log=None, stop=good)
+    h = train.fit(g, net, "cuda:0", games=128, iterations=180, sample_seed=11, log=None, stop=good,
+                  reference_evaluate=False)
     print("checks (iterations, first loss, last loss, wins, losses, draws vs the initial net):", seen)
     it, first, last, w, l, d = seen[-1]
     assert last < 0.8 * first, seen

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--iterations", type=int, default=6)
     ap.add_argument("--evaluate-every", type=int, default=3, help="(config.EVALUATE_EVERY_STEP is 100: lowered here so that "
                                                                   "the gate shows up inside a few iterations)")
+    ap.add_argument("--reference-evaluate", type=int, default=1, help="1: the gate with the reference's evaluate semantics "
+                                                                       "(fit's default in a single process); 0: sharded rounds")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_fit_breakdown.json"))
     args = ap.parse_args()
     from caro_ai_amd import config as cfg
@@ -51,8 +53,9 @@ def main():
         net.load_state_dict(torch.load(weights_path("best_026_12000.dat"), map_location="cpu"))
         net = net.to(dev)
         t0 = time.time()
+        args.reference_evaluate = bool(args.reference_evaluate)
         hist = train.fit(game, net, dev, args.games, iterations=args.iterations, sample_seed=1, log=None,
-                         concurrent=args.concurrent, stream=(form == "stream"))
+                         concurrent=args.concurrent, stream=(form == "stream"), reference_evaluate=args.reference_evaluate)
         torch.cuda.synchronize()
         total = time.time() - t0
         ph = hist["phases"]
