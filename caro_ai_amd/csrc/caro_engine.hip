@@ -640,6 +640,9 @@ static inline size_t mail_bytes(int B) {
   return GEO::APL > 1 ? (size_t)((B * GEO::LPD + 63) / 64) * (2 * GEO::AP) * sizeof(double) : 0;
 }
 
+template <class GEO>
+constexpr int geo_max_batch() { return GEO::LPD >= 64 ? 16 : GEO::LPD >= 32 ? 32 : 64; }
+
 template <class GEO, bool ONE = false>
 __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& gr, int B, int mb_index,
                                             const double* __restrict__ noise, int32_t* __restrict__ rows,
@@ -653,13 +656,16 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
   const int b = tid / LPD, l = tid % LPD;
   const int first = (tid & 63) - l;  // first lane of this descent's group inside its wave
 
-  __shared__ uint64_t s_key[MAXB][KW];
-  __shared__ int s_status[MAXB];
-  __shared__ int s_first[MAXB];
-  __shared__ int s_depth[MAXB];
-  __shared__ int s_player[MAXB];
-  __shared__ float s_value[MAXB];
-  __shared__ uint32_t s_dhome[MAXB];
+  // (LDS sized by the geometry: a block has at most 1024 threads, so at most 1024 / LPD descents -- 16 on the boards with
+  // one wavefront per descent, whose 64-byte keys would otherwise take 4 KB here and 4 KB in expand_body)
+  constexpr int MB = geo_max_batch<GEO>();
+  __shared__ uint64_t s_key[MB][KW];
+  __shared__ int s_status[MB];
+  __shared__ int s_first[MB];
+  __shared__ int s_depth[MB];
+  __shared__ int s_player[MB];
+  __shared__ float s_value[MB];
+  __shared__ uint32_t s_dhome[MB];
 
   if (gr.done) {
     if (tid == 0) {
@@ -715,7 +721,8 @@ __device__ __forceinline__ void select_body(const View& v, const GameRegs<GEO>& 
   if (v.dbg) st_noise = __builtin_amdgcn_s_memtime();
 
   // the descents' path records are collected in LDS and written out after the last level
-  constexpr int PREC_LDS = 512;
+  // (boards of more than 64 cells never fit -- batch x cells <= 512 entries --: no LDS is set aside for them)
+  constexpr int PREC_LDS = GEO::APL > 1 ? 1 : 512;
   __shared__ uint4 s_prec[PREC_LDS];
   const bool stage = B * v.maxd <= PREC_LDS;
   uint4* lprec = stage ? s_prec + b * v.maxd : nullptr;
@@ -1080,7 +1087,8 @@ __device__ __forceinline__ void expand_body(const View& v, GameRegs<GEO>& gr, in
   using R = typename GEO::R;
   using Board = typename R::Board;
   constexpr int AP = GEO::AP, KW = GEO::KW;
-  constexpr int MAXE = 512;  // entries held in LDS; longer queues fall back to the sequential form
+  constexpr int MAXE = GEO::APL > 1 ? 256 : 512;  // entries held in LDS; longer queues fall back to the sequential form
+  constexpr int MAXB = geo_max_batch<GEO>();      // (shadows the global bound: LDS sized by the geometry, see select_body)
   __shared__ int e_node[MAXE];
   __shared__ short e_act[MAXE];
   __shared__ float e_val[MAXE];
