@@ -389,3 +389,45 @@ def test_bench_selfcheck_two_ranks_on_one_gpu():
     r = subprocess.run(cmd, env=dict(env, CARO_SELFCHECK_FAULT="engine_tuples"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 4, (r.returncode, r.stderr[-3000:])
     assert "selfcheck FAILED" in r.stderr and "engine_tuples:" in r.stderr
+
+
+@pytest.mark.parametrize("d,B", [({"kind": "mnk", "n": 15, "k": 5}, 8), ({"kind": "mnk", "n": 10, "k": 5}, 4),
+                                 ({"kind": "c4"}, 16)])
+def test_multi_wave_fused_kernel_and_search_move_equal_search_plus_step(d, B):
+    """Geometries with several wavefronts per game (15 x 15 with 8 descents = config 4's: eight; 10 x 10 with 4; connect
+    four with 16 descents: two) take the fused multi-wave tree kernel: no k_encode / k_expand_backup launches between a
+    move's minibatches.  And caro_search_move (the ply + the eviction inside the search's closing launch) leaves, move
+    after move, exactly what caro_search_batch + caro_step leave: roots, plies, counters, live nodes, drained tuples --
+    which equal the oracle's games."""
+    game = _game_of(d)
+    G, S, seed = 6, 5, 19
+    kw = dict(max_batch=B, steps_before_tau_0=3, seed=seed, searches_hint=S, evict=True, node_cap=512, uid_base=70)
+    a = _engine(game, G, [_synth(game, "fused")], **kw)
+    b = _engine(game, G, [_synth(game, "fused")], **kw)
+    a.profile(True)
+    ta, tb, ga, gb = [], [], [], []
+    for move in range(14):
+        a.search(S, B)
+        a.step()
+        b.search_step(S, B)
+        ra, rb = a.roots(), b.roots()
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y), move
+        assert a.counters() == b.counters() and np.array_equal(a.tree_live(), b.tree_live()), move
+        for eng, t, g in ((a, ta, ga), (b, tb, gb)):
+            dd = eng.drain(recycle=True)
+            if int(dd["games"].shape[0]):
+                t.append({k: v.cpu().numpy() for k, v in dd.items() if k != "games"})
+                g.append(dd["games"].cpu().numpy())
+    prof = a.profile_read()
+    assert prof["select"][1] > 0 and prof["compact"][1] == 0, prof  # the fused kernel ran, k_encode never did
+    assert a.counters()["overflows"] == 0
+    a.close(); b.close()
+    if d["kind"] == "c4":  # (the short boards finish games inside 14 moves)
+        assert ga
+    if ga:
+        A_, B_ = _collect(ta, np.concatenate(ga)), _collect(tb, np.concatenate(gb))
+        assert A_ == B_
+        ref = _oracle_games(d, sorted(A_)[:3], seed, 3, S, B, 1)
+        for uid, r in ref.items():
+            assert A_[uid][:3] == (r["first"], r["result"], r["steps"]), uid

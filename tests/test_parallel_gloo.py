@@ -469,3 +469,53 @@ def test_ddp_training_step_two_ranks_equals_one():
             assert np.allclose(v.numpy(), got[0][1][k], rtol=1e-4, atol=1e-6), k
     for k in one:
         assert abs(one[k] - got[0][0][k]) < 1e-5 * max(1.0, abs(one[k])), (k, one[k], got[0][0][k])
+
+
+def _fit_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), CARO_DIST_BACKEND="gloo", CARO_SHARE_GPU="1")
+    from caro_ai_amd import config as cfg
+    from caro_ai_amd import parallel, train
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    parallel.init()
+    cfg.MIN_REPLAY_TO_TRAIN, cfg.EVALUATE_EVERY_STEP, cfg.EVALUATION_ROUNDS, cfg.BATCH_SIZE, cfg.TRAIN_ROUNDS = 300, 2, 4, 64, 2
+    g = ConnectFour()
+    torch.manual_seed(3 + rank)  # different initial nets: main()'s broadcast makes them one
+    net = Net(g.obs_shape, g.action_space).to("cuda:0")
+    parallel.broadcast_weights(net)
+    h = train.fit(g, net, "cuda:0", games=48, iterations=4, concurrent=24, stream=True, sample_seed=2, log=None,
+                  stop=lambda hist: len(hist["loss_total"]) >= 3)  # rank 0 decides (it holds the losses), everyone stops
+    import hashlib
+    sha = hashlib.sha256(b"".join(t.detach().cpu().numpy().tobytes() for t in net.state_dict().values())).hexdigest()
+    q.put((rank, h["iterations"], len(h["evaluations"]), [p["nodes"] for p in h["phases"]], sha))
+    train.release_engines()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_fit_two_ranks_stream_self_play_sharded_gate_and_a_stop_decided_by_rank_0():
+    """train.fit as two gloo ranks on the one GPU with the CLI's defaults for several ranks (round 6): self-play as a
+    stream on every rank (each rank's own engine, the tuples all-gathered at the end of each call), rank 0 trains and
+    broadcasts, the gate sharded over the ranks, and `stop(history)` decided by rank 0 and followed by rank 1 (ADVICE r5:
+    the losses live on rank 0 only; a rank-local decision left the other rank in the next collective).  Both ranks leave
+    after the same iteration with bit-identical weights."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fit_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=600)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == 3          # stopped by rank 0's history after the third iteration, on both ranks
+    assert res[0][1] == res[1][1] == 1          # one gate (iteration 2), the same on both
+    assert all(n > 0 for n in res[0][2] + res[1][2])
+    assert res[0][3] == res[1][3]               # the same weights everywhere
