@@ -441,15 +441,20 @@ class SelfPlayEngine:
                 "P": P.cpu().numpy(), "strong": strong.cpu().numpy()}
 
     # ------------------------------------------------------------ whole games
-    def play_until(self, searches, batch, n_finished=None, max_moves=None, recycle=True, on_tuples=None):
+    def play_until(self, searches, batch, n_finished=None, max_moves=None, recycle=True, on_tuples=None,
+                   one_call=False):
         """Run move steps until `n_finished` games have been drained (or `max_moves`).
+        one_call: search + ply through search_step() (caro_search_move) instead of search() and step().
         Returns (list of tuple dicts on the host unless on_tuples consumes them, game records int64[n,4])."""
         out, games = [], []
         finished = 0
         moves = 0
         while True:
-            self.search(searches, batch)
-            self.step()
+            if one_call:
+                self.search_step(searches, batch)
+            else:
+                self.search(searches, batch)
+                self.step()
             moves += 1
             d = self.drain(recycle=recycle)
             ng = d["games"].shape[0]

@@ -282,13 +282,23 @@ def _oracle_games(d, uids, seed, sbt0, S, B, n_stores, first_mode=2, salts=(0, 0
 
 
 def _check_against_oracle(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base, form="stepwise", salts=None,
-                          **engine_kw):
-    """salts = (s0, s1): player 0's leaves go to table net s0, player 1's to net s1 (n_nets = 2, play.py arena)"""
+                          one_call=False, dirty_first=None, **engine_kw):
+    """salts = (s0, s1): player 0's leaves go to table net s0, player 1's to net s1 (n_nets = 2, play.py arena).
+    one_call: every move through caro_search_move (search + ply from one call).  dirty_first = (seed, uid_base, moves):
+    the engine first plays another run for so many moves and is then RESTARTED in place (caro_engine_restart) for the
+    run that is checked."""
     game = _game_of(d)
     evs = [_synth(game, form)] if salts is None else [_synth(game, form, salts[0]), _synth(game, form, salts[1])]
-    eng = _engine(game, G, evs, n_stores=n_stores, max_batch=B, steps_before_tau_0=sbt0, seed=seed,
-                  uid_base=uid_base, node_cap=S * B * game.obs_shape[1] * game.obs_shape[2] + 64, **engine_kw)
-    tuples, games = eng.play_until(S, B, n_finished=n_finish)
+    cap = S * B * game.obs_shape[1] * game.obs_shape[2] + 64
+    if dirty_first is not None:
+        eng = _engine(game, G, evs, n_stores=n_stores, max_batch=B, steps_before_tau_0=sbt0, seed=dirty_first[0],
+                      uid_base=dirty_first[1], node_cap=cap, **engine_kw)
+        eng.play_until(S, B, max_moves=dirty_first[2], one_call=one_call)
+        eng.restart(seed=seed, uid_base=uid_base)
+    else:
+        eng = _engine(game, G, evs, n_stores=n_stores, max_batch=B, steps_before_tau_0=sbt0, seed=seed,
+                      uid_base=uid_base, node_cap=cap, **engine_kw)
+    tuples, games = eng.play_until(S, B, n_finished=n_finish, one_call=one_call)
     c = eng.counters()
     assert c["overflows"] == 0
     eng.close()

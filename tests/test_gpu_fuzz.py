@@ -6,12 +6,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [11, 12])
+@pytest.mark.parametrize("seed", [11, 12, 13])
 def test_engine_equals_oracle_on_random_configurations(seed):
     """40 configurations per seed -- connect four and m,n,k 3x3 .. 15x15, any k <= 6, searches 2 .. 12, batch 1 / 2 / 3 / 4 /
     5 / 8 / 16, one store or one per player, one or two table nets, tau switch 0 .. 8, 1 .. 24 concurrent games with
-    recycling, step-wise kernels or the fused path, the staggered schedule where one wavefront serves a game, eviction on
-    or off: every finished game equals the oracle's game of the same uid, nothing overflows."""
+    recycling, step-wise kernels or the fused path (one or several wavefronts per game), the staggered schedule where one
+    wavefront serves a game, eviction on or off, moves through caro_search_batch + caro_step or caro_search_move, a fresh
+    engine or one restarted in place after another run: every finished game equals the oracle's game of the same uid,
+    nothing overflows."""
     from tests.test_gpu_engine import _check_against_oracle
     rng = np.random.default_rng(seed)
     games = 0
@@ -38,6 +40,10 @@ def test_engine_equals_oracle_on_random_configurations(seed):
             kw.update(stagger=True, searches_hint=S)
         elif rng.random() < 0.3:
             kw["evict"] = True
+        if form == "fused" and rng.random() < 0.5:
+            kw["one_call"] = True  # search + ply through caro_search_move
+        if rng.random() < 0.25:    # on an engine restarted in place after another run (caro_engine_restart)
+            kw["dirty_first"] = (int(rng.integers(1, 1 << 30)), int(rng.integers(0, 1 << 20)), int(rng.integers(1, 12)))
         cfg = dict(d=d, G=G, n_finish=G + int(rng.integers(0, G + 1)), sbt0=int(rng.integers(0, 9)), S=S, B=B, n_stores=ns,
                    seed=int(rng.integers(1, 1 << 30)), uid_base=int(rng.integers(0, 1 << 20)), form=form,
                    salts=(0x1111, 0x2222) if two_nets else None, **kw)

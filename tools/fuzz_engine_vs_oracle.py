@@ -3,7 +3,8 @@
 connect four and m,n,k boards of 3x3 .. 15x15 with any k, searches 2 .. 12, batch 1 .. 16 (non powers of two too), one
 store or one per player, one or two table nets, tau switch 0 .. 8, 1 .. 24 concurrent games with recycling, both launch
 forms (step-wise kernels / the fused path where the geometry allows), the staggered schedule where one wavefront serves a
-game, eviction on or off -- every finished game must equal
+game, eviction on or off, the moves through caro_search_batch + caro_step or through caro_search_move, on a fresh engine
+or on one restarted in place after another run (round 6) -- every finished game must equal
 the oracle's game of the same uid (tests/test_gpu_engine.py::_check_against_oracle: result, steps, boards, players, float64
 pi, z), no overflow.
 
@@ -51,6 +52,10 @@ def main():
             kw.update(stagger=True, searches_hint=S)   # the schedule bench.py runs: every game on its own minibatch clock
         elif rng.random() < 0.3:
             kw["evict"] = True
+        if form == "fused" and rng.random() < 0.5:
+            kw["one_call"] = True  # search + ply through caro_search_move (the multi-wave kernel's closing launch makes the ply)
+        if rng.random() < 0.25:    # the checked run on an engine RESTARTED in place after another run (caro_engine_restart)
+            kw["dirty_first"] = (int(rng.integers(1, 1 << 30)), int(rng.integers(0, 1 << 20)), int(rng.integers(1, 12)))
         cfg = dict(d=d, G=G, n_finish=n_fin, sbt0=int(rng.integers(0, 9)), S=S, B=B, n_stores=ns, seed=int(rng.integers(1, 1 << 30)),
                    uid_base=int(rng.integers(0, 1 << 20)), form=form, salts=(0x1111, 0x2222) if two_nets else None, **kw)
         try:
