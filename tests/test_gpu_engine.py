@@ -301,6 +301,10 @@ def _check_against_oracle(d, G, n_finish, sbt0, S, B, n_stores, seed, uid_base, 
     tuples, games = eng.play_until(S, B, n_finished=n_finish, one_call=one_call)
     c = eng.counters()
     assert c["overflows"] == 0
+    if engine_kw.get("games_limit"):  # exactly the wanted games: slot g's k-th game while k * G + g < games_limit
+        lim = engine_kw["games_limit"]
+        assert eng.live_games() == 0 and len(games) == lim and c["finished"] == lim
+        assert sorted(games[:, 0].tolist()) == sorted(uid_base + (i % G) + (i // G) * G for i in range(lim))
     eng.close()
     uids = games[:, 0]
     assert len(set(uids.tolist())) == len(uids)

@@ -54,10 +54,14 @@ def main():
             kw["evict"] = True
         if form == "fused" and rng.random() < 0.5:
             kw["one_call"] = True  # search + ply through caro_search_move (the multi-wave kernel's closing launch makes the ply)
+        if rng.random() < 0.3:     # exactly n_finish games (caro_config.games_limit): nothing beyond them is started
+            kw["games_limit"] = -1  # (filled in below, once n_finish is drawn)
         if rng.random() < 0.25:    # the checked run on an engine RESTARTED in place after another run (caro_engine_restart)
             kw["dirty_first"] = (int(rng.integers(1, 1 << 30)), int(rng.integers(0, 1 << 20)), int(rng.integers(1, 12)))
         cfg = dict(d=d, G=G, n_finish=n_fin, sbt0=int(rng.integers(0, 9)), S=S, B=B, n_stores=ns, seed=int(rng.integers(1, 1 << 30)),
                    uid_base=int(rng.integers(0, 1 << 20)), form=form, salts=(0x1111, 0x2222) if two_nets else None, **kw)
+        if cfg.get("games_limit"):
+            cfg["games_limit"] = cfg["n_finish"]
         try:
             c, ref, g = _check_against_oracle(**cfg)
         except Exception:
