@@ -331,7 +331,11 @@ class Leg:
         common = dict(max_batch=B, steps_before_tau_0=self.sbt0, seed=0, device=str(device), searches_hint=S)
         # staggered mode (every game on its own minibatch clock: even leaf counts per launch, include/caro_hip.h):
         # wherever one wavefront serves a game and nothing needs the second key table
-        self.stagger = bool(args.stagger and self.is_hip and game_name == "c4" and B == 8 and not self.evict)
+        # (--stagger 2: wherever the geometry allows -- since round 6 also several wavefronts per game with eviction,
+        # config 4; measured there and not faster: a 15x15 net launch is thirty rounds of workgroups whatever the leaf count)
+        from caro_ai_amd.engine import staggered_geometry
+        self.stagger = bool(args.stagger and self.is_hip and staggered_geometry(self.game, B, bool(self.evict))
+                            and (args.stagger >= 2 or (game_name == "c4" and B == 8)))
         # a small copy of the same configuration: played to completion before the clock starts, it takes the
         # first-use costs (code objects, torch's clone / cat / cast kernels, allocator growth of the drain path)
         self._warm = SelfPlayEngine(self.game, 16, evaluators=make_evaluators(), uid_base=1 << 40, uid_stride=16,
@@ -457,7 +461,8 @@ class Leg:
             achieved = levels_per_launch * bytes_per_level / avg_s / 1e9
             fused = prof.get("compact", (0, 0))[1] == 0
             lpd = 8 if A == 7 else 16 if A <= 16 else 32 if A <= 32 else 64
-            tname = ("k_tree_stag" if self.stagger else "k_tree_mw" if B * lpd > 64 else "k_tree") if fused else "k_select"
+            tname = (("k_tree_stag_mw" if B * lpd > 64 else "k_tree_stag") if self.stagger else
+                     "k_tree_mw" if B * lpd > 64 else "k_tree") if fused else "k_select"
             others = {k: (max(v[0] * 1e3 / v[1] - gap_s * 1e6, 0.0) if v[1] else None) for k, v in prof.items()
                       if k not in ("select", "net", "null1", "null2")}
             roofline_tree = {"bound": "hbm", "kernel": tname, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -689,7 +694,8 @@ def main():
                          "one part overlap the net kernel of another)")
     ap.add_argument("--stream-mask", type=int, default=1, help="with --streams > 1: confine each part to its own CU slice")
     ap.add_argument("--stagger", type=int, default=1,
-                    help="1: staggered mode where the geometry allows it (connect four, batch 8); 0: lock-step")
+                    help="1: staggered mode for connect four with batch 8 (the headline, config 5); 2: wherever the geometry has "
+                         "whole wavefronts per game (also config 4); 0: lock-step")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N > 1: all-gather the finished games' tuples every this many moves (one payload message)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

@@ -1879,16 +1879,25 @@ __global__ void k_reset(View v, const int32_t* __restrict__ first_player) {
 
 // Moves the finished game of slot g aside (record + history rows) and restarts the slot; false if the previous
 // parked game of this slot has not been drained yet (the game then stays finished and tries again next launch).
-template <class GEO>
+// ONE: the block's tree work is one wavefront (k_tree_stag); otherwise every thread of the block takes part (k_tree_stag_mw).
+template <class GEO, bool ONE = true>
 __device__ __forceinline__ bool park_and_restart(const View& v, int g, GameRegs<GEO>& gr) {
   using R = typename GEO::R;
   constexpr int KW = GEO::KW;
-  if (v.pk_flag[g] == 1) return false;
+  const int nth = block_threads<ONE>();
+  if constexpr (ONE) {
+    if (v.pk_flag[g] == 1) return false;
+  } else {  // (one reader: a wavefront that came late would see the flag this very call sets below)
+    __shared__ int s_parked;
+    if (threadIdx.x == 0) s_parked = v.pk_flag[g];
+    __syncthreads();
+    if (s_parked == 1) return false;
+  }
   const int n = gr.ply;
   const size_t h0 = (size_t)g * v.maxply;
-  for (int idx = threadIdx.x; idx < n * v.A; idx += 64) v.ph_pi[h0 * v.A + idx] = v.h_pi[h0 * v.A + idx];
-  for (int idx = threadIdx.x; idx < n * KW; idx += 64) v.ph_key[h0 * KW + idx] = v.h_key[h0 * KW + idx];
-  for (int j = threadIdx.x; j < n; j += 64) v.ph_player[h0 + j] = v.h_player[h0 + j];
+  for (int idx = threadIdx.x; idx < n * v.A; idx += nth) v.ph_pi[h0 * v.A + idx] = v.h_pi[h0 * v.A + idx];
+  for (int idx = threadIdx.x; idx < n * KW; idx += nth) v.ph_key[h0 * KW + idx] = v.h_key[h0 * KW + idx];
+  for (int j = threadIdx.x; j < n; j += nth) v.ph_player[h0 + j] = v.h_player[h0 + j];
   const uint64_t uid = gr.uid;
   if (threadIdx.x == 0) {
     v.pk_ply[g] = n;
@@ -1899,7 +1908,7 @@ __device__ __forceinline__ bool park_and_restart(const View& v, int g, GameRegs<
     v.pk_uid[g] = uid;
     v.pk_flag[g] = 1;
   }
-  block_sync<true>();  // the live record has been read by every thread
+  block_sync<ONE>();  // the live record has been read by every thread
   if (!v.stag_recycle || !game_wanted(v, g, uid + v.uid_stride)) {
     if (threadIdx.x == 0) v.done[g] = 2;  // no restart asked for: parked, the slot stays finished
     gr.done = 2;
@@ -1916,9 +1925,12 @@ __device__ __forceinline__ bool park_and_restart(const View& v, int g, GameRegs<
   gr.step = 0;
   gr.uid = nuid;
   gr.done = 0;
+  // (with eviction on, the ply that ended the game has dropped every node and left both tables clean -- evict_body on a
+  // finished game --: nothing to flip, nothing to clean later)
+  const bool flip = v.etab != 2;
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
-    gr.tbl[st] = 1 - gr.tbl[st];
+    if (flip) gr.tbl[st] = 1 - gr.tbl[st];
     gr.nn[st] = 0;
   }
   if (threadIdx.x == 0) {
@@ -1926,8 +1938,10 @@ __device__ __forceinline__ bool park_and_restart(const View& v, int g, GameRegs<
     for (int st = 0; st < 2; ++st) {  // unrolled: gr.tbl must stay in registers
       if (st < v.n_stores) {
         const int t = g * v.n_stores + st;
-        v.tbl[t] = gr.tbl[st];
-        v.dirty[t] = 1;
+        if (flip) {
+          v.tbl[t] = gr.tbl[st];
+          v.dirty[t] = 1;
+        }
         v.n_nodes[t] = 0;
         v.n_created[t] = 0;
       }
@@ -2038,6 +2052,73 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
       // where the tree wave ran (HW_ID: wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13), above the depth in slot 4
       v.dbg[(size_t)g * 8 + 4] |= (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8;
     }
+  }
+}
+
+// The staggered tree kernel for geometries with SEVERAL wavefronts per game (round 6; k_tree_mw's block layout, k_tree_stag's
+// protocol): expand + backup of the game's pending minibatch, the ply if its S minibatches are done -- with eviction on,
+// followed by the eviction of what the move made unreachable (a finished game: of everything, which also leaves both
+// key tables clean for the restart) --, park + restart if the game ended, then the descents of the next minibatch.
+template <class GEO>
+__global__ void k_tree_stag_mw(View v, int B, const float* __restrict__ probs, const float* __restrict__ values,
+                               float* __restrict__ planes, uint64_t* __restrict__ leaf_keys,
+                               int32_t* __restrict__ rows_cur, int32_t* __restrict__ rows_next) {
+  constexpr int AP = GEO::AP;
+  __shared__ double s_pi[AP];
+  __shared__ int s_n[AP];
+  const int g = blockIdx.x;
+  if (g == 0 && threadIdx.x == 0) {
+    rows_next[0] = 0;
+    rows_next[1] = 0;
+    rows_next[2] = B;
+    rows_cur[2] = B;
+  }
+  // everything that depends on g alone, read by every thread BEFORE anything of it is written (lm / pend / wait at the
+  // end, the ply, the restart): the barrier below keeps a late wavefront from reading a value this call has changed
+  const int w = v.wait[g];
+  int lm = v.lm[g];
+  const int pend = v.pend[g];
+  GameRegs<GEO> gr = load_game<GEO>(v, g);
+  const ExpandPre<GEO> pre = expand_preload<GEO, false>(v, g, B, g * B, probs, values);
+  __syncthreads();
+  if (w > 0 || gr.done == 2) {  // not started yet / parked without restart: no leaves from this slot
+    if (threadIdx.x == 0) {
+      if (w > 0) v.wait[g] = w - 1;
+      v.g_nleaf[g] = 0;
+      v.g_class[g] = 0;
+      v.g_pack[g] = 0;
+    }
+    return;
+  }
+  if (pend) {
+    expand_body<GEO, false>(v, gr, B, pre, g * B, probs);
+    __syncthreads();  // the block's own tree updates are visible to what follows
+  }
+  int over = gr.done == 1;  // finished earlier and could not be parked (its slot's previous game is not drained yet)
+  if (!over && lm == v.stag_S) {
+    over = step_body<GEO>(v, g, gr, nullptr, s_pi, s_n, nullptr, nullptr, nullptr);
+    lm = 0;
+    if (v.etab == 2) {
+      __syncthreads();
+      evict_body<GEO>(v, g, gr.root, gr.done);  // ends with a barrier: the flipped tables and the counts are visible
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+        if (st < v.n_stores) {
+          gr.tbl[st] = v.tbl[g * v.n_stores + st];
+          gr.nn[st] = v.n_nodes[g * v.n_stores + st];
+        }
+    }
+  }
+  if (over) {
+    __syncthreads();
+    if (park_and_restart<GEO, false>(v, g, gr)) over = 0;  // a new game sits in the slot: its first minibatch follows
+    __syncthreads();
+  }
+  // select_body returns at once (zero leaves) for a finished game
+  select_body<GEO, false>(v, gr, B, lm, nullptr, rows_cur, planes, leaf_keys);
+  if (threadIdx.x == 0) {
+    v.lm[g] = over ? 0 : lm + 1;
+    v.pend[g] = over ? 0 : 1;
   }
 }
 
@@ -2612,9 +2693,10 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
     return fail(CARO_E_INVAL, "k must satisfy 2 <= k <= n");
   if (cfg->stagger < 0) return fail(CARO_E_INVAL, "stagger must be >= 0");
   if (cfg->stagger > 0) {
-    if (cfg->evict) return fail(CARO_E_INVAL, "staggered mode does not combine with eviction");
-    if (cfg->max_batch * lpd != 64)
-      return fail(CARO_E_INVAL, "staggered mode needs the one-wavefront-per-game geometry (max_batch x lanes per descent = 64)");
+    if (cfg->max_batch * lpd < 64 || (cfg->max_batch * lpd) % 64 != 0)
+      return fail(CARO_E_INVAL, "staggered mode needs whole wavefronts per game (max_batch x lanes per descent a multiple of 64)");
+    if (cfg->evict && cfg->max_batch * lpd == 64)
+      return fail(CARO_E_INVAL, "staggered mode with eviction: the multi-wavefront kernel only (max_batch x lanes per descent > 64)");
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -2914,8 +2996,11 @@ int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int la
   if (!h->v.stag_S) return fail(CARO_E_STATE, "the engine was not created in staggered mode (caro_config.stagger)");
   if (h->v.n_nets == 2 && !net1) return fail(CARO_E_INVAL, "engine has two nets, net1 is null");
   if (launches < 1) return fail(CARO_E_INVAL, "launches must be >= 1");
-  if (batch < 1 || batch > h->v.maxB || batch * variant_lpd(h->var) != 64)
-    return fail(CARO_E_INVAL, "staggered mode: batch x lanes per descent must be 64");
+  const int bthreads = batch * variant_lpd(h->var);
+  if (batch < 1 || batch > h->v.maxB || bthreads < 64 || bthreads % 64 != 0)
+    return fail(CARO_E_INVAL, "staggered mode: batch x lanes per descent must be a multiple of 64");
+  if (h->cfg.evict && bthreads == 64)
+    return fail(CARO_E_INVAL, "staggered mode with eviction: batch x lanes per descent must be above 64");
   if (h->stag_batch && h->stag_batch != batch) return fail(CARO_E_INVAL, "staggered mode: the batch size is fixed by the first call");
   h->stag_batch = batch;
   hipStream_t st = (hipStream_t)stream;
@@ -2925,13 +3010,19 @@ int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int la
     int32_t* nxt = h->rows + 4 * (h->rows_par ^ 1);
     h->rows_par ^= 1;
     const int p1 = prof_begin(h, PK_SELECT, st);
-    DISPATCH(h->var, hipLaunchKernelGGL(k_tree_stag<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, probs, values,
-                                        planes, leaf_keys, cur, nxt));
+    if (bthreads == 64) {
+      DISPATCH(h->var, hipLaunchKernelGGL(k_tree_stag<GEO>, dim3(h->v.G), dim3(128), 0, st, h->v, batch, probs, values,
+                                          planes, leaf_keys, cur, nxt));
+    } else {
+      DISPATCH(h->var, hipLaunchKernelGGL(k_tree_stag_mw<GEO>, dim3(h->v.G), dim3(bthreads), mail_bytes<GEO>(batch), st,
+                                          h->v, batch, probs, values, planes, leaf_keys, cur, nxt));
+    }
     prof_end(h, p1, st);
     if (hipGetLastError() != hipSuccess) { h->prof_gate = 1; return fail(CARO_E_HIP, "k_tree_stag launch failed"); }
     const int p0 = prof_begin(h, PK_NET, st);
-    const int rc = caro_net_forward_slots(net0, h->v.n_nets == 2 ? net1 : nullptr, planes, cur, h->v.g_pack, h->v.G,
-                                          batch, probs, values, stream);
+    const int rc = caro_net_forward_slot_list(net0, h->v.n_nets == 2 ? net1 : nullptr, planes, cur, h->v.g_pack,
+                                              bthreads == 64 ? nullptr : h->v.slot_list, h->v.G, batch, probs, values,
+                                              stream);
     prof_end(h, p0, st);
     prof_calibrate(h, st);
     if (rc) { h->prof_gate = 1; return rc; }

@@ -29,6 +29,20 @@ COUNTER_NAMES = ["sims", "levels", "expansions", "terminals", "dropped", "overfl
 # hipw: Winograd, the form chosen by the board (row form F(2,3); 2-D form F(2x2,3x3) from 13x13 up); hipw1 / hipw2 force one
 HIP_NET_MODES = {"hip": "f32", "hipw": "f32w", "hipw1": "f32w1", "hipw2": "f32w2"}
 
+def lanes_per_descent(game):
+    """lane geometry of the tree kernels for a game (csrc/caro_variants.h): lanes that share one descent"""
+    A = game.action_space
+    return 8 if A == 7 else 16 if A <= 16 else 32 if A <= 32 else 64
+
+
+def staggered_geometry(game, batch, evict=False):
+    """can the staggered schedule (every game on its own minibatch clock, caro_search_staggered) run this geometry: whole
+    wavefronts per game -- batch x lanes per descent a multiple of 64 --, and with eviction the multi-wavefront kernel
+    (above 64)"""
+    t = int(batch) * lanes_per_descent(game)
+    return t >= 64 and t % 64 == 0 and (t > 64 or not evict)
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 

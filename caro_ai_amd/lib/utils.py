@@ -140,12 +140,11 @@ def play_games(game, n_games, replay_buffer, net1, net2=None, steps_before_tau_0
     # after every move (result-neutral), the default cap then bounds the LIVE nodes -- and an overflow raises, below
     hw = game.obs_shape[1] * game.obs_shape[2]
     evict = mcts_searches * mcts_batch_size * hw + 64 > SelfPlayEngine.DEFAULT_CAP_LIMIT
-    # One generation of games on a geometry with one wavefront per game (connect four, batch 8: play.py's arena):
-    # the engine's staggered mode without restarts -- every game on its own minibatch clock, the same games, evener
+    # One generation of games on a geometry with whole wavefronts per game (connect four with batch 8: play.py's arena;
+    # 15 x 15 with batch 8; ...): the engine's staggered mode without restarts -- every game on its own minibatch clock, the same games, evener
     # launches.  Several generations keep the lock-step engine, whose drain restarts the slots.
-    A = game.action_space
-    lpd = 8 if A == 7 else 16 if A <= 16 else 32 if A <= 32 else 64
-    stagger = G == n_games and mcts_batch_size * lpd == 64 and not evict
+    from caro_ai_amd.engine import staggered_geometry
+    stagger = G == n_games and staggered_geometry(game, mcts_batch_size, evict)
     # slot g plays uids uid_base + g, + G, + 2G, ... while they lie inside the wanted range (games_limit): no game
     # beyond it is ever started
     engine = SelfPlayEngine(game, G, net1=net1, net2=net2 if arena else None, n_stores=n_stores,

@@ -145,11 +145,11 @@ def train_neural_net(game, replay_buffer, net, optimizer, device="cuda:0", train
     return {"loss_total": sums[0], "loss_value": sums[1], "loss_policy": sums[2]}
 
 
-def staggered_ok(game, batch):
-    """the geometry staggered mode needs: one wavefront per game (batch x lanes per descent = 64)"""
-    A = game.action_space
-    lpd = 8 if A == 7 else 16 if A <= 16 else 32 if A <= 32 else 64
-    return batch * lpd == 64
+def staggered_ok(game, batch, evict=False):
+    """the geometry staggered mode needs: whole wavefronts per game (batch x lanes per descent a multiple of 64; with
+    eviction: above 64)"""
+    from caro_ai_amd.engine import staggered_geometry
+    return staggered_geometry(game, batch, evict)
 
 
 # The engines of self_play, kept between calls (the reference builds its MCTS store once, train.py:185, and plays every
@@ -175,7 +175,7 @@ def _engine_for(game, G, batch, searches, device, stagger, run, hip, reuse, node
     # (boards whose no-overflow bound is beyond a default tree run with eviction, as lib.utils.play_games does)
     evict = not node_cap and searches * batch * hw + 64 > SelfPlayEngine.DEFAULT_CAP_LIMIT
     cap = int(node_cap) if node_cap else SelfPlayEngine.default_node_cap(searches, batch, hw, evict)
-    stagger = bool(stagger) and not evict
+    stagger = bool(stagger) and staggered_ok(game, batch, evict)
     key = (type(game).__name__, game.kind, game.n, game.k, G, batch, cap, evict, stagger, str(torch.device(device)))
     eng = _ENGINES.pop(key, None) if reuse else None
     if eng is not None and eng.h:

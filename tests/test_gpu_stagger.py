@@ -116,17 +116,20 @@ def test_staggered_launches_carry_an_even_leaf_count():
 def test_staggered_mode_refuses_what_it_cannot_do():
     from caro_ai_amd import _lib
     game = _game_of({"kind": "c4"})
-    with pytest.raises(_lib.CaroError):  # eviction uses the second key table
+    with pytest.raises(_lib.CaroError):  # eviction inside the ply exists in the multi-wavefront kernel only (batch x lanes > 64)
         _engine(game, 8, [_synth(game, "fused")], max_batch=8, stagger=True, searches_hint=5, evict=True, node_cap=256)
     eng = _engine(game, 8, [_synth(game, "fused")], max_batch=8, stagger=True, searches_hint=5)
-    with pytest.raises(_lib.CaroError):  # batch x lanes per descent must be 64
+    with pytest.raises(_lib.CaroError):  # batch x lanes per descent must be a multiple of 64 (4 x 8 = 32 is not)
         eng.L.caro_search_staggered.restype  # (binding exists)
         _lib.check(eng.L.caro_search_staggered(eng.h, eng.evaluators[0].h, None, 1, 4, eng.planes.data_ptr(), None,
                                                eng._probs.data_ptr(), eng._values.data_ptr(), None))
     eng.close()
+    g5 = _game_of({"kind": "mnk", "n": 5, "k": 4})
+    with pytest.raises(_lib.CaroError):  # 5 x 5 with batch 3: 96 lanes, not whole wavefronts
+        _engine(g5, 4, [_synth(g5, "fused")], max_batch=3, stagger=True, searches_hint=5)
     g15 = _game_of({"kind": "mnk", "n": 15, "k": 5})
-    with pytest.raises(_lib.CaroError):  # 15 x 15 with batch 8 is eight wavefronts per game
-        _engine(g15, 4, [_synth(g15, "fused")], max_batch=8, stagger=True, searches_hint=5)
+    ok = _engine(g15, 4, [_synth(g15, "fused")], max_batch=8, stagger=True, searches_hint=5, evict=True, node_cap=512)
+    ok.close()  # (eight wavefronts per game with eviction: accepted since round 6)
     lock = _engine(game, 8, [_synth(game, "fused")], max_batch=8, searches_hint=5)
     assert lock.L.caro_search_staggered(lock.h, lock.evaluators[0].h, None, 1, 8, lock.planes.data_ptr(), None,
                                         lock._probs.data_ptr(), lock._values.data_ptr(), None) == -71  # lock-step engine
@@ -442,3 +445,55 @@ def test_train_self_play_plays_the_same_games_staggered_and_lock_step(n_games, c
     # the empty board opens every game: exactly n_games such rows (a dropped or half-played game would show here)
     empty = np.array([game.to_keys([game.initial_state])[0]]).view(np.uint8).tobytes()
     assert sum(1 for r in rows[1][0] if r.startswith(empty)) == n_games
+
+
+# ------------------------------------------------------------------ round 6: several wavefronts per game, eviction
+@pytest.mark.parametrize("d,G,n_fin,S,B,ns,kw", [
+    ({"kind": "mnk", "n": 15, "k": 5}, 6, 9, 5, 8, 1, {"evict": True}),    # config 4's geometry: eight wavefronts, eviction
+    ({"kind": "mnk", "n": 15, "k": 5}, 5, 7, 4, 4, 2, {}),                  # four wavefronts, one tree per player, no eviction
+    ({"kind": "mnk", "n": 3, "k": 3}, 48, 200, 9, 8, 1, {}),                # TicTacToe with the reference's batch of 8: two wavefronts, draws
+    ({"kind": "mnk", "n": 10, "k": 5}, 8, 12, 5, 4, 1, {"evict": True}),    # two actions per lane
+    ({"kind": "c4"}, 24, 60, 6, 16, 2, {"evict": True}),                    # connect four with 16 descents: two wavefronts
+])
+def test_staggered_multi_wave_games_vs_oracle(d, G, n_fin, S, B, ns, kw):
+    """the staggered schedule on geometries with several wavefronts per game (k_tree_stag_mw; round 6), with the eviction
+    inside the kernel's ply where it is on: every finished game -- first generation of its slot or a later one -- equals
+    the oracle's game of the same uid (result, steps, boards, float64 pi, z)"""
+    c, ref, games = _check_against_oracle(d, G, n_fin, 3, S, B, ns, seed=31, uid_base=400, form="fused",
+                                          salts=(0x1111, 0x2222) if ns == 2 else None, stagger=True, searches_hint=S, **kw)
+    assert len(games) >= n_fin and c["overflows"] == 0
+    assert games[:, 0].max() >= 400 + G  # a slot restarted in-kernel
+    if d.get("n") == 3:
+        assert (games[:, 2] == 0).any()  # drawn games among them
+
+
+def test_staggered_eviction_keeps_the_live_nodes_small_and_equals_lock_step():
+    """config 4's shape in small: a staggered engine with eviction and a lock-step engine with eviction play the same
+    games (uids, tuples) -- and the staggered one's trees hold what survives its own plies, never more than the cap"""
+    d = {"kind": "mnk", "n": 15, "k": 5}
+    game = _game_of(d)
+    G, S, B = 6, 6, 8
+    kw = dict(max_batch=B, steps_before_tau_0=4, seed=8, uid_base=90, searches_hint=S, evict=True, node_cap=600)
+    lock = _engine(game, G, [_synth(game, "fused")], **kw)
+    tl, gl = lock.play_until(S, B, n_finished=8)
+    lock.close()
+    stag = _engine(game, G, [_synth(game, "fused")], stagger=True, **kw)
+    ts, gs = stag.play_until(S, B, n_finished=8)
+    live = stag.tree_live()
+    c = stag.counters()
+    stag.close()
+    assert c["overflows"] == 0 and live.max() <= 600
+
+    def by_uid(tuples, games):
+        out, off = {}, 0
+        PI = np.concatenate([t["pi"] for t in tuples]); ST = np.concatenate([t["states"] for t in tuples])
+        for uid, first, result, steps in games.tolist():
+            n = steps + 1
+            out[uid] = (first, result, steps, ST[off:off + n].tobytes(), PI[off:off + n].tobytes())
+            off += n
+        return out
+    a, b = by_uid(tl, gl), by_uid(ts, gs)
+    common = sorted(set(a) & set(b))
+    assert len(common) >= 6
+    for uid in common:
+        assert a[uid] == b[uid], uid

@@ -48,10 +48,10 @@ def main():
         kw = {}
         A = 7 if d["kind"] == "c4" else cells
         lpd = 8 if A == 7 else 16 if A <= 16 else 32 if A <= 32 else 64
-        if form == "fused" and B * lpd == 64 and rng.random() < 0.5:
-            kw.update(stagger=True, searches_hint=S)   # the schedule bench.py runs: every game on its own minibatch clock
-        elif rng.random() < 0.3:
+        if rng.random() < 0.3:
             kw["evict"] = True
+        if form == "fused" and B * lpd >= 64 and (B * lpd) % 64 == 0 and (B * lpd > 64 or "evict" not in kw) and rng.random() < 0.5:
+            kw.update(stagger=True, searches_hint=S)   # every game on its own minibatch clock: k_tree_stag / k_tree_stag_mw
         if form == "fused" and rng.random() < 0.5:
             kw["one_call"] = True  # search + ply through caro_search_move (the multi-wave kernel's closing launch makes the ply)
         if rng.random() < 0.3:     # exactly n_finish games (caro_config.games_limit): nothing beyond them is started

@@ -17,7 +17,7 @@ import os
 import sys
 from collections import defaultdict
 
-SHORT = ["k_tree_stag", "k_tree_mw", "k_tree", "k_net_heads", "k_net_forward_w2", "k_net_forward_w", "k_net_forward", "k_select", "k_expand_backup", "k_encode",
+SHORT = ["k_tree_stag_mw", "k_tree_stag", "k_tree_mw", "k_tree", "k_net_heads", "k_net_forward_w2", "k_net_forward_w", "k_net_forward", "k_select", "k_expand_backup", "k_encode",
          "k_step", "k_drain_copy", "k_drain_scan", "k_evict", "k_net_hash"]
 
 
