@@ -1713,7 +1713,13 @@ __device__ __forceinline__ void evict_body(const View& v, int g, const typename 
   using R = typename GEO::R;
   using Board = typename R::Board;
   constexpr int AP = GEO::AP, KW = GEO::KW;
-  __shared__ int s_cnt;
+  // Round by round the block looks at blockDim slots of the old table: a thread whose slot holds a survivor claims a
+  // slot of the new table (all keys are distinct: atomicCAS on word 0), writes the key there and QUEUES the pair
+  // (old slot, new slot); then the whole block copies the queued rows together -- coalesced 16-byte accesses, AP of
+  // them per row.  (One thread per row, 256 loads and stores in a chain on the 15 x 15 board, made the slowest block
+  // of a launch ~180 us long once the eviction rode inside the staggered kernel's ply.)
+  __shared__ int s_cnt, s_nq;
+  __shared__ int2 s_q[1024];
   for (int st = 0; st < v.n_stores; ++st) {
     const int t = g * v.n_stores + st;
     const int live = v.tbl[t];
@@ -1721,30 +1727,42 @@ __device__ __forceinline__ void evict_body(const View& v, int g, const typename 
     uint64_t* okeys = v.node_key + ob * KW;
     uint64_t* nkeys = v.node_key + nb * KW;
     const uint32_t mask = (uint32_t)v.hcap - 1u;
-    if (threadIdx.x == 0) s_cnt = 0;
+    if (threadIdx.x == 0) { s_cnt = 0; s_nq = 0; }
     __syncthreads();
-    int mine = 0;
-    for (int i = threadIdx.x; i < v.hcap; i += blockDim.x) {
-      uint64_t* k = okeys + (size_t)i * KW;
-      if (k[0] == EMPTY_KEY) continue;
-      const Board b = load_board<R>(k);
-      k[0] = EMPTY_KEY;  // the old table ends up empty
-      if (!done && R::contains(v.gp, b, root)) {
-        uint32_t j = home_slot<R>(v, t, b);
-        for (int it = 0; it < v.hcap; ++it) {  // claim a slot: all inserted keys are distinct
-          unsigned long long* w0 = (unsigned long long*)(nkeys + (size_t)j * KW);
-          if (atomicCAS(w0, (unsigned long long)EMPTY_KEY, (unsigned long long)b.w[0]) == (unsigned long long)EMPTY_KEY) break;
-          j = (j + 1u) & mask;
+    for (int base = 0; base < v.hcap; base += blockDim.x) {  // uniform trip count: barriers inside
+      const int i = base + (int)threadIdx.x;
+      if (i < v.hcap) {
+        uint64_t* k = okeys + (size_t)i * KW;
+        if (k[0] != EMPTY_KEY) {
+          const Board b = load_board<R>(k);
+          k[0] = EMPTY_KEY;  // the old table ends up empty
+          if (!done && R::contains(v.gp, b, root)) {
+            uint32_t j = home_slot<R>(v, t, b);
+            for (int it = 0; it < v.hcap; ++it) {
+              unsigned long long* w0 = (unsigned long long*)(nkeys + (size_t)j * KW);
+              if (atomicCAS(w0, (unsigned long long)EMPTY_KEY, (unsigned long long)b.w[0]) == (unsigned long long)EMPTY_KEY) break;
+              j = (j + 1u) & mask;
+            }
+            for (int w = 1; w < KW; ++w) nkeys[(size_t)j * KW + w] = b.w[w];
+            s_q[atomicAdd(&s_nq, 1)] = make_int2(i, (int)j);
+          }
         }
-        for (int w = 1; w < KW; ++w) nkeys[(size_t)j * KW + w] = b.w[w];
-        const uint4* src = reinterpret_cast<const uint4*>(v.edges + (ob + i) * 4 * AP);
-        uint4* dst = reinterpret_cast<uint4*>(v.edges + (nb + j) * 4 * AP);
-        for (int q = 0; q < AP; ++q) dst[q] = src[q];  // 4*AP dwords = AP uint4
-        ++mine;
       }
+      __syncthreads();
+      const int nq = s_nq;
+      for (int idx = threadIdx.x; idx < nq * AP; idx += blockDim.x) {
+        const int e = idx / AP, q = idx - e * AP;
+        const int2 pr = s_q[e];
+        reinterpret_cast<uint4*>(v.edges + (nb + pr.y) * 4 * AP)[q] =
+            reinterpret_cast<const uint4*>(v.edges + (ob + pr.x) * 4 * AP)[q];
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        s_cnt += nq;
+        s_nq = 0;
+      }
+      __syncthreads();
     }
-    if (mine) atomicAdd(&s_cnt, mine);
-    __syncthreads();
     if (threadIdx.x == 0) {
       v.n_nodes[t] = s_cnt;
       v.tbl[t] = 1 - live;

@@ -368,8 +368,11 @@ int caro_search_move(caro_engine* h, caro_net* net0, caro_net* net1, int searche
  * `searches` minibatches are done (lib/utils.py:80-99), and a finished game is parked (record + history rows copied
  * aside) and its slot restarted at once (uid += uid_stride) when `recycle` != 0.  Every launch then carries the
  * same mix of minibatch indices.  Game by game the results are those of caro_search_batch + caro_step: the same
- * minibatches on the same tree with the same noise keys.  Needs the one-wavefront-per-game geometry (batch x lanes
- * per descent = 64: connect four with batch 8), generated noise / move uniforms, no eviction; a fresh engine.
+ * minibatches on the same tree with the same noise keys.  Needs whole wavefronts per game (batch x lanes per descent a
+ * multiple of 64: connect four with batch 8 = one wavefront, k_tree_stag; several wavefronts -- TicTacToe with batch 8,
+ * 15 x 15 with batch 8 -- k_tree_stag_mw, round 6), generated noise / move uniforms, a fresh or restarted engine.
+ * caro_config.evict combines with it where several wavefronts serve a game: the eviction then runs inside the kernel,
+ * right behind the game's ply (a finished game drops every node, which also leaves both key tables clean for the restart).
  *   caro_config.stagger     = mcts_searches at caro_engine_create (fixed for the engine's life)
  *   caro_search_staggered   `launches` x (tree kernel -> net kernel); on average every game moves once per
  *                           `searches` launches

@@ -139,12 +139,13 @@ def test_staggered_mode_refuses_what_it_cannot_do():
 def test_train_self_play_staggered_fills_the_replay_buffer():
     """train.self_play(stagger=True) -- the CLI's throughput form (train.py:25-59's loop, all games at once): at least
     n_games finished games reach the device replay buffer with well-formed rows, and -- connect four, batch 8 -- the
-    staggered engine is really what ran.  The same call on a geometry without one wavefront per game falls back to
-    lock-step."""
+    staggered engine is really what ran.  The same call on TicTacToe with the reference's batch of 8 (two wavefronts per
+    game: the multi-wavefront staggered kernel since round 6)."""
     from caro_ai_amd import train
     from caro_ai_amd.lib.model import Net
     game = _game_of({"kind": "c4"})
-    assert train.staggered_ok(game, 8) and not train.staggered_ok(_game_of({"kind": "mnk", "n": 3, "k": 3}), 8)
+    assert train.staggered_ok(game, 8) and train.staggered_ok(_game_of({"kind": "mnk", "n": 3, "k": 3}), 8)  # (3x3: two wavefronts)
+    assert not train.staggered_ok(_game_of({"kind": "mnk", "n": 3, "k": 3}), 3) and not train.staggered_ok(game, 8, evict=True)
     torch.manual_seed(1)
     net = Net(game.obs_shape, game.action_space).to(DEV).eval()
     rb = train.DeviceReplayBuffer(game, 20000, DEV)
