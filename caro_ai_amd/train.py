@@ -622,6 +622,7 @@ def main(argv=None):
         log=lambda m: print(m, flush=True),
         concurrent=args.concurrent or min(args.games, 1024), stream=not args.exact_self_play)
     writer.close()
+    release_engines()  # (the self-play engines are kept between iterations: gigabytes of tree tables)
 
 
 if __name__ == "__main__":
