@@ -431,3 +431,31 @@ def test_multi_wave_fused_kernel_and_search_move_equal_search_plus_step(d, B):
         ref = _oracle_games(d, sorted(A_)[:3], seed, 3, S, B, 1)
         for uid, r in ref.items():
             assert A_[uid][:3] == (r["first"], r["result"], r["steps"]), uid
+
+
+def test_bench_under_torchrun_two_ranks_on_one_gpu():
+    """the DRIVER's launch form for N > 1 -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W -- as two gloo ranks sharing the one GPU: one JSON
+    line from rank 0, n_gpus 2, weak scaling, the dist record with both ranks, value = the sum of what the ranks played
+    over the max-over-ranks time"""
+    import json
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, PYTHONPATH=ROOT, CARO_SHARE_GPU="1", CARO_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--games", "128"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines  # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["warmup"] == 2
+    assert d["dist"]["world_size"] == 2 and d["dist"]["backend"] == "gloo" and len(d["dist"]["ranks"]) == 2
+    assert d["cpu_baseline"] is None and d["train_loop"] is None  # N = 1 only
+    assert d["value"] > 0 and d["overflows"] == 0 and abs(d["per_gpu"] * 2 - d["value"]) < 1e-6 * d["value"]
