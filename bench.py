@@ -650,6 +650,12 @@ def train_loop_record(args, device, headline, games=4096, concurrent=1024):
             "seconds_play", "seconds_gather", "engine_reused", "passes")
     cold, warm = ({k: c[k] for k in keep} for c in calls)
     return {"speed_nodes": cold["speed_nodes_wall"], "unit": "node-expansions/s", "frac_of_headline": cold["speed_nodes_wall"] / headline,
+            # what `python -m caro_ai_amd.train` itself runs (its default is the stream form): the FIRST call -- engine
+            # construction, HipNet, the stream's ramp inside -- and a later one
+            "cli_default": {"form": "stream", "speed_nodes_first_call": stream[0]["speed_nodes_wall"],
+                            "frac_of_headline_first_call": stream[0]["speed_nodes_wall"] / headline,
+                            "speed_nodes": stream[-1]["speed_nodes_wall"],
+                            "frac_of_headline": stream[-1]["speed_nodes_wall"] / headline},
             "reused": dict(warm, speed_nodes=warm["speed_nodes_wall"], frac_of_headline=warm["speed_nodes_wall"] / headline),
             "cold": cold,
             "stream": {"speed_nodes": stream[-1]["speed_nodes_wall"], "frac_of_headline": stream[-1]["speed_nodes_wall"] / headline,

@@ -212,13 +212,13 @@ def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0,
     What changes against `self_play`: WHEN a game's tuples arrive (a long game may land one iteration later), not
     which games are played or how.  When the net's weights have changed since the stream was started (a promotion),
     the games in flight belong to the old net: the stream is restarted (they are dropped, at most one game per slot).
-    Needs the staggered geometry (one wavefront per game).  Returns what self_play returns; `nodes` / `speed_nodes`
+    Needs the staggered geometry (whole wavefronts per game: `staggered_ok`).  Returns what self_play returns; `nodes` / `speed_nodes`
     count the node-expansions of this call's launches (incl. the part of the in-flight games played in it)."""
     from caro_ai_amd import net_hip
     t_call = time.time()
     rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
     if not staggered_ok(game, batch):
-        raise _lib.CaroError("self_play_stream needs the one-wavefront-per-game geometry (connect four with batch 8, ...)")
+        raise _lib.CaroError("self_play_stream needs whole wavefronts per game (batch x lanes per descent a multiple of 64)")
     G = max(1, int(concurrent or n_games))
     stride = world * G
     hip = net_hip.hipnet_for(net, device)
