@@ -280,11 +280,15 @@ def test_hot_kernels_do_not_spill():
     net = _code_object_metadata("caro_net.hip.o")
     eng = _code_object_metadata("caro_engine.hip.o")
     seen = 0
-    for md, wanted in ((net, ("k_net_forward_w2", "k_net_forward_wE", "k_net_heads")), (eng, ("k_tree_stag", "k_treeI"))):
+    # (mangled names: "11k_tree_stagI" is k_tree_stag alone, not k_tree_stag_mw; "9k_tree_mwI": config 4's tree kernel)
+    for md, wanted in ((net, ("k_net_forward_w2", "k_net_forward_wE", "k_net_heads")),
+                       (eng, ("11k_tree_stagI", "6k_treeI", "9k_tree_mwI"))):
         for name, k in md.items():
             if any(w in name for w in wanted):
                 assert k[".vgpr_spill_count"] == 0 and k[".vgpr_count"] <= 256, (name, k[".vgpr_spill_count"])
-                if md is net or "C4Rules" in name:  # (the m,n,k tree kernels index small per-thread arrays: scratch, no spill)
+                # (the m,n,k tree kernels index small per-thread arrays: scratch, no spill; so does the multi-wave kernel's
+                # general-form ply on connect four, which no bench leg runs)
+                if md is net or ("C4Rules" in name and "k_tree_mw" not in name):
                     seen += 1
                     assert k[".private_segment_fixed_size"] == 0, (name, k[".private_segment_fixed_size"])
     assert seen >= 5
