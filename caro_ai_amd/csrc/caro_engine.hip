@@ -108,6 +108,11 @@ struct View {
   // staggered mode (caro_stagger_enable; k_tree_stag): every game runs its own minibatch clock
   int stag_S;           // minibatches per move (0: lock-step engine)
   int stag_recycle;     // finished games restart in-kernel (uid += uid_stride)
+  int stag_pool;        // caro_config.stagger_recycle == 2 (with games_limit): a finished slot does not restart in-kernel
+                        // with ITS next uid but waits (done = 2) for the next drain, where k_stag_assign hands the free
+                        // slots the next games not started yet, in slot order (deterministic): the slots stay busy until
+                        // the wanted games run out, whatever the lengths of the games a slot happened to get
+  int32_t* handed;      // [1] staggered pool mode: local indices of the wanted set handed out so far
   int32_t* lm;          // [G] index of the game's next minibatch, 0..stag_S (== stag_S: the move is due)
   int32_t* pend;        // [G] 1: a selected minibatch awaits its expand + backup
   int32_t* wait;        // [G] launches the game still sits out before its first search (the initial stagger)
@@ -1927,7 +1932,7 @@ __device__ __forceinline__ bool park_and_restart(const View& v, int g, GameRegs<
     v.pk_flag[g] = 1;
   }
   block_sync<ONE>();  // the live record has been read by every thread
-  if (!v.stag_recycle || !game_wanted(v, g, uid + v.uid_stride)) {
+  if (!v.stag_recycle || v.stag_pool || !game_wanted(v, g, uid + v.uid_stride)) {
     if (threadIdx.x == 0) v.done[g] = 2;  // no restart asked for: parked, the slot stays finished
     gr.done = 2;
     return false;
@@ -2140,8 +2145,71 @@ __global__ void k_tree_stag_mw(View v, int B, const float* __restrict__ probs, c
   }
 }
 
+// Staggered pool mode (caro_config.stagger_recycle == 2), part of every drain: the slots whose game is over and parked
+// (done == 2) get the next local indices of the wanted set that have not been started yet -- in slot order, by one
+// block: which slot plays which game is a function of the games' progress alone.  Local index i = uid
+// uid_base + i % G + (i / G) * uid_stride: the same SET of games the static layout plays.  The slot's trees move to their
+// other, clean key table (the one left behind is cleared by k_stag_clean, launched right behind this kernel).
+template <class GEO>
+__global__ void k_stag_assign(View v) {
+  using R = typename GEO::R;
+  constexpr int KW = GEO::KW;
+  __shared__ int s_c[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (v.G + 1023) / 1024;
+  const int lo = tid * chunk, hi = min(v.G, lo + chunk);
+  int c = 0;
+  for (int g = lo; g < hi; ++g) c += v.done[g] == 2;
+  s_c[tid] = c;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int a = tid >= d ? s_c[tid - d] : 0;
+    __syncthreads();
+    s_c[tid] += a;
+    __syncthreads();
+  }
+  const int handed = v.handed[0];
+  long long idx = (long long)handed + (s_c[tid] - c);
+  const int total = s_c[1023];
+  __syncthreads();
+  for (int g = lo; g < hi; ++g) {
+    if (v.done[g] != 2) continue;
+    if (idx < v.games_limit) {
+      const uint64_t uid = v.uid_base + (uint64_t)(idx % v.G) + (uint64_t)(idx / v.G) * v.uid_stride;
+      const int fp = v.first_mode == 2 ? (int)(uid & 1ull) : v.first_mode;
+      for (int st = 0; st < v.n_stores; ++st) {
+        const int t = g * v.n_stores + st;
+        if (v.etab != 2) {  // (with eviction both tables are clean already: the finished game's ply dropped every node)
+          v.tbl[t] = 1 - v.tbl[t];
+          v.dirty[t] = 1;
+        }
+        v.n_nodes[t] = 0;
+        v.n_created[t] = 0;
+      }
+      store_board<R>(v.root + (size_t)g * KW, R::initial(v.gp));
+      v.player[g] = fp;
+      v.first[g] = fp;
+      v.ply[g] = 0;
+      v.step[g] = 0;
+      v.uid[g] = uid;
+      v.result[g] = 0;
+      v.final_r[g] = 0;
+      v.lm[g] = 0;
+      v.pend[g] = 0;
+      v.wait[g] = 0;
+      v.done[g] = 0;
+    }
+    ++idx;
+  }
+  if (tid == 0) {
+    const long long h = (long long)handed + total;
+    v.handed[0] = (int)(h < v.games_limit ? h : v.games_limit);
+  }
+}
+
 __global__ void k_stag_init(View v) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g == 0 && v.handed) v.handed[0] = (int)(v.games_limit > 0 && v.games_limit < v.G ? v.games_limit : v.G);
   if (g >= v.G) return;
   v.lm[g] = 0;
   v.pend[g] = 0;
@@ -2674,6 +2742,7 @@ static void apply_run_params(caro_engine* h, const caro_config* cfg) {
   if (cfg->stagger > 0) {
     v.stag_S = cfg->stagger;
     v.stag_recycle = cfg->stagger_recycle ? 1 : 0;
+    v.stag_pool = (cfg->stagger_recycle == 2 && cfg->games_limit > 0) ? 1 : 0;
   }
 }
 // everything a fresh engine starts from, enqueued on `stream`: games at the initial position, empty trees (every key
@@ -2801,6 +2870,7 @@ int caro_engine_create(const caro_config* cfg, caro_engine** out) {
     DA(v.lm, G); DA(v.pend, G); DA(v.wait, G); DA(v.dirty, T);
     DA(v.pk_flag, G); DA(v.pk_ply, G); DA(v.pk_final_r, G); DA(v.pk_first, G); DA(v.pk_result, G); DA(v.pk_step, G);
     DA(v.pk_uid, G);
+    DA(v.handed, 1);
     DA(v.ph_key, G * v.maxply * KW);
     DA(v.ph_player, G * v.maxply);
     DA(v.ph_pi, G * v.maxply * v.A);
@@ -3065,6 +3135,8 @@ int caro_drain_parked_begin(caro_engine* h, int64_t cap, uint64_t* states, int32
   hipLaunchKernelGGL(k_drain_scan, dim3(1), dim3(1024), 0, st, pv, (long long)cap);
   DISPATCH(h->var, hipLaunchKernelGGL(k_drain_copy<GEO>, dim3(pv.G), dim3(256), 0, st, pv, states, players, pi, z,
                                       games, 0));
+  if (h->v.stag_pool)
+    DISPATCH(h->var, hipLaunchKernelGGL(k_stag_assign<GEO>, dim3(1), dim3(1024), 0, st, h->v));
   DISPATCH(h->var, hipLaunchKernelGGL(k_stag_clean<GEO>, dim3(h->v.G * h->v.n_stores), dim3(256), 0, st, h->v));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(h->pinned64 + 8, h->v.dr_tot, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));

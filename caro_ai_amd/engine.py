@@ -120,7 +120,9 @@ class SelfPlayEngine:
         if self.stagger and not self.async_net:
             raise _lib.CaroError("stagger=True needs device-side evaluators (the fused HIP net or HashNet)")
         c.stagger = self.stag_S if self.stagger else 0
-        c.stagger_recycle = 1 if stagger_recycle else 0
+        # (2 = pool mode, with games_limit: finished slots are handed the next games not started yet at every drain
+        # instead of restarting with their own next uid -- caro_config.stagger_recycle)
+        c.stagger_recycle = int(stagger_recycle)
         c.games_limit = int(games_limit or 0)
         self.stagger_recycle = bool(stagger_recycle)
         self.cfg = c
@@ -183,7 +185,7 @@ class SelfPlayEngine:
             self.flush()
         c = self.cfg
         for k, val in run.items():
-            setattr(c, k, (1 if val else 0) if k == "stagger_recycle" else val)
+            setattr(c, k, int(val) if k == "stagger_recycle" else val)
         if searches is not None and self.stagger:
             self.stag_S = int(searches)
             c.stagger = self.stag_S

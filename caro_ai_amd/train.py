@@ -306,14 +306,15 @@ def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0,
 
 
 def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0, searches=cfg.MCTS_SEARCHES,
-              batch=cfg.MCTS_BATCH_SIZE, concurrent=None, stagger=False, reuse=True, node_cap=None):
+              batch=cfg.MCTS_BATCH_SIZE, concurrent=None, stagger=False, reuse=True, node_cap=None, pool=True):
     """Play n_games (per rank) with the (best) net against itself, tuples appended on the device.
     Returns speed_steps, speed_nodes, steps, nodes (train.py:49-58) on the wall clock of the WHOLE call -- engine
     construction or restart, weight upload, the games, the tuple exchange --, plus where the time went.
 
-    WHICH games: slot g of this rank plays uids uid_base + rank*G + g (+ k * world * G for its k-th restart), and the
-    games played are exactly the first n_games of that sequence (local index k*G + g < n_games; the engine's
-    `games_limit`): a slot whose next game would lie beyond them stays finished, so no game outside the wanted set is
+    WHICH games: the uids uid_base + rank*G + g + k * world * G with local index k*G + g < n_games (the engine's
+    `games_limit`) -- slot g plays the k-th of them itself, or (staggered, `pool=True`, fewer slots than games) whichever
+    slot is free next is handed the next one not started yet, in slot order at every drain: the same set of games either
+    way.  A slot with no wanted game left stays finished, so no game outside the wanted set is
     ever started, every counted node-expansion belongs to a wanted game, and the replay buffer never holds a
     length-biased "first to finish" sample.  The same set whether the engine runs lock-step or staggered.
     stagger=True (the CLI's choice where the geometry allows): the engine's staggered mode -- every game on its own
@@ -331,8 +332,11 @@ def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_ba
     stagger = bool(stagger) and staggered_ok(game, batch)
     restarts = n_games > G
     base, stride = uid_base + rank * G, world * G
-    run = dict(seed=seed, uid_base=base, uid_stride=stride, games_limit=n_games, stagger_recycle=restarts,
-               steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0)
+    # (staggered with fewer slots than games: the pool form -- a finished slot is handed the next game not started yet at
+    # the next drain, so the slots stay busy until the wanted games run out; with each slot tied to its own uids g, g + G, ...
+    # the call ended with the longest chain of a slot's games: 111-115 passes for 4 096 games on 1 024 slots against 88)
+    run = dict(seed=seed, uid_base=base, uid_stride=stride, games_limit=n_games,
+               stagger_recycle=(2 if (stagger and pool) else 1) if restarts else 0, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0)
     hip = net_hip.hipnet_for(net, device)
     eng, reused = _engine_for(game, G, batch, searches, device, stagger, run, hip, reuse, node_cap)
     t_ready = time.time()

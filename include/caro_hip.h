@@ -65,7 +65,12 @@ typedef struct caro_config {
                                  not contain the new root).  Result-neutral; node_cap then bounds the LIVE nodes. */
   int32_t stagger;            /* > 0: staggered mode with this many minibatches (mcts_searches) per move -- every game
                                  on its own minibatch clock, see caro_search_staggered; 0: lock-step */
-  int32_t stagger_recycle;    /* staggered mode: a finished game's slot restarts in-kernel (uid += uid_stride) */
+  int32_t stagger_recycle;    /* staggered mode, 1: a finished game's slot restarts in-kernel (uid += uid_stride).
+                                 2 (with games_limit > 0), the POOL form: a finished slot waits for the next
+                                 caro_drain_parked_begin, which hands the free slots the next games of the wanted set that
+                                 have not been started yet, in slot order (local index i = uid uid_base + i % n_games +
+                                 (i / n_games) * uid_stride: the same set of games) -- the slots stay busy until the
+                                 wanted games run out, whatever the lengths of the games a slot happened to get */
   int64_t games_limit;        /* > 0: the engine plays exactly the games with local index k * n_games + g < games_limit
                                  (slot g, its k-th game; uid = uid_base + g + k * uid_stride): a slot whose next game
                                  would lie beyond that stays finished instead of restarting, in either schedule, and

@@ -459,3 +459,63 @@ def test_bench_under_torchrun_two_ranks_on_one_gpu():
     assert d["dist"]["world_size"] == 2 and d["dist"]["backend"] == "gloo" and len(d["dist"]["ranks"]) == 2
     assert d["cpu_baseline"] is None and d["train_loop"] is None  # N = 1 only
     assert d["value"] > 0 and d["overflows"] == 0 and abs(d["per_gpu"] * 2 - d["value"]) < 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("d,B,kw", [({"kind": "c4"}, 8, {}), ({"kind": "mnk", "n": 3, "k": 3}, 8, {}),
+                                    ({"kind": "mnk", "n": 10, "k": 5}, 4, {"evict": True})])
+def test_staggered_pool_mode_hands_free_slots_the_next_games(d, B, kw):
+    """caro_config.stagger_recycle = 2 with games_limit: a finished slot is handed the next game of the wanted set not
+    started yet (at the drain, in slot order) instead of its own next uid.  Exactly the wanted games are played, each
+    equal to the oracle's game of its uid; slots play games that are not "theirs"; and a second run is the first one
+    bit for bit (the assignment is a function of the games' progress, not of timing)."""
+    game = _game_of(d)
+    G, S, seed, base, n_games = 8, 5, 37, 300, 44
+    runs = []
+    for _ in range(2):
+        eng = _engine(game, G, [_synth(game, "fused")], max_batch=B, steps_before_tau_0=3, seed=seed, uid_base=base,
+                      searches_hint=S, stagger=True, stagger_recycle=2, games_limit=n_games,
+                      node_cap=S * B * game.obs_shape[1] * game.obs_shape[2] + 64, **kw)
+        slots = {}
+        tuples, games = [], []
+        for _ in range(400):
+            eng.search(S, B)
+            dd = eng.drain(recycle=True)
+            if int(dd["games"].shape[0]):
+                tuples.append({k: v.cpu().numpy() for k, v in dd.items() if k != "games"})
+                games.append(dd["games"].cpu().numpy())
+            for g, u in enumerate(eng.roots()[3].tolist()):
+                slots.setdefault(int(u), g)
+            if eng.live_games() == 0 and sum(len(x) for x in games) >= n_games:
+                break
+        c = eng.counters()
+        eng.close()
+        games = np.concatenate(games)
+        runs.append((tuples, games, c, slots))
+    tuples, games, c, slots = runs[0]
+    assert sorted(games[:, 0].tolist()) == list(range(base, base + n_games)) and c["finished"] == n_games and c["overflows"] == 0
+    assert any((u - base) % G != g for u, g in slots.items() if base <= u < base + n_games)  # a slot played another slot's uid
+    ref = _oracle_games(d, games[:, 0], seed, 3, S, B, 1)
+    got = _collect(tuples, games)
+    for uid, r in ref.items():
+        assert got[uid][:3] == (r["first"], r["result"], r["steps"]), uid
+    assert c["sims"] == sum(r["counters"]["sims"] for r in ref.values())
+    assert np.array_equal(runs[1][1], games) and runs[1][2] == c and _collect(runs[1][0], runs[1][1]) == got
+
+
+def test_self_play_pool_plays_the_same_games_in_fewer_passes():
+    from caro_ai_amd import train
+    game, (net, _) = _c4_nets()
+
+    def rows(rb):
+        n = len(rb)
+        rec = np.concatenate([t[:n].cpu().numpy().view(np.uint8).reshape(n, -1) for t in (rb.states, rb.players, rb.pi, rb.z)], axis=1)
+        return sorted(map(bytes, rec))
+    out = {}
+    for pool in (False, True):
+        rb = train.DeviceReplayBuffer(game, 60000, DEV)
+        sp = train.self_play(game, rb, net, 256, device=DEV, seed=2, uid_base=50, searches=6, batch=8, concurrent=32,
+                             stagger=True, pool=pool, reuse=False)
+        out[pool] = (rows(rb), sp["steps"], sp["passes"])
+        assert sp["games"] == 256
+    assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
+    assert out[True][2] < out[False][2]  # the slots stay busy: fewer passes for the same games
