@@ -3114,6 +3114,11 @@ int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int la
     prof_end(h, p0, st);
     prof_calibrate(h, st);
     if (rc) { h->prof_gate = 1; return rc; }
+    // pool form: free slots are handed their next games every fifth launch too (not only at the drain that ends a pass):
+    // a finished slot waits two or three launches, a tenth of a ply, instead of half a pass.  (The tables such a slot
+    // leaves behind are cleaned at the next drain; no slot ends two games between two drains.)
+    if (h->v.stag_pool && j % 5 == 4)
+      DISPATCH(h->var, hipLaunchKernelGGL(k_stag_assign<GEO>, dim3(1), dim3(1024), 0, st, h->v));
   }
   h->prof_gate = 1;
   return 0;
