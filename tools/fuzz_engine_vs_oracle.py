@@ -62,6 +62,8 @@ def main():
                    uid_base=int(rng.integers(0, 1 << 20)), form=form, salts=(0x1111, 0x2222) if two_nets else None, **kw)
         if cfg.get("games_limit"):
             cfg["games_limit"] = cfg["n_finish"]
+            if cfg.get("stagger") and rng.random() < 0.5:
+                cfg["stagger_recycle"] = 2  # the pool form: free slots are handed the next unstarted games (k_stag_assign)
         try:
             c, ref, g = _check_against_oracle(**cfg)
         except Exception:
