@@ -200,6 +200,55 @@ def _forget_engine(eng):
         pass
 
 
+class _Drains:
+    """what the move loop of a self-play call collects.  Nothing here waits for the GPU -- the next move is already
+    enqueued on the stream, and one synchronising read would hold the host until that move is over: counts come from
+    shapes, the game records are looked at once, after the loop (`records()`)"""
+
+    def __init__(self):
+        self.finished = self.rows = 0
+        self._records = []
+        self.gatherer = parallel.TupleGatherer(every=1 << 30, pi_dtype=torch.float32)
+
+    def take(self, d):
+        if d is None or not int(d["games"].shape[0]):
+            return
+        self.finished += int(d["games"].shape[0])
+        self.rows += int(d["z"].shape[0])
+        self._records.append(d["games"])
+        self.gatherer.push(d)
+
+    def records(self):
+        """(uid, first player, result, steps) of every drained game, on the host"""
+        return torch.cat(self._records).cpu().numpy() if self._records else np.zeros((0, 4), np.int64)
+
+    def deliver(self, replay_buffer):
+        """the exchange -- ONE collective per call, when every rank has left its rank-local loop -- and the append"""
+        out = self.gatherer.flush()
+        if out is not None:
+            replay_buffer.extend(out)
+
+
+def _abort(eng):
+    """a self-play call failed: the engine goes whatever happens (its trees are gigabytes, its state is unknown).  Under
+    several ranks the error must END this rank: the peers are on their way to the collective of `_Drains.deliver` and would
+    wait there for the backend's timeout; a rank that exits non-zero is what the launcher's fail-fast path acts on."""
+    _forget_engine(eng)
+    if parallel.is_dist():
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(13)
+
+
+def _stats(steps, nodes, dr, t_call, t_ready, t_played, reused, passes):
+    dt = time.time() - t_call
+    return {"speed_steps": steps / dt, "speed_nodes": nodes / dt, "steps": steps, "nodes": nodes, "games": dr.finished,
+            "games_dropped": 0, "rows": dr.rows, "seconds": dt, "seconds_setup": t_ready - t_call,
+            "seconds_play": t_played - t_ready, "seconds_gather": time.time() - t_played, "engine_reused": reused,
+            "passes": passes, "speed_nodes_play": nodes / max(t_played - t_ready, 1e-9)}
+
+
 def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0,
                      searches=cfg.MCTS_SEARCHES, batch=cfg.MCTS_BATCH_SIZE, concurrent=None, node_cap=None):
     """self_play as a STREAM: the engine is never stopped between calls.  Every slot restarts the moment its game ends
@@ -248,25 +297,14 @@ def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0,
     while len(_ENGINES) > ENGINE_CACHE:
         _ENGINES.popitem(last=False)[1].close()
     t_ready = time.time()
-    st = {"finished": 0, "rows": 0}
-    records = []
-    gatherer = parallel.TupleGatherer(every=1 << 30, pi_dtype=torch.float32)
-
-    def take(d):
-        if d is None or not int(d["games"].shape[0]):
-            return
-        st["finished"] += int(d["games"].shape[0])
-        st["rows"] += int(d["z"].shape[0])
-        records.append(d["games"])
-        gatherer.push(d)
-
+    dr = _Drains()
     try:
         max_passes = (hw + 4) * (-(-n_games // G)) + searches + 8
         passes = 0
         # (no flush at the end: the last enqueued pass keeps the GPU busy while the host goes on, its rows are handed
         # out by the first move() of the next call)
-        while st["finished"] < n_games and passes <= max_passes:
-            take(eng.move(searches, batch, recycle=True))
+        while dr.finished < n_games and passes <= max_passes:
+            dr.take(eng.move(searches, batch, recycle=True))
             passes += 1
         ss["passes"] += passes
         t_played = time.time()
@@ -274,35 +312,23 @@ def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0,
         if c["overflows"] > ss["c"]["overflows"]:
             raise _lib.CaroError("self_play_stream: %d minibatches overflowed the node pool (node_cap=%d)"
                                  % (c["overflows"] - ss["c"]["overflows"], eng.cfg.node_cap))
-        if st["finished"] < n_games:
-            raise _lib.CaroError("self_play_stream: %d of %d games finished after %d passes" % (st["finished"], n_games, passes))
+        if dr.finished < n_games:
+            raise _lib.CaroError("self_play_stream: %d of %d games finished after %d passes" % (dr.finished, n_games, passes))
         nodes = c["expansions"] - ss["c"]["expansions"]
         ss["c"] = {k: c[k] for k in ss["c"]}
-        recs = torch.cat(records).cpu().numpy()
+        recs = dr.records()
         if len(np.unique(recs[:, 0])) != len(recs):
             raise _lib.CaroError("self_play_stream: a game was drained twice")
         steps = int(recs[:, 3].sum())
     except BaseException:
-        _forget_engine(eng)
-        if parallel.is_dist():
-            import traceback
-            traceback.print_exc()
-            sys.stderr.flush()
-            os._exit(13)
+        _abort(eng)
         raise
     try:
-        out = gatherer.flush()
-        if out is not None:
-            replay_buffer.extend(out)
+        dr.deliver(replay_buffer)
     except BaseException:
         _forget_engine(eng)
         raise
-    dt = time.time() - t_call
-    return {"speed_steps": steps / dt, "speed_nodes": nodes / dt, "steps": steps, "nodes": nodes,
-            "games": st["finished"], "games_dropped": 0, "rows": st["rows"], "seconds": dt,
-            "seconds_setup": t_ready - t_call, "seconds_play": t_played - t_ready,
-            "seconds_gather": time.time() - t_played, "engine_reused": reused, "passes": passes,
-            "speed_nodes_play": nodes / max(t_played - t_ready, 1e-9)}
+    return _stats(steps, nodes, dr, t_call, t_ready, t_played, reused, passes)
 
 
 def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0, searches=cfg.MCTS_SEARCHES,
@@ -334,80 +360,47 @@ def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_ba
     base, stride = uid_base + rank * G, world * G
     # (staggered with fewer slots than games: the pool form -- a finished slot is handed the next game not started yet at
     # the next drain, so the slots stay busy until the wanted games run out; with each slot tied to its own uids g, g + G, ...
-    # the call ended with the longest chain of a slot's games: 111-115 passes for 4 096 games on 1 024 slots against 88)
+    # the call ended with the longest chain of a slot's games: 111-115 passes for 4 096 games on 1 024 slots against 92-94)
     run = dict(seed=seed, uid_base=base, uid_stride=stride, games_limit=n_games,
                stagger_recycle=(2 if (stagger and pool) else 1) if restarts else 0, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0)
     hip = net_hip.hipnet_for(net, device)
     eng, reused = _engine_for(game, G, batch, searches, device, stagger, run, hip, reuse, node_cap)
     t_ready = time.time()
-    st = {"finished": 0, "rows": 0}
-    records = []
-    gatherer = parallel.TupleGatherer(every=1 << 30, pi_dtype=torch.float32)
-
-    def take(d):
-        """the tuples of one drain (every drained game is a wanted one: games_limit).  Nothing here waits for the
-        GPU -- the next move is already enqueued on this stream, and a synchronising read would hold the host until
-        that move is over: counts come from shapes, the game records are looked at once, after the loop"""
-        if d is None or not int(d["games"].shape[0]):
-            return
-        st["finished"] += int(d["games"].shape[0])
-        st["rows"] += int(d["z"].shape[0])
-        records.append(d["games"])
-        gatherer.push(d)
-
+    dr = _Drains()  # (every drained game is a wanted one: games_limit)
     try:
         # one pass = `searches` launches = one ply per game (staggered: on average; a game sits out fewer than
         # `searches` launches at the start): a bound on the passes that a healthy run never reaches
         hw = game.obs_shape[1] * game.obs_shape[2]
         max_passes = (hw + 4) * (-(-n_games // G)) + 8
         passes = 0
-        while st["finished"] < n_games:
-            take(eng.move(searches, batch, recycle=restarts))  # host-pipelined: hands out the previous pass's rows
+        while dr.finished < n_games and passes <= max_passes:
+            dr.take(eng.move(searches, batch, recycle=restarts))  # host-pipelined: hands out the previous pass's rows
             passes += 1
-            if passes > max_passes:
-                break
-        take(eng.flush())
+        dr.take(eng.flush())
         t_played = time.time()
         c = eng.counters()
         if c["overflows"]:
             raise _lib.CaroError("self_play: %d minibatches overflowed the node pool (node_cap=%d) or plies were refused "
                                  "on a root without visits: the games are not the reference's" % (c["overflows"], eng.cfg.node_cap))
-        if st["finished"] < n_games:
-            raise _lib.CaroError("self_play: %d of %d games finished after %d passes" % (st["finished"], n_games, passes))
-        recs = torch.cat(records).cpu().numpy() if records else np.zeros((0, 4), np.int64)
+        if dr.finished < n_games:
+            raise _lib.CaroError("self_play: %d of %d games finished after %d passes" % (dr.finished, n_games, passes))
+        recs = dr.records()
         off = recs[:, 0] - base
         k, g = off // stride, off % stride
         if not ((off >= 0) & (g < G) & (k * G + g < n_games)).all() or len(np.unique(recs[:, 0])) != n_games:
             raise _lib.CaroError("self_play: the engine drained games outside the wanted set")
         steps = int(recs[:, 3].sum())
     except BaseException:
-        # the engine goes whatever happens (its trees are gigabytes, and its state is unknown).  Under several ranks the
-        # error must END this rank: the peers are on their way to the collective in gatherer.flush() and would wait
-        # there for the backend's timeout; a rank that exits non-zero is what the launcher's fail-fast path acts on.
-        _forget_engine(eng)
-        if parallel.is_dist():
-            import traceback
-            traceback.print_exc()
-            sys.stderr.flush()
-            os._exit(13)
+        _abort(eng)
         raise
     try:
-        # multi-GPU: the loop above is driven by rank-local counts, so the exchange is ONE collective at the end, when
-        # every rank has left its loop
-        out = gatherer.flush()
-        if out is not None:
-            replay_buffer.extend(out)
+        dr.deliver(replay_buffer)
     except BaseException:
         _forget_engine(eng)
         raise
     if not reuse:
         eng.close()
-    dt = time.time() - t_call
-    return {"speed_steps": steps / dt, "speed_nodes": c["expansions"] / dt, "steps": steps,
-            "nodes": c["expansions"], "games": st["finished"], "games_dropped": 0, "rows": st["rows"],
-            "seconds": dt, "seconds_setup": t_ready - t_call, "seconds_play": t_played - t_ready,
-            "seconds_gather": time.time() - t_played, "engine_reused": reused, "passes": passes,
-            "speed_nodes_play": c["expansions"] / max(t_played - t_ready, 1e-9)}
+    return _stats(steps, c["expansions"], dr, t_call, t_ready, t_played, reused, passes)
 
 
 def evaluate(game, challenger, champion, rounds=cfg.EVALUATION_ROUNDS, device="cuda:0", seed=0,
