@@ -1444,6 +1444,7 @@ __global__ void k_tree(View v, int B, int mb_index, const double* __restrict__ n
     noise_wave<GEO>(v, B, go, go ? v.uid[g] : 0ull, go ? (uint32_t)v.ply[g] : 0u, mb_index, s_nz, &s_flag);
     return;
   }
+  __builtin_amdgcn_s_setprio(3);  // (as in k_tree_stag: the latency-bound tree wave issues ahead of the noise waves)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     rows_next[0] = 0;
     rows_next[1] = 0;
@@ -2024,6 +2025,11 @@ __global__ void k_tree_stag(View v, int B, const float* __restrict__ probs, cons
     noise_wave<GEO>(v, B, go, go ? gr.uid : 0ull, ply_h, lm_h, s_nz, &s_flag);
     return;
   }
+  // The tree wave is a chain of memory latencies with short bursts of instructions between them; the noise waves that
+  // share its SIMD (this block's or a neighbour's) are pure float64 arithmetic.  With the issue priority raised the tree
+  // wave's bursts go first when its data arrive: +0.4 % on the headline (same-box A/B of two builds, four alternations:
+  // 8.452-8.473 M against 8.418-8.433 M; NOTES, round 6).
+  __builtin_amdgcn_s_setprio(3);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     rows_next[0] = 0;
     rows_next[1] = 0;
