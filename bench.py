@@ -449,13 +449,13 @@ class Leg:
             e1 = prof["null1"][0] * 1e-3 / prof["null1"][1]
             e2 = prof["null2"][0] * 1e-3 / prof["null2"][1]
             gap_s, ncal = min(max(2.0 * e1 - e2, 0.0), e1), prof["null1"][1]
-        timing_note = ("HIP-event pairs on the launch stream around a sample of the launches (every 12th minibatch), minus "
+        timing_note = ("HIP-event pairs on the launch stream around a sample of the launches (every 23rd minibatch), minus "
                        "what a pair adds to the kernel it brackets: %.2f us = 2 E1 - E2 of pairs around one / two launches "
                        "of an empty kernel recorded beside them (E1 %.2f us, E2 %.2f us, %d calibrations)"
                        % (gap_s * 1e6, e1 * 1e6, e2 * 1e6, ncal))
         if prof is not None and prof["select"][1] > 0:
             ms, n = prof["select"]
-            avg_s = max(ms * 1e-3 / n - gap_s, 1e-9)  # timed on a sample of the launches (every 12th minibatch, all indices equally)
+            avg_s = max(ms * 1e-3 / n - gap_s, 1e-9)  # timed on a sample of the launches (every 23rd minibatch, all indices equally)
             n_launches = steps * S * n_streams
             levels_per_launch = delta["levels"] / n_launches
             achieved = levels_per_launch * bytes_per_level / avg_s / 1e9

@@ -2613,6 +2613,7 @@ struct caro_engine {
   long long prof_n[8];
 };
 
+constexpr unsigned PROF_EVERY = 23;  // HIP-event pairs around every 23rd minibatch's launches (search_batch_impl)
 enum ProfKind { PK_SELECT = 0, PK_COMPACT = 1, PK_EXPAND = 2, PK_STEP = 3, PK_NET = 4, PK_NULL1 = 5, PK_NULL2 = 6, PK_N = 8 };
 // Calibration of the event pairs themselves.  A pair around a kernel reads  E = K + o  (o: what bracketing adds -- the
 // dispatch behind an event's barrier packet; ~3 us, rocprofv3 sees K alone).  An EMPTY pair does not measure o (two
@@ -3005,10 +3006,13 @@ static int search_batch_impl(caro_engine* h, caro_net* net0, caro_net* net1, int
   const bool fused1 = h->fused_ok && bthreads == 64;
   const bool fused = h->fused_ok && bthreads >= 64 && bthreads % 64 == 0;
   for (int mb = 0; mb < searches; ++mb) {
-    // HIP-event timing is SAMPLED: an event pair per kernel costs ~8 % of the step.  Every 12th minibatch of a
-    // counter that runs across moves: 12 is coprime to the usual 25 / 20 / 100 searches per move, so every
-    // minibatch index (the first ones after a move carry more leaves) is sampled equally often.
-    h->prof_gate = (h->prof_ctr++ % 12) == 0;
+    // HIP-event timing is SAMPLED: an event pair per kernel costs ~8 % of the step (a pair's barrier packets expose the
+    // dispatch latency that back-to-back launches hide).  Every 23rd minibatch of a counter that runs across moves: 23 is
+    // coprime to the usual 25 / 20 / 50 / 100 searches per move, so every minibatch index (the first ones after a move
+    // carry more leaves) is sampled equally often.  (Every 12th until round 6: measured, 1.2 % of the bench's value --
+    // 8.49 against 8.59 M without events, same box, three alternations; every 23rd costs half of that and still gives
+    // 21 timed launches of each kernel in the driver's 20 steps.)
+    h->prof_gate = (h->prof_ctr++ % PROF_EVERY) == 0;
     int rc = 0;
     const int32_t* counts = h->v.leaf_count;
     if (fused) {
@@ -3099,7 +3103,7 @@ int caro_search_staggered(caro_engine* h, caro_net* net0, caro_net* net1, int la
   h->stag_batch = batch;
   hipStream_t st = (hipStream_t)stream;
   for (int j = 0; j < launches; ++j) {
-    h->prof_gate = (h->prof_ctr++ % 12) == 0;  // sampled HIP-event timing, as caro_search_batch
+    h->prof_gate = (h->prof_ctr++ % PROF_EVERY) == 0;  // sampled HIP-event timing, as caro_search_batch
     int32_t* cur = h->rows + 4 * h->rows_par;
     int32_t* nxt = h->rows + 4 * (h->rows_par ^ 1);
     h->rows_par ^= 1;
