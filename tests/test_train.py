@@ -93,6 +93,48 @@ def test_train_step_equals_plain_restatement_cpu():
         assert torch.equal(a, b)
 
 
+def test_drains_collect_by_shape_and_deliver_once():
+    """the host side of a self-play call's move loop (train._Drains; CPU tensors stand in for the drained rows): empty
+    drains are skipped, counts come from SHAPES (no value is read inside the loop: the next move is already enqueued on
+    the stream), the game records come out once, and `deliver` appends every row to the replay ring in push order"""
+    from caro_ai_amd import train
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    g = ConnectFour()
+
+    def drain(n_games, rows, tag):
+        return {"games": torch.arange(n_games * 4, dtype=torch.int64).reshape(n_games, 4) + tag,
+                "states": torch.full((rows, 1), tag, dtype=torch.int64), "players": torch.zeros(rows, dtype=torch.int32),
+                "pi": torch.full((rows, 7), 1.0 / 7, dtype=torch.float64), "z": torch.ones(rows, dtype=torch.int32)}
+    dr = train._Drains()
+    dr.take(None)
+    dr.take(drain(0, 0, 0))
+    assert dr.finished == 0 and dr.rows == 0 and dr.records().shape == (0, 4)
+    dr.take(drain(2, 15, 100))
+    dr.take(drain(1, 9, 200))
+    assert (dr.finished, dr.rows) == (3, 24)
+    assert dr.records()[:, 0].tolist() == [100, 104, 200]
+    rb = train.DeviceReplayBuffer(g, 64, "cpu")
+    dr.deliver(rb)
+    assert len(rb) == 24 and rb.states[:24, 0].tolist() == [100] * 15 + [200] * 9 and rb.pi.dtype == torch.float32
+    dr.deliver(rb)  # nothing pending any more
+    assert len(rb) == 24
+
+
+def test_staggered_geometry_and_default_schedule_choices():
+    """which schedule a caller gets (engine.staggered_geometry; train.staggered_ok is the same test): whole wavefronts per
+    game, and with eviction only the multi-wavefront kernel"""
+    from caro_ai_amd.engine import lanes_per_descent, staggered_geometry
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.game.tictactoe import TicTacToe
+    c4, t3, t5, t15 = ConnectFour(), TicTacToe(3, 3), TicTacToe(5, 4), TicTacToe(15, 5)
+    assert [lanes_per_descent(x) for x in (c4, t3, t5, t15)] == [8, 16, 32, 64]
+    assert staggered_geometry(c4, 8) and staggered_geometry(c4, 16) and not staggered_geometry(c4, 4)
+    assert not staggered_geometry(c4, 8, evict=True) and staggered_geometry(c4, 16, evict=True)
+    assert staggered_geometry(t3, 4) and staggered_geometry(t3, 8) and not staggered_geometry(t3, 3)
+    assert staggered_geometry(t5, 2) and not staggered_geometry(t5, 3)
+    assert staggered_geometry(t15, 1) and staggered_geometry(t15, 8, evict=True) and not staggered_geometry(t15, 1, evict=True)
+
+
 @pytest.mark.gpu
 def test_short_training_run_end_to_end(tmp_path, monkeypatch):
     """TicTacToe: self-play on the engine -> device replay -> SGD -> arena gate -> .dat checkpoint that the
