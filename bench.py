@@ -39,9 +39,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
+MFMA_BF16_PEAK_TFS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA ~2.5 PFLOP/s dense (the extra bf16x3 leg only)
 PMC_FILE = os.path.join("profiles", "pmc_r06.json")
 CPU_RATIO_FILE = os.path.join("profiles", "cpu_ratio_r03.json")
-NET_KERNEL = {"hip": "k_net_forward", "hipw": "k_net_forward_w"}
+NET_KERNEL = {"hip": "k_net_forward", "hipw": "k_net_forward_w", "hipx3": "k_net_forward_x3"}
 
 
 def host_cores():
@@ -84,7 +85,7 @@ def pmc_status():
 
 def load_pmc(section=None):
     """HBM bytes per launch and MFMA-busy fraction from the committed PMC passes (separate rocprofv3 --pmc runs of
-    this command, tools/profile_r06.sh), by kernel; section = None (headline) | "config5" | "config4".  Empty when
+    this command, tools/profile_r06.sh), by kernel; section = None (headline) | "config5" | "config4" | "net_bf16x3" (the headline's configuration with --net hipx3).  Empty when
     the kernel sources are not the ones the passes were taken on (pmc_status)."""
     if pmc_status()[1] is not None:
         return {}
@@ -289,7 +290,7 @@ class Leg:
     """One BASELINE.json configuration: engine + nets + the move loop."""
 
     def __init__(self, args, game_name, G, S, B, arena, rank, world, device, evict=None, node_cap=0, streams=None,
-                 stream_mask=None):
+                 stream_mask=None, net=None):
         from caro_ai_amd import parallel
         from caro_ai_amd.engine import SelfPlayEngine, StreamedSelfPlay, torch_evaluator
         from caro_ai_amd.lib.game.connect_four import ConnectFour
@@ -297,6 +298,7 @@ class Leg:
         from caro_ai_amd.lib.model import GemmNet
         self.args, self.game_name, self.G, self.S, self.B, self.arena = args, game_name, G, S, B, arena
         self.rank, self.world, self.device = rank, world, device
+        self.net = net or args.net  # inference form of this leg (the labelled bf16x3 leg overrides the run's)
         if game_name == "c4":
             self.game, weights, self.sbt0 = ConnectFour(), args.weights, 10
         else:
@@ -310,16 +312,16 @@ class Leg:
             extra["evict"] = True
             extra.setdefault("node_cap", 4096)
         if arena:
-            assert game_name == "c4" and args.net in NET_KERNEL
+            assert game_name == "c4" and self.net in NET_KERNEL
             self.sbt0 = 0
             net2, wtag2 = load_net(self.game, device, os.path.join(os.path.dirname(weights), "best_025_10600.dat"))
             self.wtag += " vs " + wtag2
             extra.update(n_stores=2, first_player_mode=2)
-        self.is_hip = args.net in NET_KERNEL
+        self.is_hip = self.net in NET_KERNEL
         self.hipnet = None
         if self.is_hip:
             from caro_ai_amd.net_hip import HipNet
-            mode = {"hip": "f32", "hipw": "f32w"}[args.net]
+            mode = {"hip": "f32", "hipw": "f32w", "hipx3": "bf16x3"}[self.net]
             self.hipnet = HipNet(net, str(device), mode=mode)
             hipnets = [self.hipnet] + ([HipNet(net2, str(device), mode=mode)] if arena else [])
             make_evaluators = lambda: list(hipnets)
@@ -425,7 +427,8 @@ class Leg:
         args, game, G, S, B = self.args, self.game, self.G, self.S, self.B
         exp_all, sims_all, levels_all, plies_all, fin_all = tot
         n_streams = self.n_streams
-        section = None if (self.game_name == "c4" and G == 1024 and not self.arena and S == 25) else \
+        section = "net_bf16x3" if (self.net == "hipx3" and self.game_name == "c4" and G == 1024 and not self.arena and S == 25) else \
+            None if (self.game_name == "c4" and G == 1024 and not self.arena and S == 25) else \
             "config5" if (self.arena and G == 512 and S == 100) else \
             "config4" if (self.game_name == "gomoku15" and G == 1024 and S == 50) else "none"
         pmc = load_pmc(section) if section != "none" else {}
@@ -480,16 +483,16 @@ class Leg:
             avg_s = max(ms * 1e-3 / n - gap_s, 1e-9)
             leaves_per_launch = delta["expansions"] / (steps * S * n_streams)
             achieved = leaves_per_launch * flops_per_leaf / avg_s / 1e12
-            peak = MFMA_F32_PEAK_TFS
-            kname = NET_KERNEL[args.net]
-            if args.net == "hipw" and self.hipnet.mode == "f32w2":
+            peak = MFMA_BF16_PEAK_TFS if self.net == "hipx3" else MFMA_F32_PEAK_TFS
+            kname = NET_KERNEL[self.net]
+            if self.net == "hipw" and self.hipnet.mode == "f32w2":
                 kname = "k_net_forward_w2"  # large boards: the 2-D Winograd form
             # What the matrix pipe EXECUTES per launch.  hipw, row-Winograd F(2,3): 60 transformed taps x 32 MFMAs x
             # 8 waves x 4096 flop per workgroup of TB boards, tile padding and the last partial tile included -- 2/3 of
             # the 3x3 multiplies of the direct form; hipw on large boards, 2-D Winograd F(2x2,3x3): 80 taps x 4 blocks
             # of 32 MFMAs per board -- 4/9.  hip: the direct form executes its algorithmic count.
             executed = None
-            if args.net == "hipw":
+            if self.net in ("hipw", "hipx3"):
                 tb = self.hipnet.L.caro_net_boards_per_workgroup(self.hipnet.h)
                 wg_flops = self.hipnet.workgroup_mfma_flops()
                 executed = math.ceil(leaves_per_launch / tb) * wg_flops / avg_s / 1e12
@@ -544,9 +547,12 @@ class Leg:
             netdesc = {"f32": "fused HIP MFMA kernel k_net_forward, direct 3x3 convs,",
                        "f32w1": "fused HIP MFMA kernel k_net_forward_w, 3x3 convs in row-Winograd F(2,3) form,",
                        "f32w2": "fused HIP MFMA kernels k_net_forward_w2 + k_net_heads, 3x3 convs in 2-D Winograd "
-                                "F(2x2,3x3) form, FC heads batched 32 boards per workgroup,"}[self.hipnet.mode]
+                                "F(2x2,3x3) form, FC heads batched 32 boards per workgroup,",
+                       "bf16x3": "fused HIP MFMA kernel k_net_forward_x3, direct 3x3 convs, bf16x3 split operands, fp32 "
+                                 "accumulate (NOT bit-identical to the fp32 forms: within tests/test_gpu_net.py's tolerance);"
+                                 " conv_in, epilogues and heads in"}[self.hipnet.mode]
         else:
-            netdesc = {"gemm": "torch gather+GEMM"}[args.net]
+            netdesc = {"gemm": "torch gather+GEMM"}[self.net]
         return {
             "value": exp_all / dt, "unit": "node-expansions/s", "steps": steps, "warmup": warmup,
             "ms_per_step": ms_per_step,
@@ -690,11 +696,13 @@ def main():
     ap.add_argument("--evict", type=int, default=-1,
                     help="drop unreachable nodes after every move (result-neutral); default: on for gomoku15")
     ap.add_argument("--weights", default=os.path.join(ROOT, "caro_ai_amd", "data", "weights", "best_026_12000.dat"))
-    ap.add_argument("--net", default="hipw", choices=["hipw", "hip", "gemm"],
+    ap.add_argument("--net", default="hipw", choices=["hipw", "hip", "gemm", "hipx3"],
                     help="inference form of lib/model.py Net: hipw = fused HIP fp32 MFMA kernel, 3x3 convs in Winograd form "
                          "(row form F(2,3); 2-D form F(2x2,3x3) on 13x13 .. 15x15 boards) -- the default and the only form "
                          "that is tuned; the other two are A/B baselines: hip = the same kernel structure with direct 3x3 "
-                         "convs, gemm = PyTorch-ROCm gather + GEMM (leaf counts cross to the host)")
+                         "convs, gemm = PyTorch-ROCm gather + GEMM (leaf counts cross to the host); hipx3 = the extra bf16x3 "
+                         "split-operand form (every fp32 trunk operand as three bfloat16 parts, six part products on the bf16 "
+                         "MFMA, fp32 accumulate): not bit-identical to fp32, the line then says so in `dtype`")
     ap.add_argument("--streams", type=int, default=1,
                     help="split the games of a GPU over this many engines on separate HIP streams (tree kernels of "
                          "one part overlap the net kernel of another)")
@@ -823,6 +831,23 @@ def main():
             traceback.print_exc()
             extras["config4"] = {"error": repr(e)}
             extras_rc = 1
+        if args.net == "hipw" and args.game == "c4":
+            # A LABELLED EXTRA LEG, never the headline: the headline's configuration with the residual trunk in bf16x3
+            # split-operand arithmetic (caro_net_enable_split_bf16).  Its games are not bit-identical to the fp32 kernels'
+            # (the net's outputs differ within tests/test_gpu_net.py's tolerance), its roofline is priced against the
+            # bf16 MFMA peak, and `dtype` of this line stays "f32".
+            try:
+                x3 = side_leg("net_bf16x3", dict(game_name="c4", G=args.games, S=args.searches, B=args.batch, arena=False,
+                                                 net="hipx3"), 10, 5, not args.no_profile)
+                x3["vs_headline"] = x3["value"] / res["value"]
+                x3["note"] = ("extra leg, not the headline: lib/model.py Net with bf16x3 split operands, fp32 accumulate "
+                              "(k_net_forward_x3); 10 moves after 5 of warm-up, the headline's games and seeds")
+                extras["net_bf16x3"] = x3
+            except Exception as e:
+                import traceback
+                traceback.print_exc()
+                extras["net_bf16x3"] = {"error": repr(e)}
+                extras_rc = 1
 
     if rank == 0:
         out = {"metric": "self-play MCTS node-expansions/sec/GPU (Connect4, 200 sims/move); 1->8 GPU scaling"
@@ -830,7 +855,7 @@ def main():
                "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32"}
+               "dtype": "f32" if args.net != "hipx3" else "f32 (residual trunk: bf16x3 split operands, f32 accumulate)"}
         out.update({k: v for k, v in res.items() if k not in out})
         out["dist"] = dist_rec
         out["selfcheck"] = selfcheck

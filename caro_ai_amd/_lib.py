@@ -66,6 +66,8 @@ _SIGNATURES = {
     "caro_net_winograd2d_size": (C.c_int, []),
     "caro_net_winograd2d_supported": (C.c_int, [C.c_int, C.c_int]),
     "caro_net_enable_winograd2d": (C.c_int, [_P, _P, C.c_int64]),
+    "caro_net_split_bf16_size": (C.c_int64, []),
+    "caro_net_enable_split_bf16": (C.c_int, [_P, _P, C.c_int64]),
     "caro_net_boards_per_workgroup": (C.c_int, [_P]),
     "caro_net_stream_evictions": (C.c_int64, [_P]),
     "caro_net_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P]),

@@ -72,6 +72,7 @@ struct NetParams {
   const float* ww;      // f32w mode: [5][3 dx][2 granule halves] chunks of [4 p][2 h][64 co][16] transformed residual weights (LDS image order of trunk_w), or null
   const uint32_t* wtab; // f32w mode: [128] tile of MFMA row (row tile, lane): board | ty << 8 | x << 16 | valid << 24
   const float* ww2;     // f32w2 mode: [5][8 chunks][2 b][4 a][2 h][64 co][8] 2-D Winograd F(2x2,3x3) transformed residual weights (LDS image order of trunk_w2d), or null
+  const uint16_t* wx3;  // bf16x3 mode: [45 taps][4 c][3 parts][2 h][64 co][8 ci] bfloat16 split residual weights (k_net_forward_x3), or null
   int ncu, TB2, TB4;    // f32w mode: compute units; boards per workgroup of the 2- / 4-way K-split overflow tiles (0: off)
 };
 
@@ -674,6 +675,339 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
   }
 }
 
+// ===================================================================================================
+// Split-operand form ("bf16x3"): an EXTRA arithmetic mode, never the default and never the bench's headline.  Every
+// float32 operand of the residual trunk is written as the sum of three bfloat16 parts (hi + mid + lo = the float32 value,
+// 8 + 8 + 8 significant bits) and a product a*b is taken as the six part products of weight 2^-16 and above
+// (ah bh, ah bm, am bh, ah bl, al bh, am bm) on v_mfma_f32_32x32x16_bf16 with float32 accumulation: 12 instructions of
+// 8 passes per 16 input channels where the float32 form issues 16 of 16 passes.  The dropped products are below
+// 2^-24 of |a b|: the result is not bit-identical to the float32 kernels but within a small multiple of their own
+// rounding error (tests/test_gpu_net.py states the gate).  conv_in, the biases, the residual adds, LeakyReLU and the
+// heads stay float32 VALU code exactly as in k_net_forward.
+//   LDS: [0, 64 KB) float32 activations at both ends of the trunk, the ring of staged weight quarters in between;
+//        [64 KB, 160 KB) the split activations [3 parts][8 granules of 8 channels][256 rows][8 bf16].
+//   The weights arrive pre-split from the host: per (layer, tap) [4 c][3 parts][2 h][64 co][8 ci] bf16 (24 576 B).
+//   The MFMA takes the WEIGHTS as its first operand: a lane then owns 16 + 16 output channels of ONE row, and the
+//   epilogue reads / writes its residual in 8-byte pieces of that row.
+#ifndef CARO_X3_TIMERS
+#define CARO_X3_TIMERS 0
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int X3_Q = 3 * 2 * 64;        // uint4 (8 bf16) per quarter tap = the 16 input channels of one c: 384
+constexpr int X3_TAP_U4 = 4 * X3_Q;     // per tap image: 1536 (24 576 B)
+constexpr int X3_PAD_TAPS = 2;          // zero taps behind the image: the staging loads run two taps ahead, unconditionally
+constexpr int X3_RING13 = 3 * X3_Q;     // ring: three slots of quarter 0, then two slots of quarters 1..3
+
+// two float32 <-> two bfloat16 in one register (v_cvt_pk_bf16_f32, round to nearest even)
+__device__ __forceinline__ uint32_t pk_bf16(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ f32x2 unpk_bf16(uint32_t w) {
+  f32x2 r;
+  r.x = __builtin_bit_cast(float, w << 16);
+  r.y = __builtin_bit_cast(float, w & 0xFFFF0000u);
+  return r;
+}
+__device__ __forceinline__ void split3(f32x2 v, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  hi = pk_bf16(v);
+  const f32x2 r1 = v - unpk_bf16(hi);  // exact
+  mid = pk_bf16(r1);
+  const f32x2 r2 = r1 - unpk_bf16(mid);  // exact
+  lo = pk_bf16(r2);
+}
+__device__ __forceinline__ f32x2 join3(uint32_t hi, uint32_t mid, uint32_t lo) {
+  return (unpk_bf16(hi) + unpk_bf16(mid)) + unpk_bf16(lo);
+}
+
+__global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParams p1, const float* __restrict__ planes,
+                                                            const int32_t* __restrict__ counts, int which, int row1,
+                                                            float* __restrict__ probs, float* __restrict__ values,
+                                                            unsigned long long* __restrict__ stamps,
+                                                            const int32_t* __restrict__ gpack, int gG, int gB) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float* act = lds;
+  float* wbuf = lds + ACT;
+
+  int L, row0, board0;
+  bool second = false;
+  if (which < 2) {
+    L = counts[which];
+    row0 = which ? counts[0] : 0;
+    board0 = blockIdx.x * p0.TB;
+  } else {
+    const int L0 = counts[0];
+    const int t0 = (L0 + p0.TB - 1) / p0.TB;
+    second = (int)blockIdx.x >= t0;
+    L = second ? counts[1] : L0;
+    row0 = second ? (row1 >= 0 ? row1 : L0) : 0;
+    board0 = (second ? (int)blockIdx.x - t0 : (int)blockIdx.x) * p0.TB;
+  }
+  if (board0 >= L) return;
+  const NetParams p = second ? p1 : p0;
+  const float slope = p.slope;
+  unsigned long long t_c0 = 0, t_r0 = 0, t_epi = 0;  // diagnostic only (stamps == nullptr in every product launch)
+  if (stamps) {
+    t_c0 = __builtin_amdgcn_s_memtime();
+    t_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  const int nb = min(p.TB, L - board0);
+  const int HW = p.HW;
+  const int R = nb * HW;  // real rows
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 31, h = lane >> 5;
+
+  for (int k = tid; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = tid; k < 9 * 2 * NF; k += NT) wbuf[k] = p.w_in[k];
+  int* smap = reinterpret_cast<int*>(wbuf + 1536);
+  tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
+  conv_in_mfma(p, planes, smap, act, wbuf, R, tid);
+  const int slot_v = tid < nb ? smap[tid] : 0;
+  __syncthreads();
+
+  unsigned long long t_trunk0 = 0;
+  if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
+  // The residual stream of this lane's 32 outputs (row wave * 32 + i, channels 8 j + 4 h + 0..3) stays in float32
+  // registers across the layers: the epilogue adds to it and writes its split image for the next layer's MFMAs.
+  const int myrow = wave * 32 + i;
+  const bool rvalid = myrow < R;
+  f32x2 res[8][2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float4 v = *reinterpret_cast<const float4*>(act + myrow * NF + (((2 * j + h) ^ (myrow & 15)) << 2));
+    res[j][0] = f32x2{v.x, v.y};
+    res[j][1] = f32x2{v.z, v.w};
+  }
+  // ---- float32 activations -> three bf16 part planes (rows >= R are zero in `act`, so they are zero here)
+  uint4* parts = reinterpret_cast<uint4*>(wbuf);  // [part * 8 + g][256 rows]
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int k = tid + NT * m, row = k & 255, g = k >> 8;
+    const float4 lo4 = *reinterpret_cast<const float4*>(act + row * NF + (((2 * g) ^ (row & 15)) << 2));
+    const float4 hi4 = *reinterpret_cast<const float4*>(act + row * NF + (((2 * g + 1) ^ (row & 15)) << 2));
+    const f32x2 v[4] = {{lo4.x, lo4.y}, {lo4.z, lo4.w}, {hi4.x, hi4.y}, {hi4.z, hi4.w}};
+    uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3(v[e], ph[e], pm[e], pl[e]);
+    parts[(0 * 8 + g) * 256 + row] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+    parts[(1 * 8 + g) * 256 + row] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+    parts[(2 * 8 + g) * 256 + row] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+  }
+  __syncthreads();  // every thread is done with `act`: it becomes the weight ring
+  // The ring.  Quarter 0 of a tap (its first 16 input channels) has three slots (tap % 3), quarters 1..3 two (tap & 1):
+  // while tap t runs, the rest of tap t+1 and quarter 0 of tap t+2 are staged, so that the first operand set of tap
+  // t+1 can be requested BEFORE the barrier that ends tap t (its weights were complete one barrier earlier).
+  uint4* ring = reinterpret_cast<uint4*>(act);
+  const uint4* wsrc = reinterpret_cast<const uint4*>(p.wx3);
+  // what this thread stages per tap: items tid, tid + 512 and (tid < 128) tid + 1024 of the 1152 of quarters 1..3 of
+  // the next tap; (tid >= 128) item tid - 128 of quarter 0 of the tap after it
+  const bool stage_q0 = tid >= 128;
+  const int s2_src = stage_q0 ? X3_TAP_U4 + (tid - 128) : X3_Q + tid + 1024;  // relative to the next tap's image
+  {
+    ring[0 * X3_Q + (tid < X3_Q ? tid : 0)] = wsrc[tid < X3_Q ? tid : 0];                         // tap 0, quarter 0 (slot 0)
+    if (tid < X3_Q) ring[1 * X3_Q + tid] = wsrc[X3_TAP_U4 + tid];                                 // tap 1, quarter 0 (slot 1)
+    ring[X3_RING13 + tid] = wsrc[X3_Q + tid];                                                     // tap 0, quarters 1..3
+    ring[X3_RING13 + tid + NT] = wsrc[X3_Q + tid + NT];
+    if (tid < 128) ring[X3_RING13 + tid + 2 * NT] = wsrc[X3_Q + tid + 2 * NT];
+  }
+  __syncthreads();
+
+  const int rbi = myrow / HW;
+  const int rcell = myrow - rbi * HW;
+  const int ry = rcell / p.W, rx = rcell - ry * p.W;
+  auto neighbour = [&](int tap) {
+    const int ny = ry + tap / 3 - 1, nx = rx + tap % 3 - 1;
+    const bool ok = rvalid && ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
+    return ok ? rbi * HW + ny * p.W + nx : (int)ZROW;
+  };
+
+  int nrow9[9];  // the lane's neighbour row per tap (ZROW outside the board)
+#pragma unroll
+  for (int t = 0; t < 9; ++t) nrow9[t] = neighbour(t);
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    acc0[e] = 0.f;
+    acc1[e] = 0.f;
+  }
+  // operand sets: A_ = activation parts of the lane's neighbour row, B_ = weight parts of channels i / 32 + i
+#define CARO_X3_LOAD(S_, AB_, BB_, C_)                  \
+  S_##ah = (AB_)[(0 * 8 + 2 * (C_)) * 256];             \
+  S_##am = (AB_)[(1 * 8 + 2 * (C_)) * 256];             \
+  S_##al = (AB_)[(2 * 8 + 2 * (C_)) * 256];             \
+  S_##bh0 = (BB_)[0 * 128];                             \
+  S_##bh1 = (BB_)[0 * 128 + 32];                        \
+  S_##bm0 = (BB_)[1 * 128];                             \
+  S_##bm1 = (BB_)[1 * 128 + 32];                        \
+  S_##bl0 = (BB_)[2 * 128];                             \
+  S_##bl1 = (BB_)[2 * 128 + 32];
+#define CARO_X3_MM(W_, A_, ACC_) \
+  ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W_), __builtin_bit_cast(bf16x8, A_), ACC_, 0, 0, 0);
+  // smallest products first: the float32 accumulator takes the low-order corrections before the leading term
+#define CARO_X3_MFMA(S_)            \
+  CARO_X3_MM(S_##bm0, S_##am, acc0) \
+  CARO_X3_MM(S_##bm1, S_##am, acc1) \
+  CARO_X3_MM(S_##bl0, S_##ah, acc0) \
+  CARO_X3_MM(S_##bl1, S_##ah, acc1) \
+  CARO_X3_MM(S_##bh0, S_##al, acc0) \
+  CARO_X3_MM(S_##bh1, S_##al, acc1) \
+  CARO_X3_MM(S_##bm0, S_##ah, acc0) \
+  CARO_X3_MM(S_##bm1, S_##ah, acc1) \
+  CARO_X3_MM(S_##bh0, S_##am, acc0) \
+  CARO_X3_MM(S_##bh1, S_##am, acc1) \
+  CARO_X3_MM(S_##bh0, S_##ah, acc0) \
+  CARO_X3_MM(S_##bh1, S_##ah, acc1)
+  // Twelve MFMAs with the nine operand reads of the NEXT segment woven into their gaps, one LDS instruction behind each
+  // MFMA: issued in the shadow of an MFMA an LDS instruction costs the wave nothing; issued as a burst between the
+  // segments it holds the wave -- and with it the matrix pipe, which its partner on the SIMD is not using either, the
+  // two being in the same phase after every barrier -- for 80-150 cycles.
+#define CARO_X3_WEAVE_READS                             \
+  _Pragma("unroll") for (int q_ = 0; q_ < 9; ++q_) {    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  \
+  }                                                     \
+  __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#if CARO_X3_TIMERS  /* diagnostic build (tools/probe_clock.py): per-phase cycles of a wave, summed over the 45 taps */
+  unsigned long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = 0;
+#define CARO_T0 tl = __builtin_amdgcn_s_memtime();
+#define CARO_T(K_) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tq[K_] += t_ - tl; tl = t_; }
+#else
+#define CARO_T0
+#define CARO_T(K_)
+#endif
+  uint4 xah, xam, xal, xbh0, xbh1, xbm0, xbm1, xbl0, xbl1;
+  uint4 yah, yam, yal, ybh0, ybh1, ybm0, ybm1, ybl0, ybl1;
+  const uint4* arow = parts + h * 256;    // + neighbour row
+  const uint4* bcol = ring + h * 64 + i;  // + slot
+  CARO_X3_LOAD(x, arow + nrow9[0], bcol, 0)
+  uint4 wn0, wn1, wn2;
+  const uint4* wnext = wsrc + X3_TAP_U4;  // image of the tap after the current one
+  for (int layer = 0; layer < NRES; ++layer) {
+    float4 bq[8];  // the layer's biases of this lane's channels (8 j + 4 h + 0..3), requested two taps before their use
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // 9 taps per layer: the quarter-0 slot of a tap is tap % 3 in every layer, the slot of its quarters 1..3 alternates
+      const int cur = (layer + tap) & 1;
+      const int slot1 = (tap + 1) % 3, slot2 = (tap + 2) % 3;
+      CARO_T0
+      // issue early (the image is followed by X3_PAD_TAPS zero taps: no bounds to check)
+      wn0 = wnext[X3_Q + tid];
+      wn1 = wnext[X3_Q + tid + NT];
+      wn2 = wnext[s2_src];
+      wnext += X3_TAP_U4;
+      if (tap == 7) {
+        const float* bias = p.b_res + layer * NF;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bq[j] = *reinterpret_cast<const float4*>(bias + 8 * j + 4 * h);
+      }
+      const uint4* abase = arow + nrow9[tap];
+      const uint4* bbase = bcol + X3_RING13 + cur * X3_RING13;  // quarters 1..3 of this tap: + (c - 1) * X3_Q
+      __builtin_amdgcn_sched_barrier(0);
+      CARO_T(0)
+      CARO_X3_LOAD(y, abase, bbase, 1)
+      CARO_X3_MFMA(x)
+      CARO_X3_WEAVE_READS
+      __builtin_amdgcn_sched_barrier(0);
+      CARO_T(1)
+      CARO_X3_LOAD(x, abase, bbase + X3_Q, 2)
+      CARO_X3_MFMA(y)
+      CARO_X3_WEAVE_READS
+      __builtin_amdgcn_sched_barrier(0);
+      CARO_T(2)
+      CARO_X3_LOAD(y, abase, bbase + 2 * X3_Q, 3)
+      CARO_X3_MFMA(x)
+      CARO_X3_WEAVE_READS
+      __builtin_amdgcn_sched_barrier(0);
+      CARO_T(3)
+      {  // the staged quarters (their slots were last read one tap ago, before the barrier that ended it) and the next
+         // tap's first operand set -- at a layer's last tap that set is read again behind the epilogue
+        uint4* d13 = ring + X3_RING13 + (cur ^ 1) * X3_RING13;
+        d13[tid] = wn0;
+        d13[tid + NT] = wn1;
+        uint4* d2 = stage_q0 ? ring + slot2 * X3_Q + (tid - 128) : d13 + tid + 2 * NT;
+        *d2 = wn2;
+      }
+      CARO_X3_LOAD(x, arow + nrow9[tap == 8 ? 0 : tap + 1], bcol + slot1 * X3_Q, 0)
+      CARO_X3_MFMA(y)
+#pragma unroll
+      for (int q_ = 0; q_ < 3; ++q_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+#pragma unroll
+      for (int q_ = 0; q_ < 9; ++q_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      CARO_T(4)
+      if (tap == 8) {
+        unsigned long long t_e0 = 0;
+        if (stamps) t_e0 = __builtin_amdgcn_s_memtime();
+        __syncthreads();  // every wave has read this layer's input activations: they may be overwritten
+        // epilogue, in place: v = v + leaky(conv(v) + b)  (lib/model.py:85-89).  acc[e] of lane (i, h) = output channel
+        // (e & 3) + 8 (e >> 2) + 4 h (+ 32 in acc1) of row wave * 32 + i: four consecutive channels per 8-byte piece.
+        uint2* mine = reinterpret_cast<uint2*>(parts + myrow) + h;  // + (part * 8 + g) * 512
+        const f32x2 slope2 = {slope, slope};
+        const f32x2 keep = rvalid ? f32x2{1.f, 1.f} : f32x2{0.f, 0.f};  // rows this tile does not have stay zero
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // granule g = j: channels 8 j + 4 h + 0..3
+          const int e0 = (j & 3) * 4;
+          const f32x2 a01 = j < 4 ? f32x2{acc0[e0], acc0[e0 + 1]} : f32x2{acc1[e0], acc1[e0 + 1]};
+          const f32x2 a23 = j < 4 ? f32x2{acc0[e0 + 2], acc0[e0 + 3]} : f32x2{acc1[e0 + 2], acc1[e0 + 3]};
+          const f32x2 t01 = a01 + f32x2{bq[j].x, bq[j].y}, t23 = a23 + f32x2{bq[j].z, bq[j].w};
+          const f32x2 s01 = t01 * slope2, s23 = t23 * slope2;
+          const f32x2 l01 = {t01.x > 0.f ? t01.x : s01.x, t01.y > 0.f ? t01.y : s01.y};
+          const f32x2 l23 = {t23.x > 0.f ? t23.x : s23.x, t23.y > 0.f ? t23.y : s23.y};
+          res[j][0] = (res[j][0] + l01) * keep;
+          res[j][1] = (res[j][1] + l23) * keep;
+          uint2 wh, wm, wl;
+          split3(res[j][0], wh.x, wm.x, wl.x);
+          split3(res[j][1], wh.y, wm.y, wl.y);
+          mine[(0 * 8 + j) * 512] = wh;
+          mine[(1 * 8 + j) * 512] = wm;
+          mine[(2 * 8 + j) * 512] = wl;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          acc0[e] = 0.f;
+          acc1[e] = 0.f;
+        }
+        if (stamps) t_epi += __builtin_amdgcn_s_memtime() - t_e0;
+      }
+      CARO_T0
+      __syncthreads();  // the staged quarters / the new activations are visible to every wave
+      CARO_T(5)
+      if (tap == 8 && layer + 1 < NRES) {  // the next layer's first operand set reads the activations just written
+        CARO_X3_LOAD(x, arow + nrow9[0], bcol + slot1 * X3_Q, 0)
+      }
+    }
+  }
+#undef CARO_X3_WEAVE_READS
+#undef CARO_X3_LOAD
+#undef CARO_X3_MM
+#undef CARO_X3_MFMA
+  // ---- the trunk output back to float32 in `act` (the ring is dead: the loop ended with a barrier), then the float32
+  // heads with the parts' region as scratch
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    *reinterpret_cast<float4*>(act + myrow * NF + (((2 * j + h) ^ (myrow & 15)) << 2)) =
+        make_float4(res[j][0].x, res[j][0].y, res[j][1].x, res[j][1].y);
+  __syncthreads();
+  unsigned long long t_trunk1 = 0;
+  if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
+  heads_f32<false>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
+  if (stamps && tid == 0) {
+    stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
+    stamps[4 * blockIdx.x + 1] = ((__builtin_amdgcn_s_memrealtime() - t_r0) & 0xFFFFFull) | (t_epi << 20);  // + the five epilogues
+    stamps[4 * blockIdx.x + 2] = t_trunk0 - t_c0;
+    stamps[4 * blockIdx.x + 3] = t_trunk1 - t_c0;
+#if CARO_X3_TIMERS
+    for (int q = 0; q < 8; ++q) stamps[4 * 512 + 8 * blockIdx.x + q] = tq[q];
+#endif
+  }
+}
 
 // ===================================================================================================
 // Winograd form F(2,3) along the board rows ("f32w"): the same float32 network function with one third fewer
@@ -1888,6 +2222,7 @@ struct caro_net {
   uint32_t* wtab_dev;  // tile table (f32w mode), or null
   float* ww2_dev;      // 2-D Winograd transformed residual weights (f32w2 mode), or null
   float* wpT_dev;      // policy matrix transposed, or null
+  uint16_t* wx3_dev;   // split bfloat16 residual weights (bf16x3 mode), or null
   // f32w2 mode: the feature rows [rows][3][HW] that travel from k_net_forward_w2 to k_net_heads and the output row of
   // every dense board -- one set per stream the handle is launched on (launches on different streams may overlap)
   struct HeadRows { void* stream; float* feat; int32_t* rowl; int64_t rows; uint64_t used; } hrows[8];
@@ -1952,6 +2287,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   n->wtab_dev = nullptr;
   n->ww2_dev = nullptr;
   n->wpT_dev = nullptr;
+  n->wx3_dev = nullptr;
   n->n_hrows = 0;
   n->hrows_clock = 0;
   n->hrows_evictions = 0;
@@ -1987,6 +2323,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
   p.wtab = nullptr;
   p.ww2 = nullptr;
   p.w_pT = nullptr;
+  p.wx3 = nullptr;
   p.ncu = 0; p.TB2 = 0; p.TB4 = 0;
   if (cnet::head_span_host(HW, A) > cnet::HEAD_STAGE_MAX) {  // the policy matrix column-major for the large-board heads
     // per plane: [cell / 4][A][4], then the last HW % 4 cells as [cell][A]; a plane's image starts on a 16-byte boundary
@@ -2021,7 +2358,7 @@ int caro_net_create(int H, int W, int A, float negative_slope, const float* pack
 int caro_net_enable_winograd(caro_net* n, const float* ww_host, int64_t n_floats) {
   if (!n || !ww_host) return nfail(CARO_E_INVAL, "null argument");
   if (n->kind != 0) return nfail(CARO_E_STATE, "not a conv net");
-  if (n->p.ww2) return nfail(CARO_E_STATE, "net is already in another arithmetic mode");
+  if (n->p.ww2 || n->p.wx3) return nfail(CARO_E_STATE, "net is already in another arithmetic mode");
   const int64_t want = (int64_t)cnet::WTAPS * cnet::WCHUNK;
   if (n_floats != want) return nfail(CARO_E_INVAL, "transformed weight image has the wrong size");
   if (hipSetDevice(n->device) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
@@ -2123,7 +2460,7 @@ int caro_net_winograd2d_supported(int H, int W) {
 int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_floats) {
   if (!n || !ww2_host) return nfail(CARO_E_INVAL, "null argument");
   if (n->kind != 0) return nfail(CARO_E_STATE, "not a conv net");
-  if (n->p.ww) return nfail(CARO_E_STATE, "net is already in another arithmetic mode");
+  if (n->p.ww || n->p.wx3) return nfail(CARO_E_STATE, "net is already in another arithmetic mode");
   if (!caro_net_winograd2d_supported(n->p.H, n->p.W))
     return nfail(CARO_E_INVAL, "2-D Winograd form: boards of one per workgroup with at most 8 x 8 tiles (12x12 .. 15x15)");
   const int64_t want = (int64_t)cnet::W2NCHUNK * cnet::WCH;
@@ -2139,6 +2476,28 @@ int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_flo
   return 0;
 }
 
+/* bf16x3 mode (an extra arithmetic mode, see k_net_forward_x3): upload the residual weights split into three bfloat16
+ * parts, [45 (layer, tap)][4 c][3 parts][2 h][64 co][8 ci] uint16 with ci = 16 c + 8 h + 0..7, packed by
+ * caro_ai_amd/net_hip.py:pack_net_x3; from then on the forward calls of this net run k_net_forward_x3. */
+int64_t caro_net_split_bf16_size(void) { return (int64_t)cnet::NTAPS * cnet::X3_TAP_U4 * 8; }
+int caro_net_enable_split_bf16(caro_net* n, const uint16_t* parts_host, int64_t n_u16) {
+  if (!n || !parts_host) return nfail(CARO_E_INVAL, "null argument");
+  if (n->kind != 0) return nfail(CARO_E_STATE, "not a conv net");
+  if (n->p.ww || n->p.ww2) return nfail(CARO_E_STATE, "net is already in another arithmetic mode");
+  const int64_t want = caro_net_split_bf16_size();
+  if (n_u16 != want) return nfail(CARO_E_INVAL, "split weight image has the wrong size");
+  if (hipSetDevice(n->device) != hipSuccess) return nfail(CARO_E_HIP, "hipSetDevice failed");
+  const size_t pad = (size_t)cnet::X3_PAD_TAPS * cnet::X3_TAP_U4 * 8;  // the kernel's staging loads run two taps ahead
+  if (!n->wx3_dev) {
+    if (hipMalloc((void**)&n->wx3_dev, (want + pad) * sizeof(uint16_t)) != hipSuccess) return nfail(CARO_E_NOMEM, "hipMalloc failed");
+    if (hipMemset(n->wx3_dev + want, 0, pad * sizeof(uint16_t)) != hipSuccess) return nfail(CARO_E_HIP, "hipMemset failed");
+  }
+  if (hipMemcpy(n->wx3_dev, parts_host, want * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
+    return nfail(CARO_E_HIP, "hipMemcpy failed");
+  n->p.wx3 = n->wx3_dev;
+  return 0;
+}
+
 int64_t caro_net_stream_evictions(const caro_net* n) { return n ? n->hrows_evictions : 0; }
 
 void caro_net_destroy(caro_net* n) {
@@ -2147,6 +2506,7 @@ void caro_net_destroy(caro_net* n) {
   if (n->wtab_dev) (void)hipFree(n->wtab_dev);
   if (n->ww2_dev) (void)hipFree(n->ww2_dev);
   if (n->wpT_dev) (void)hipFree(n->wpT_dev);
+  if (n->wx3_dev) (void)hipFree(n->wx3_dev);
   for (int k = 0; k < n->n_hrows; ++k) {
     if (n->hrows[k].feat) (void)hipFree(n->hrows[k].feat);
     if (n->hrows[k].rowl) (void)hipFree(n->hrows[k].rowl);
@@ -2173,6 +2533,7 @@ int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro
   n->wtab_dev = nullptr;
   n->ww2_dev = nullptr;
   n->wpT_dev = nullptr;
+  n->wx3_dev = nullptr;
   n->n_hrows = 0;
   n->hrows_clock = 0;
   n->hrows_evictions = 0;
@@ -2242,6 +2603,9 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
     else if (n0->p.ww)
       hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B);
+    else if (n0->p.wx3)
+      hipLaunchKernelGGL(cnet::k_net_forward_x3, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
+                         counts_dev, which, row1, probs_dev, values_dev, stamps, gpack, G, B);
     else
       hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, stamps, gpack, G, B);
@@ -2252,7 +2616,8 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
 static int pair_ok(const caro_net* n0, const caro_net* n1) {
   if (n0->p.H != n1->p.H || n0->p.W != n1->p.W || n0->p.A != n1->p.A) return nfail(CARO_E_INVAL, "nets differ in shape");
   if (n0->kind != n1->kind || 
-      (n0->p.ww == nullptr) != (n1->p.ww == nullptr) || (n0->p.ww2 == nullptr) != (n1->p.ww2 == nullptr))
+      (n0->p.ww == nullptr) != (n1->p.ww == nullptr) || (n0->p.ww2 == nullptr) != (n1->p.ww2 == nullptr) ||
+      (n0->p.wx3 == nullptr) != (n1->p.wx3 == nullptr))
     return nfail(CARO_E_INVAL, "nets differ in kind / arithmetic mode");
   return 0;
 }

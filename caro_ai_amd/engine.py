@@ -27,7 +27,8 @@ COUNTER_NAMES = ["sims", "levels", "expansions", "terminals", "dropped", "overfl
 
 # inference= values served by the fused HIP net kernel -> HipNet mode
 # hipw: Winograd, the form chosen by the board (row form F(2,3); 2-D form F(2x2,3x3) from 13x13 up); hipw1 / hipw2 force one
-HIP_NET_MODES = {"hip": "f32", "hipw": "f32w", "hipw1": "f32w1", "hipw2": "f32w2"}
+# hipx3: the extra bf16x3 split-operand form (net_hip.HipNet mode "bf16x3"): never a default, not bit-identical to fp32
+HIP_NET_MODES = {"hip": "f32", "hipw": "f32w", "hipw1": "f32w1", "hipw2": "f32w2", "hipx3": "bf16x3"}
 
 def lanes_per_descent(game):
     """lane geometry of the tree kernels for a game (csrc/caro_variants.h): lanes that share one descent"""

@@ -117,6 +117,42 @@ def pack_net_w2(net: Net) -> np.ndarray:
     return out.reshape(-1)
 
 
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """float32 -> the nearest bfloat16 (ties to even), as uint16 bit patterns; finite inputs"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_value(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def split_bf16x3(x: np.ndarray):
+    """x (float32) -> three bfloat16 bit arrays hi, mid, lo with hi + mid + lo == x (each residual is exact)"""
+    x = np.ascontiguousarray(x, np.float32)
+    hi = bf16_round(x)
+    r1 = x - bf16_value(hi)
+    mid = bf16_round(r1)
+    r2 = r1 - bf16_value(mid)
+    lo = bf16_round(r2)
+    return hi, mid, lo
+
+
+def pack_net_x3(net: Net) -> np.ndarray:
+    """uint16[45 (layer, tap)][4 c][3 parts][2 h][64 co][8 ci]: the folded residual weights split into three bfloat16
+    parts, in the LDS image order of k_net_forward_x3 (ci = 16 c + 8 h + 0..7)."""
+    net = net.eval()
+    out = np.zeros((5, 9, 4, 3, 2, 64, 8), np.uint16)
+    for li, blk in enumerate(net.residual_blocks()):
+        w, _ = _fold(blk)
+        w = w.detach().cpu().numpy().astype(np.float32)           # [co, ci, ky, kx]
+        for tap in range(9):
+            wt = w[:, :, tap // 3, tap % 3].reshape(64, 4, 2, 8).transpose(1, 2, 0, 3)  # [c, h, co, 8]
+            for part, bits in enumerate(split_bf16x3(wt)):
+                out[li, tap, :, part] = bits
+    return out.reshape(-1)
+
+
 def wino2d_pays(H: int, W: int) -> bool:
     """the 2-D form executes 64 tiles x 16 taps per board, the row form ceil(tiles / 32) * 32 x 12 with
     ceil(H / 2) * W tiles: take the 2-D form where it is supported and at least 1/4 cheaper (13x13 up)"""
@@ -132,7 +168,10 @@ class HipNet:
     mode "f32w" (default): float32 on v_mfma_f32_32x32x2_f32, the 3x3 convolutions in Winograd form -- the row form
                  F(2,3) ("f32w1"), or on large boards (13x13 up, one board per workgroup) the 2-D form F(2x2,3x3) ("f32w2").
     mode "f32w1" / "f32w2": that form, forced.
-    mode "f32": the same with direct 3x3 convolutions (a plain fma chain in k order): the A/B baseline."""
+    mode "f32": the same with direct 3x3 convolutions (a plain fma chain in k order): the A/B baseline.
+    mode "bf16x3": an EXTRA mode, never a default: the direct form with every float32 trunk operand split into three
+                 bfloat16 parts, six part products per multiply on the bf16 MFMA, float32 accumulation (k_net_forward_x3);
+                 not bit-identical to the float32 modes, within the tolerance tests/test_gpu_net.py states."""
 
     device_counts = True  # the engine may call forward_dev without knowing L on the host
 
@@ -157,6 +196,10 @@ class HipNet:
         elif mode == "f32w1":
             ww = pack_net_w(net)
             _lib.check(self.L.caro_net_enable_winograd(self.h, ww.ctypes.data, ww.size))
+        elif mode == "bf16x3":
+            wx = pack_net_x3(net)
+            assert wx.size == self.L.caro_net_split_bf16_size()
+            _lib.check(self.L.caro_net_enable_split_bf16(self.h, wx.ctypes.data, wx.size))
         else:
             assert mode == "f32", mode
 
@@ -177,6 +220,8 @@ class HipNet:
         (4 p x 3 dx), each 32 k-steps on 8 waves; f32 (direct): 5 x 9 taps; f32w2: 5 x 16 taps on 64 tiles."""
         if self.mode == "f32w2":  # 5 layers x 16 taps x (2 row tiles x 2 column tiles) blocks of 32 k-steps
             return 5 * 16 * 4 * 32 * 4096.0
+        if self.mode == "bf16x3":  # 45 taps x 48 v_mfma_f32_32x32x16_bf16 (32768 flop: six part products per multiply) x 8 waves
+            return 45 * 48 * 8 * 32768.0
         taps = {"f32w1": 60, "f32": 45}.get(self.mode)
         return None if taps is None else taps * 32 * 8 * 4096.0
 

@@ -281,7 +281,7 @@ def test_hot_kernels_do_not_spill():
     eng = _code_object_metadata("caro_engine.hip.o")
     seen = 0
     # (mangled names: "11k_tree_stagI" is k_tree_stag alone, not k_tree_stag_mw; "9k_tree_mwI": config 4's tree kernel)
-    for md, wanted in ((net, ("k_net_forward_w2", "k_net_forward_wE", "k_net_heads")),
+    for md, wanted in ((net, ("k_net_forward_w2", "k_net_forward_wE", "k_net_heads", "k_net_forward_x3")),
                        (eng, ("11k_tree_stagI", "6k_treeI", "9k_tree_mwI"))):
         for name, k in md.items():
             if any(w in name for w in wanted):

@@ -375,7 +375,7 @@ def _compare_with_recorded_games(d, eng, g, n_moves):
 
 # the net arithmetic under test: fused HIP kernel (row-Winograd; the same forced onto full 128-row tiles, the
 # tile bench.py's 1024-game launches use; direct form) and the torch GEMM form
-NET_FORMS = ["hipw", "hipw-fulltiles", "hip", "gemm"]
+NET_FORMS = ["hipw", "hipw-fulltiles", "hip", "gemm", "hipx3"]  # hipx3: the extra bf16x3 form under the same tolerance
 
 
 @pytest.mark.parametrize("inference", NET_FORMS)
@@ -408,7 +408,7 @@ def test_real_weights_gpu_net_32_games(inference, monkeypatch):
     assert followed >= 24
 
 
-@pytest.mark.parametrize("inference", ["hipw", "hip"])
+@pytest.mark.parametrize("inference", ["hipw", "hip", "hipx3"])
 def test_real_weights_gpu_net_arena_800_sims(inference):
     """G5 at BASELINE config 5's per-game settings: best_026 vs best_025, 100 x 8 sims/move, tau = 0 from move 0,
     one tree per player; 8 games recorded from the reference, both nets in one launch (two-net k_tree)."""
@@ -431,7 +431,8 @@ def test_real_weights_gpu_net_arena_800_sims(inference):
 
 
 @pytest.mark.parametrize("name,inference", [("arena_c4_320_x16.json.gz", "hipw"), ("arena_c4_800_x16.json.gz", "hipw"),
-                                            ("arena_c4_800_x16.json.gz", "hip")])
+                                            ("arena_c4_800_x16.json.gz", "hip"), ("arena_c4_320_x16.json.gz", "hipx3"),
+                                            ("arena_c4_800_x16.json.gz", "hipx3")])
 def test_arena_32_recorded_games_gpu_net(name, inference):
     """SURVEY 8(c) G5 (tests/golden/make_golden_r5.py): 16 + 16 seeded tau = 0 arena games best_026 vs best_025 recorded
     from the reference at play.py's 40 x 8 and config 5's 100 x 8 sims/move, all 16 of a set in one engine, both nets

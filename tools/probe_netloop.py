@@ -6,7 +6,7 @@ from caro_ai_amd.lib.model import Net
 from caro_ai_amd.net_hip import HipNet
 mode = sys.argv[1] if len(sys.argv) > 1 else "f32"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-net = Net((2, 6, 7), 7); net.load_state_dict(torch.load("caro_ai_amd/data/weights/best_026_12000.dat", map_location="cpu"))
+net = Net((2, 6, 7), 7); net.load_state_dict(torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "caro_ai_amd/data/weights/") + "best_026_12000.dat", map_location="cpu"))
 hn = HipNet(net, "cuda:0", mode=mode)
 rows = 1434
 x = (torch.rand((rows, 2, 6, 7), device="cuda") < 0.3).float()

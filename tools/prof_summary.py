@@ -17,7 +17,7 @@ import os
 import sys
 from collections import defaultdict
 
-SHORT = ["k_tree_stag_mw", "k_tree_stag", "k_tree_mw", "k_tree", "k_net_heads", "k_net_forward_w2", "k_net_forward_w", "k_net_forward", "k_select", "k_expand_backup", "k_encode",
+SHORT = ["k_tree_stag_mw", "k_tree_stag", "k_tree_mw", "k_tree", "k_net_heads", "k_net_forward_w2", "k_net_forward_w", "k_net_forward_x3", "k_net_forward", "k_select", "k_expand_backup", "k_encode",
          "k_step", "k_drain_copy", "k_drain_scan", "k_evict", "k_net_hash"]
 
 
@@ -129,6 +129,8 @@ def main():
     for extra in ("config5", "config4"):  # profile_r03.sh: the same three passes on BASELINE configs 5 and 4
         if os.path.isdir(os.path.join(src, extra + "_fetch")):
             out_json[extra] = section(extra + "_")
+    if os.path.isdir(os.path.join(src, "x3_fetch")):  # the headline's configuration with --net hipx3 (the labelled extra leg)
+        out_json["net_bf16x3"] = section("x3_")
     # what the passes were taken on (tools/profile_r06.sh leaves the kernel sources' hashes beside the counters), and
     # the commit that holds exactly those sources -- bench.py refuses to quote the counters once the sources differ
     sha_file = os.path.join(src, "source_sha256.json")

@@ -31,6 +31,7 @@ run_pmc() {  # $1 prefix, $2.. bench arguments
 run_pmc pmc $H
 run_pmc config5 $C5
 run_pmc config4 $C4
+run_pmc x3 $H --net hipx3   # the labelled extra leg: bf16x3 split operands (k_net_forward_x3)
 echo "rocprofv3 --kernel-trace --stats -- $B $C4" | sed "s#$ROOT/##g" > $OUT/stats_config4.cmd
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_config4 -- $B $C4 > $OUT/stats_config4.json 2> $OUT/stats_config4.err
 echo config4 stats done
