@@ -72,7 +72,7 @@ struct NetParams {
   const float* ww;      // f32w mode: [5][3 dx][2 granule halves] chunks of [4 p][2 h][64 co][16] transformed residual weights (LDS image order of trunk_w), or null
   const uint32_t* wtab; // f32w mode: [128] tile of MFMA row (row tile, lane): board | ty << 8 | x << 16 | valid << 24
   const float* ww2;     // f32w2 mode: [5][8 chunks][2 b][4 a][2 h][64 co][8] 2-D Winograd F(2x2,3x3) transformed residual weights (LDS image order of trunk_w2d), or null
-  const uint16_t* wx3;  // bf16x3 mode: [45 taps][4 c][3 parts][2 h][64 co][8 ci] bfloat16 split residual weights (k_net_forward_x3), or null
+  const uint16_t* wx3;  // bf16x3 mode: [45 taps][2 c][3 parts][4 kg][64 co][8 ci] bfloat16 split residual weights (k_net_forward_x3), or null
   int ncu, TB2, TB4;    // f32w mode: compute units; boards per workgroup of the 2- / 4-way K-split overflow tiles (0: off)
 };
 
@@ -679,26 +679,28 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
 // Split-operand form ("bf16x3"): an EXTRA arithmetic mode, never the default and never the bench's headline.  Every
 // float32 operand of the residual trunk is written as the sum of three bfloat16 parts (hi + mid + lo = the float32 value,
 // 8 + 8 + 8 significant bits) and a product a*b is taken as the six part products of weight 2^-16 and above
-// (ah bh, ah bm, am bh, ah bl, al bh, am bm) on v_mfma_f32_32x32x16_bf16 with float32 accumulation: 12 instructions of
-// 8 passes per 16 input channels where the float32 form issues 16 of 16 passes.  The dropped products are below
+// (ah bh, ah bm, am bh, ah bl, al bh, am bm) on v_mfma_f32_16x16x32_bf16 with float32 accumulation: per wave and tap
+// 96 instructions of 16 cycles where the float32 direct form issues 64 of 64 cycles (the 16x16x32 shape because the chip
+// holds a 12-15 % higher clock under it than under 32x32x16 at the same flops: a full launch is power-limited).  The dropped products are below
 // 2^-24 of |a b|: the result is not bit-identical to the float32 kernels but within a small multiple of their own
 // rounding error (tests/test_gpu_net.py states the gate).  conv_in, the biases, the residual adds, LeakyReLU and the
 // heads stay float32 VALU code exactly as in k_net_forward.
-//   LDS: [0, 64 KB) float32 activations at both ends of the trunk, the ring of staged weight quarters in between;
+//   LDS: [0, 64 KB) float32 activations at both ends of the trunk, the ring of staged weight halves in between;
 //        [64 KB, 160 KB) the split activations [3 parts][8 granules of 8 channels][256 rows][8 bf16].
-//   The weights arrive pre-split from the host: per (layer, tap) [4 c][3 parts][2 h][64 co][8 ci] bf16 (24 576 B).
-//   The MFMA takes the WEIGHTS as its first operand: a lane then owns 16 + 16 output channels of ONE row, and the
-//   epilogue reads / writes its residual in 8-byte pieces of that row.
+//   The weights arrive pre-split from the host: per (layer, tap) [2 c][3 parts][4 kg][64 co][8 ci] bf16 (24 576 B),
+//   ci = 32 c + 8 kg + 0..7.  The MFMA takes the WEIGHTS as its first operand: a lane then owns 4 x 4 consecutive output
+//   channels of TWO rows, and the epilogue writes its residual in 8-byte pieces of those rows.
 #ifndef CARO_X3_TIMERS
 #define CARO_X3_TIMERS 0
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int X3_Q = 3 * 2 * 64;        // uint4 (8 bf16) per quarter tap = the 16 input channels of one c: 384
-constexpr int X3_TAP_U4 = 4 * X3_Q;     // per tap image: 1536 (24 576 B)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int X3_H = 3 * 4 * 64;        // uint4 (8 bf16) per half tap = 32 input channels: [3 parts][4 kg][64 co] = 768
+constexpr int X3_TAP_U4 = 2 * X3_H;     // per tap image: 1536 (24 576 B)
 constexpr int X3_PAD_TAPS = 2;          // zero taps behind the image: the staging loads run two taps ahead, unconditionally
-constexpr int X3_RING13 = 3 * X3_Q;     // ring: three slots of quarter 0, then two slots of quarters 1..3
+constexpr int X3_RING_H1 = 3 * X3_H;    // ring: three slots of half 0, then two slots of half 1 (61 440 B)
 
 // two float32 <-> two bfloat16 in one register (v_cvt_pk_bf16_f32, round to nearest even)
 __device__ __forceinline__ uint32_t pk_bf16(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
@@ -762,22 +764,30 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
   int* smap = reinterpret_cast<int*>(wbuf + 1536);
   tile_rows(gpack, gG, gB, second ? 1 : 0, row0 + board0, board0, nb, smap + 64, smap, tid);  // ends with a barrier
   conv_in_mfma(p, planes, smap, act, wbuf, R, tid);
-  const int slot_v = tid < nb ? smap[tid] : 0;
+  const int slot_v0 = tid < nb ? smap[tid] : 0;
   __syncthreads();
 
   unsigned long long t_trunk0 = 0;
   if (stamps) t_trunk0 = __builtin_amdgcn_s_memtime();
-  // The residual stream of this lane's 32 outputs (row wave * 32 + i, channels 8 j + 4 h + 0..3) stays in float32
-  // registers across the layers: the epilogue adds to it and writes its split image for the next layer's MFMAs.
-  const int myrow = wave * 32 + i;
-  const bool rvalid = myrow < R;
-  f32x2 res[8][2];
+  // MFMA geometry (v_mfma_f32_16x16x32_bf16, the weights as first operand): lane (r16, kg) feeds input channels
+  // 32 c + 8 kg + 0..7 of output channel 16 cb + r16 (weights) and of the neighbours of rows wave * 32 + 16 rb + r16
+  // (activations), and receives output channels 16 cb + 4 kg + 0..3 of those two rows.
+  const int r16 = lane & 15, kg = lane >> 4;
+  (void)i; (void)h;
+  const int myrow0 = wave * 32 + r16, myrow1 = myrow0 + 16;
+  const bool rvalid0 = myrow0 < R, rvalid1 = myrow1 < R;
+  // The residual stream of this lane's 32 outputs stays in float32 registers across the layers: the epilogue adds to it
+  // and writes its split image for the next layer's MFMAs.
+  f32x2 res[2][4][2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float4 v = *reinterpret_cast<const float4*>(act + myrow * NF + (((2 * j + h) ^ (myrow & 15)) << 2));
-    res[j][0] = f32x2{v.x, v.y};
-    res[j][1] = f32x2{v.z, v.w};
-  }
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int row = rb ? myrow1 : myrow0;
+      const float4 v = *reinterpret_cast<const float4*>(act + row * NF + (((4 * cb + kg) ^ (row & 15)) << 2));
+      res[rb][cb][0] = f32x2{v.x, v.y};
+      res[rb][cb][1] = f32x2{v.z, v.w};
+    }
   // ---- float32 activations -> three bf16 part planes (rows >= R are zero in `act`, so they are zero here)
   uint4* parts = reinterpret_cast<uint4*>(wbuf);  // [part * 8 + g][256 rows]
 #pragma unroll
@@ -794,80 +804,93 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
     parts[(2 * 8 + g) * 256 + row] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
   }
   __syncthreads();  // every thread is done with `act`: it becomes the weight ring
-  // The ring.  Quarter 0 of a tap (its first 16 input channels) has three slots (tap % 3), quarters 1..3 two (tap & 1):
-  // while tap t runs, the rest of tap t+1 and quarter 0 of tap t+2 are staged, so that the first operand set of tap
-  // t+1 can be requested BEFORE the barrier that ends tap t (its weights were complete one barrier earlier).
+  // The ring.  Half 0 of a tap (its first 32 input channels) has three slots (tap % 3), half 1 two (tap & 1): while tap t
+  // runs, half 1 of tap t+1 and half 0 of tap t+2 are staged, so that the first operand sets of tap t+1 can be requested
+  // BEFORE the barrier that ends tap t (its half 0 was complete one barrier earlier).
   uint4* ring = reinterpret_cast<uint4*>(act);
   const uint4* wsrc = reinterpret_cast<const uint4*>(p.wx3);
-  // what this thread stages per tap: items tid, tid + 512 and (tid < 128) tid + 1024 of the 1152 of quarters 1..3 of
-  // the next tap; (tid >= 128) item tid - 128 of quarter 0 of the tap after it
-  const bool stage_q0 = tid >= 128;
-  const int s2_src = stage_q0 ? X3_TAP_U4 + (tid - 128) : X3_Q + tid + 1024;  // relative to the next tap's image
+  // what this thread stages per tap: item tid and (tid < 256) item 512 + tid of the 768 of half 1 of the next tap;
+  // (tid >= 256) item tid - 256 and item 256 + tid of the 768 of half 0 of the tap after it
+  const bool stage_h0 = tid >= 256;
+  const int s1_src = stage_h0 ? X3_TAP_U4 + (tid - 256) : X3_H + 512 + tid;  // relative to the next tap's image
   {
-    ring[0 * X3_Q + (tid < X3_Q ? tid : 0)] = wsrc[tid < X3_Q ? tid : 0];                         // tap 0, quarter 0 (slot 0)
-    if (tid < X3_Q) ring[1 * X3_Q + tid] = wsrc[X3_TAP_U4 + tid];                                 // tap 1, quarter 0 (slot 1)
-    ring[X3_RING13 + tid] = wsrc[X3_Q + tid];                                                     // tap 0, quarters 1..3
-    ring[X3_RING13 + tid + NT] = wsrc[X3_Q + tid + NT];
-    if (tid < 128) ring[X3_RING13 + tid + 2 * NT] = wsrc[X3_Q + tid + 2 * NT];
+    ring[0 * X3_H + tid] = wsrc[tid];                                       // tap 0, half 0 (slot 0)
+    if (tid < 256) ring[0 * X3_H + 512 + tid] = wsrc[512 + tid];
+    ring[1 * X3_H + tid] = wsrc[X3_TAP_U4 + tid];                           // tap 1, half 0 (slot 1)
+    if (tid < 256) ring[1 * X3_H + 512 + tid] = wsrc[X3_TAP_U4 + 512 + tid];
+    ring[X3_RING_H1 + tid] = wsrc[X3_H + tid];                              // tap 0, half 1 (slot 0)
+    if (tid < 256) ring[X3_RING_H1 + 512 + tid] = wsrc[X3_H + 512 + tid];
   }
+  // the 4 KB behind the ring: the five layers' biases (read by the epilogues) and every thread's output row (read by the
+  // heads) -- values that would otherwise occupy registers across the whole trunk
+  static_assert((X3_RING_H1 + 2 * X3_H) * 16 + NRES * NF * 4 + NT * 4 <= ACT * 4, "ring + biases + output rows must fit the 64 KB of the float32 activations");
+  float* bias_l = reinterpret_cast<float*>(ring + X3_RING_H1 + 2 * X3_H);  // [5][64]
+  int* slot_l = reinterpret_cast<int*>(bias_l + NRES * NF);                 // [NT]
+  if (tid < NRES * NF) bias_l[tid] = p.b_res[tid];
+  slot_l[tid] = slot_v0;
   __syncthreads();
 
-  const int rbi = myrow / HW;
-  const int rcell = myrow - rbi * HW;
-  const int ry = rcell / p.W, rx = rcell - ry * p.W;
-  auto neighbour = [&](int tap) {
-    const int ny = ry + tap / 3 - 1, nx = rx + tap % 3 - 1;
-    const bool ok = rvalid && ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
-    return ok ? rbi * HW + ny * p.W + nx : (int)ZROW;
-  };
-
-  int nrow9[9];  // the lane's neighbour row per tap (ZROW outside the board)
+  int nrow9[9];  // the neighbour rows of the lane's two rows per tap (ZROW outside the board): row 0 | row 1 << 16
 #pragma unroll
-  for (int t = 0; t < 9; ++t) nrow9[t] = neighbour(t);
-
-  f32x16 acc0, acc1;
+  for (int t = 0; t < 9; ++t) nrow9[t] = 0;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    acc0[e] = 0.f;
-    acc1[e] = 0.f;
+  for (int rb = 0; rb < 2; ++rb) {
+    const int row = rb ? myrow1 : myrow0;
+    const bool rv = rb ? rvalid1 : rvalid0;
+    const int rbi = row / HW;
+    const int rcell = row - rbi * HW;
+    const int ry = rcell / p.W, rx = rcell - ry * p.W;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ny = ry + t / 3 - 1, nx = rx + t % 3 - 1;
+      const bool ok = rv && ny >= 0 && ny < p.H && nx >= 0 && nx < p.W;
+      nrow9[t] |= (ok ? rbi * HW + ny * p.W + nx : (int)ZROW) << (16 * rb);
+    }
   }
-  // operand sets: A_ = activation parts of the lane's neighbour row, B_ = weight parts of channels i / 32 + i
-#define CARO_X3_LOAD(S_, AB_, BB_, C_)                  \
-  S_##ah = (AB_)[(0 * 8 + 2 * (C_)) * 256];             \
-  S_##am = (AB_)[(1 * 8 + 2 * (C_)) * 256];             \
-  S_##al = (AB_)[(2 * 8 + 2 * (C_)) * 256];             \
-  S_##bh0 = (BB_)[0 * 128];                             \
-  S_##bh1 = (BB_)[0 * 128 + 32];                        \
-  S_##bm0 = (BB_)[1 * 128];                             \
-  S_##bm1 = (BB_)[1 * 128 + 32];                        \
-  S_##bl0 = (BB_)[2 * 128];                             \
-  S_##bl1 = (BB_)[2 * 128 + 32];
-#define CARO_X3_MM(W_, A_, ACC_) \
-  ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W_), __builtin_bit_cast(bf16x8, A_), ACC_, 0, 0, 0);
-  // smallest products first: the float32 accumulator takes the low-order corrections before the leading term
-#define CARO_X3_MFMA(S_)            \
-  CARO_X3_MM(S_##bm0, S_##am, acc0) \
-  CARO_X3_MM(S_##bm1, S_##am, acc1) \
-  CARO_X3_MM(S_##bl0, S_##ah, acc0) \
-  CARO_X3_MM(S_##bl1, S_##ah, acc1) \
-  CARO_X3_MM(S_##bh0, S_##al, acc0) \
-  CARO_X3_MM(S_##bh1, S_##al, acc1) \
-  CARO_X3_MM(S_##bm0, S_##ah, acc0) \
-  CARO_X3_MM(S_##bm1, S_##ah, acc1) \
-  CARO_X3_MM(S_##bh0, S_##am, acc0) \
-  CARO_X3_MM(S_##bh1, S_##am, acc1) \
-  CARO_X3_MM(S_##bh0, S_##ah, acc0) \
-  CARO_X3_MM(S_##bh1, S_##ah, acc1)
-  // Twelve MFMAs with the nine operand reads of the NEXT segment woven into their gaps, one LDS instruction behind each
-  // MFMA: issued in the shadow of an MFMA an LDS instruction costs the wave nothing; issued as a burst between the
-  // segments it holds the wave -- and with it the matrix pipe, which its partner on the SIMD is not using either, the
-  // two being in the same phase after every barrier -- for 80-150 cycles.
-#define CARO_X3_WEAVE_READS                             \
-  _Pragma("unroll") for (int q_ = 0; q_ < 9; ++q_) {    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  \
-  }                                                     \
-  __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+
+  f32x4v acc[2][4];  // [rb][cb]
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  // operand sets of six 16-byte fragments, index part * 2 + (rb | cb & 1):
+  //   activations of 32 input channels c: the three parts of the neighbour rows of the lane's two rows
+  //   weights of 32 input channels c and a pair of channel blocks cp: the three parts of blocks 2 cp, 2 cp + 1
+  const uint4* arow = parts + kg * 256;  // + (part * 8 + 4 c) * 256 + neighbour row
+#define CARO_X3_LOAD_ACT(S_, C_, N0_, N1_)                                  \
+  _Pragma("unroll") for (int pt_ = 0; pt_ < 3; ++pt_) {                     \
+    S_[pt_ * 2] = arow[(pt_ * 8 + 4 * (C_)) * 256 + (N0_)];                 \
+    S_[pt_ * 2 + 1] = arow[(pt_ * 8 + 4 * (C_)) * 256 + (N1_)];             \
+  }
+#define CARO_X3_LOAD_W(S_, HB_, CP_)                                        \
+  _Pragma("unroll") for (int pt_ = 0; pt_ < 3; ++pt_) {                     \
+    S_[pt_ * 2] = (HB_)[pt_ * 256 + (CP_) * 32];                            \
+    S_[pt_ * 2 + 1] = (HB_)[pt_ * 256 + (CP_) * 32 + 16];                   \
+  }
+  // the six part products of weight 2^-16 and above, smallest first (the float32 accumulator takes the low-order
+  // corrections before the leading term); the four accumulators of a segment take turns
+#define CARO_X3_PROD(W_, A_, CP_, WP_, AP_)                                                                     \
+  _Pragma("unroll") for (int cbi_ = 0; cbi_ < 2; ++cbi_) _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)   \
+    acc[rb_][2 * (CP_) + cbi_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                       \
+        __builtin_bit_cast(bf16x8, W_[(WP_) * 2 + cbi_]), __builtin_bit_cast(bf16x8, A_[(AP_) * 2 + rb_]),      \
+        acc[rb_][2 * (CP_) + cbi_], 0, 0, 0);
+#define CARO_X3_SEG(W_, A_, CP_)  \
+  CARO_X3_PROD(W_, A_, CP_, 1, 1) \
+  CARO_X3_PROD(W_, A_, CP_, 2, 0) \
+  CARO_X3_PROD(W_, A_, CP_, 0, 2) \
+  CARO_X3_PROD(W_, A_, CP_, 1, 0) \
+  CARO_X3_PROD(W_, A_, CP_, 0, 1) \
+  CARO_X3_PROD(W_, A_, CP_, 0, 0)
+  // A segment = 24 MFMAs of 16 cycles with the operand reads of a LATER segment woven into their gaps, one LDS instruction
+  // behind every second MFMA (every MFMA in the tap's last segment): issued in the shadow of an MFMA an LDS instruction
+  // costs the wave nothing; issued as a burst between the segments it holds the wave -- and with it the matrix pipe,
+  // which its partner on the SIMD is not using either, the two being in the same phase after every barrier.
+#define CARO_X3_WEAVE(NR_)                                  \
+  _Pragma("unroll") for (int q_ = 0; q_ < (NR_); ++q_) {    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
+  }                                                         \
+  __builtin_amdgcn_sched_group_barrier(0x008, 24 - 2 * (NR_), 0);
 #if CARO_X3_TIMERS  /* diagnostic build (tools/probe_clock.py): per-phase cycles of a wave, summed over the 45 taps */
   unsigned long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = 0;
 #define CARO_T0 tl = __builtin_amdgcn_s_memtime();
@@ -876,124 +899,130 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
 #define CARO_T0
 #define CARO_T(K_)
 #endif
-  uint4 xah, xam, xal, xbh0, xbh1, xbm0, xbm1, xbl0, xbl1;
-  uint4 yah, yam, yal, ybh0, ybh1, ybm0, ybm1, ybl0, ybl1;
-  const uint4* arow = parts + h * 256;    // + neighbour row
-  const uint4* bcol = ring + h * 64 + i;  // + slot
-  CARO_X3_LOAD(x, arow + nrow9[0], bcol, 0)
+  uint4 X[6], Y[6], P[6], Q[6];
+  const uint4* wcol = ring + kg * 64 + r16;  // + slot + part * 256 + 16 cb
+  CARO_X3_LOAD_ACT(X, 0, nrow9[0] & 0xFFFF, nrow9[0] >> 16)
+  CARO_X3_LOAD_W(P, wcol, 0)
   uint4 wn0, wn1, wn2;
   const uint4* wnext = wsrc + X3_TAP_U4;  // image of the tap after the current one
   for (int layer = 0; layer < NRES; ++layer) {
-    float4 bq[8];  // the layer's biases of this lane's channels (8 j + 4 h + 0..3), requested two taps before their use
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      // 9 taps per layer: the quarter-0 slot of a tap is tap % 3 in every layer, the slot of its quarters 1..3 alternates
+      // 9 taps per layer: the half-0 slot of a tap is tap % 3 in every layer, the slot of its half 1 alternates
       const int cur = (layer + tap) & 1;
-      const int slot1 = (tap + 1) % 3, slot2 = (tap + 2) % 3;
+      const int slot0 = tap % 3, slot1 = (tap + 1) % 3, slot2 = (tap + 2) % 3;
       CARO_T0
       // issue early (the image is followed by X3_PAD_TAPS zero taps: no bounds to check)
-      wn0 = wnext[X3_Q + tid];
-      wn1 = wnext[X3_Q + tid + NT];
-      wn2 = wnext[s2_src];
+      wn0 = wnext[X3_H + tid];
+      wn1 = wnext[s1_src];
+      wn2 = wnext[X3_TAP_U4 + 256 + tid];
       wnext += X3_TAP_U4;
-      if (tap == 7) {
-        const float* bias = p.b_res + layer * NF;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bq[j] = *reinterpret_cast<const float4*>(bias + 8 * j + 4 * h);
-      }
-      const uint4* abase = arow + nrow9[tap];
-      const uint4* bbase = bcol + X3_RING13 + cur * X3_RING13;  // quarters 1..3 of this tap: + (c - 1) * X3_Q
+      const uint4* hb0 = wcol + slot0 * X3_H;
+      const uint4* hb1 = wcol + X3_RING_H1 + cur * X3_H;
+      const int n0 = nrow9[tap] & 0xFFFF, n1 = nrow9[tap] >> 16;
       __builtin_amdgcn_sched_barrier(0);
       CARO_T(0)
-      CARO_X3_LOAD(y, abase, bbase, 1)
-      CARO_X3_MFMA(x)
-      CARO_X3_WEAVE_READS
+      CARO_X3_LOAD_W(Q, hb0, 1)
+      CARO_X3_SEG(P, X, 0)
+      CARO_X3_WEAVE(6)
       __builtin_amdgcn_sched_barrier(0);
       CARO_T(1)
-      CARO_X3_LOAD(x, abase, bbase + X3_Q, 2)
-      CARO_X3_MFMA(y)
-      CARO_X3_WEAVE_READS
+      CARO_X3_LOAD_ACT(Y, 1, n0, n1)
+      CARO_X3_LOAD_W(P, hb1, 0)
+      CARO_X3_SEG(Q, X, 1)
+      CARO_X3_WEAVE(12)
       __builtin_amdgcn_sched_barrier(0);
       CARO_T(2)
-      CARO_X3_LOAD(y, abase, bbase + 2 * X3_Q, 3)
-      CARO_X3_MFMA(x)
-      CARO_X3_WEAVE_READS
+      CARO_X3_LOAD_W(Q, hb1, 1)
+      CARO_X3_SEG(P, Y, 0)
+      CARO_X3_WEAVE(6)
       __builtin_amdgcn_sched_barrier(0);
       CARO_T(3)
-      {  // the staged quarters (their slots were last read one tap ago, before the barrier that ended it) and the next
-         // tap's first operand set -- at a layer's last tap that set is read again behind the epilogue
-        uint4* d13 = ring + X3_RING13 + (cur ^ 1) * X3_RING13;
-        d13[tid] = wn0;
-        d13[tid + NT] = wn1;
-        uint4* d2 = stage_q0 ? ring + slot2 * X3_Q + (tid - 128) : d13 + tid + 2 * NT;
-        *d2 = wn2;
+      {  // the staged halves (their slots were last read one tap ago, before the barrier that ended it) and the next
+         // tap's first operand sets -- at a layer's last tap the activations are read again behind the epilogue
+        uint4* d1 = ring + X3_RING_H1 + (cur ^ 1) * X3_H;
+        uint4* d0 = ring + slot2 * X3_H;
+        d1[tid] = wn0;
+        *(stage_h0 ? d0 + (tid - 256) : d1 + 512 + tid) = wn1;
+        d0[256 + tid] = wn2;
       }
-      CARO_X3_LOAD(x, arow + nrow9[tap == 8 ? 0 : tap + 1], bcol + slot1 * X3_Q, 0)
-      CARO_X3_MFMA(y)
+      CARO_X3_LOAD_ACT(X, 0, nrow9[tap == 8 ? 0 : tap + 1] & 0xFFFF, nrow9[tap == 8 ? 0 : tap + 1] >> 16)
+      CARO_X3_LOAD_W(P, wcol + slot1 * X3_H, 0)
+      CARO_X3_SEG(Q, Y, 1)
 #pragma unroll
       for (int q_ = 0; q_ < 3; ++q_) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       }
 #pragma unroll
-      for (int q_ = 0; q_ < 9; ++q_) {
+      for (int q_ = 0; q_ < 12; ++q_) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
+      __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
       __builtin_amdgcn_sched_barrier(0);
       CARO_T(4)
       if (tap == 8) {
         unsigned long long t_e0 = 0;
         if (stamps) t_e0 = __builtin_amdgcn_s_memtime();
         __syncthreads();  // every wave has read this layer's input activations: they may be overwritten
-        // epilogue, in place: v = v + leaky(conv(v) + b)  (lib/model.py:85-89).  acc[e] of lane (i, h) = output channel
-        // (e & 3) + 8 (e >> 2) + 4 h (+ 32 in acc1) of row wave * 32 + i: four consecutive channels per 8-byte piece.
-        uint2* mine = reinterpret_cast<uint2*>(parts + myrow) + h;  // + (part * 8 + g) * 512
+        // epilogue, in place: v = v + leaky(conv(v) + b)  (lib/model.py:85-89).  acc[rb][cb][e] = output channel
+        // 16 cb + 4 kg + e of row wave * 32 + 16 rb + r16: four consecutive channels per 8-byte piece of a part plane.
         const f32x2 slope2 = {slope, slope};
-        const f32x2 keep = rvalid ? f32x2{1.f, 1.f} : f32x2{0.f, 0.f};  // rows this tile does not have stay zero
+        float4 bq[4];  // the layer's biases of this lane's channels (16 cb + 4 kg + 0..3)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {  // granule g = j: channels 8 j + 4 h + 0..3
-          const int e0 = (j & 3) * 4;
-          const f32x2 a01 = j < 4 ? f32x2{acc0[e0], acc0[e0 + 1]} : f32x2{acc1[e0], acc1[e0 + 1]};
-          const f32x2 a23 = j < 4 ? f32x2{acc0[e0 + 2], acc0[e0 + 3]} : f32x2{acc1[e0 + 2], acc1[e0 + 3]};
-          const f32x2 t01 = a01 + f32x2{bq[j].x, bq[j].y}, t23 = a23 + f32x2{bq[j].z, bq[j].w};
-          const f32x2 s01 = t01 * slope2, s23 = t23 * slope2;
-          const f32x2 l01 = {t01.x > 0.f ? t01.x : s01.x, t01.y > 0.f ? t01.y : s01.y};
-          const f32x2 l23 = {t23.x > 0.f ? t23.x : s23.x, t23.y > 0.f ? t23.y : s23.y};
-          res[j][0] = (res[j][0] + l01) * keep;
-          res[j][1] = (res[j][1] + l23) * keep;
-          uint2 wh, wm, wl;
-          split3(res[j][0], wh.x, wm.x, wl.x);
-          split3(res[j][1], wh.y, wm.y, wl.y);
-          mine[(0 * 8 + j) * 512] = wh;
-          mine[(1 * 8 + j) * 512] = wm;
-          mine[(2 * 8 + j) * 512] = wl;
-        }
+        for (int cb = 0; cb < 4; ++cb) bq[cb] = *reinterpret_cast<const float4*>(bias_l + layer * NF + 16 * cb + 4 * kg);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          acc0[e] = 0.f;
-          acc1[e] = 0.f;
+        for (int rb = 0; rb < 2; ++rb) {
+          const int row = rb ? myrow1 : myrow0;
+          const bool rv = rb ? rvalid1 : rvalid0;
+          const f32x2 keep = rv ? f32x2{1.f, 1.f} : f32x2{0.f, 0.f};  // rows this tile does not have stay zero
+          uint2* mine = reinterpret_cast<uint2*>(parts + (kg >> 1) * 256 + row) + (kg & 1);  // + (part * 8 + 2 cb) * 512
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) {
+            const f32x4v a = acc[rb][cb];
+            const f32x2 t01 = f32x2{a[0], a[1]} + f32x2{bq[cb].x, bq[cb].y}, t23 = f32x2{a[2], a[3]} + f32x2{bq[cb].z, bq[cb].w};
+            const f32x2 s01 = t01 * slope2, s23 = t23 * slope2;
+            const f32x2 l01 = {t01.x > 0.f ? t01.x : s01.x, t01.y > 0.f ? t01.y : s01.y};
+            const f32x2 l23 = {t23.x > 0.f ? t23.x : s23.x, t23.y > 0.f ? t23.y : s23.y};
+            res[rb][cb][0] = (res[rb][cb][0] + l01) * keep;
+            res[rb][cb][1] = (res[rb][cb][1] + l23) * keep;
+            uint2 wh, wm, wl;
+            split3(res[rb][cb][0], wh.x, wm.x, wl.x);
+            split3(res[rb][cb][1], wh.y, wm.y, wl.y);
+            mine[(0 * 8 + 2 * cb) * 512] = wh;
+            mine[(1 * 8 + 2 * cb) * 512] = wm;
+            mine[(2 * 8 + 2 * cb) * 512] = wl;
+            acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+          }
         }
         if (stamps) t_epi += __builtin_amdgcn_s_memtime() - t_e0;
       }
       CARO_T0
-      __syncthreads();  // the staged quarters / the new activations are visible to every wave
+      __syncthreads();  // the staged halves / the new activations are visible to every wave
       CARO_T(5)
-      if (tap == 8 && layer + 1 < NRES) {  // the next layer's first operand set reads the activations just written
-        CARO_X3_LOAD(x, arow + nrow9[0], bcol + slot1 * X3_Q, 0)
+      if (tap == 8 && layer + 1 < NRES) {  // the next layer's first activation set reads the rows just written
+        CARO_X3_LOAD_ACT(X, 0, nrow9[0] & 0xFFFF, nrow9[0] >> 16)
       }
     }
   }
-#undef CARO_X3_WEAVE_READS
-#undef CARO_X3_LOAD
-#undef CARO_X3_MM
-#undef CARO_X3_MFMA
+#undef CARO_X3_WEAVE
+#undef CARO_X3_LOAD_ACT
+#undef CARO_X3_LOAD_W
+#undef CARO_X3_PROD
+#undef CARO_X3_SEG
   // ---- the trunk output back to float32 in `act` (the ring is dead: the loop ended with a barrier), then the float32
   // heads with the parts' region as scratch
+  const int slot_v = slot_l[tid];
+  __syncthreads();  // (slot_l sits where the last rows of `act` go)
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    *reinterpret_cast<float4*>(act + myrow * NF + (((2 * j + h) ^ (myrow & 15)) << 2)) =
-        make_float4(res[j][0].x, res[j][0].y, res[j][1].x, res[j][1].y);
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int row = rb ? myrow1 : myrow0;
+      *reinterpret_cast<float4*>(act + row * NF + (((4 * cb + kg) ^ (row & 15)) << 2)) =
+          make_float4(res[rb][cb][0].x, res[rb][cb][0].y, res[rb][cb][1].x, res[rb][cb][1].y);
+    }
   __syncthreads();
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
@@ -2477,7 +2506,7 @@ int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_flo
 }
 
 /* bf16x3 mode (an extra arithmetic mode, see k_net_forward_x3): upload the residual weights split into three bfloat16
- * parts, [45 (layer, tap)][4 c][3 parts][2 h][64 co][8 ci] uint16 with ci = 16 c + 8 h + 0..7, packed by
+ * parts, [45 (layer, tap)][2 c][3 parts][4 kg][64 co][8 ci] uint16 with ci = 32 c + 8 kg + 0..7, packed by
  * caro_ai_amd/net_hip.py:pack_net_x3; from then on the forward calls of this net run k_net_forward_x3. */
 int64_t caro_net_split_bf16_size(void) { return (int64_t)cnet::NTAPS * cnet::X3_TAP_U4 * 8; }
 int caro_net_enable_split_bf16(caro_net* n, const uint16_t* parts_host, int64_t n_u16) {

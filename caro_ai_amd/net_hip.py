@@ -139,15 +139,15 @@ def split_bf16x3(x: np.ndarray):
 
 
 def pack_net_x3(net: Net) -> np.ndarray:
-    """uint16[45 (layer, tap)][4 c][3 parts][2 h][64 co][8 ci]: the folded residual weights split into three bfloat16
-    parts, in the LDS image order of k_net_forward_x3 (ci = 16 c + 8 h + 0..7)."""
+    """uint16[45 (layer, tap)][2 c][3 parts][4 kg][64 co][8 ci]: the folded residual weights split into three bfloat16
+    parts, in the LDS image order of k_net_forward_x3 (ci = 32 c + 8 kg + 0..7)."""
     net = net.eval()
-    out = np.zeros((5, 9, 4, 3, 2, 64, 8), np.uint16)
+    out = np.zeros((5, 9, 2, 3, 4, 64, 8), np.uint16)
     for li, blk in enumerate(net.residual_blocks()):
         w, _ = _fold(blk)
         w = w.detach().cpu().numpy().astype(np.float32)           # [co, ci, ky, kx]
         for tap in range(9):
-            wt = w[:, :, tap // 3, tap % 3].reshape(64, 4, 2, 8).transpose(1, 2, 0, 3)  # [c, h, co, 8]
+            wt = w[:, :, tap // 3, tap % 3].reshape(64, 2, 4, 8).transpose(1, 2, 0, 3)  # [c, kg, co, 8]
             for part, bits in enumerate(split_bf16x3(wt)):
                 out[li, tap, :, part] = bits
     return out.reshape(-1)
@@ -170,7 +170,7 @@ class HipNet:
     mode "f32w1" / "f32w2": that form, forced.
     mode "f32": the same with direct 3x3 convolutions (a plain fma chain in k order): the A/B baseline.
     mode "bf16x3": an EXTRA mode, never a default: the direct form with every float32 trunk operand split into three
-                 bfloat16 parts, six part products per multiply on the bf16 MFMA, float32 accumulation (k_net_forward_x3);
+                 bfloat16 parts, six part products per multiply on v_mfma_f32_16x16x32_bf16, float32 accumulation (k_net_forward_x3);
                  not bit-identical to the float32 modes, within the tolerance tests/test_gpu_net.py states."""
 
     device_counts = True  # the engine may call forward_dev without knowing L on the host
@@ -220,8 +220,8 @@ class HipNet:
         (4 p x 3 dx), each 32 k-steps on 8 waves; f32 (direct): 5 x 9 taps; f32w2: 5 x 16 taps on 64 tiles."""
         if self.mode == "f32w2":  # 5 layers x 16 taps x (2 row tiles x 2 column tiles) blocks of 32 k-steps
             return 5 * 16 * 4 * 32 * 4096.0
-        if self.mode == "bf16x3":  # 45 taps x 48 v_mfma_f32_32x32x16_bf16 (32768 flop: six part products per multiply) x 8 waves
-            return 45 * 48 * 8 * 32768.0
+        if self.mode == "bf16x3":  # 45 taps x 96 v_mfma_f32_16x16x32_bf16 (16384 flop: six part products per multiply) x 8 waves
+            return 45 * 96 * 8 * 16384.0
         taps = {"f32w1": 60, "f32": 45}.get(self.mode)
         return None if taps is None else taps * 32 * 8 * 4096.0
 

@@ -283,10 +283,10 @@ int caro_net_winograd2d_supported(int H, int W);
 int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_floats);
 /* bf16x3 mode -- an EXTRA arithmetic mode, not the default of any caller and not what bench.py's headline runs: every
  * float32 operand of the residual trunk (lib/model.py:36-47) as the sum of three bfloat16 parts, a product as the six
- * part products of weight 2^-16 and above on v_mfma_f32_32x32x16_bf16, float32 accumulation; conv_in, biases, residual
+ * part products of weight 2^-16 and above on v_mfma_f32_16x16x32_bf16, float32 accumulation; conv_in, biases, residual
  * adds, LeakyReLU and the heads in float32 as in the default kernel.  NOT bit-identical to the float32 modes: within
  * the tolerance tests/test_gpu_net.py states for it.  parts_host: caro_net_split_bf16_size() uint16 =
- * [45 (layer, tap)][4 c][3 parts][2 h][64 co][8 ci] bfloat16 bit patterns, ci = 16 c + 8 h + 0..7
+ * [45 (layer, tap)][2 c][3 parts][4 kg][64 co][8 ci] bfloat16 bit patterns, ci = 32 c + 8 kg + 0..7
  * (caro_ai_amd/net_hip.py:pack_net_x3).  Mutually exclusive with the other arithmetic modes of a net. */
 int64_t caro_net_split_bf16_size(void);
 int caro_net_enable_split_bf16(caro_net* n, const uint16_t* parts_host, int64_t n_u16);

@@ -336,7 +336,7 @@ def test_large_board_net_serves_more_streams_than_it_has_slots():
 @pytest.mark.parametrize("L", [1, 5, 6, 7, 29, 300])
 def test_split_bf16_net_within_the_float32_tolerance(shape, A, weights, L):
     """The EXTRA arithmetic mode "bf16x3" (k_net_forward_x3: every float32 operand of the residual trunk, lib/model.py:36-47,
-    as three bfloat16 parts, six part products per multiply on v_mfma_f32_32x32x16_bf16, float32 accumulation) under the
+    as three bfloat16 parts, six part products per multiply on v_mfma_f32_16x16x32_bf16, float32 accumulation) under the
     gates of test_hip_net_matches_torch_fp32, UNCHANGED and on the same boards: |dP| < 1e-4, |dv| < 1e-4 against torch's
     float32 forward, and no further from a float64 forward than 4 x torch's own float32 distance.  It is NOT bit-identical
     to the float32 modes and no caller selects it by default."""
@@ -404,7 +404,7 @@ def test_split_bf16_parts_are_an_exact_decomposition_and_the_c_abi_refuses_misus
     assert (back.astype(np.float32) == w).mean() > 0.99
     img = pack_net_x3(net)
     L = _lib.load()
-    assert img.dtype == np.uint16 and img.size == L.caro_net_split_bf16_size() == 45 * 4 * 3 * 2 * 64 * 8
+    assert img.dtype == np.uint16 and img.size == L.caro_net_split_bf16_size() == 45 * 2 * 3 * 4 * 64 * 8
     hw = HipNet(net, "cuda:0", mode="f32w")
     assert L.caro_net_enable_split_bf16(hw.h, img.ctypes.data, img.size) == -71
     hw.close()
