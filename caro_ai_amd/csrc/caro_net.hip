@@ -680,16 +680,22 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
 // float32 operand of the residual trunk is written as the sum of three bfloat16 parts (hi + mid + lo = the float32 value,
 // 8 + 8 + 8 significant bits) and a product a*b is taken as the six part products of weight 2^-16 and above
 // (ah bh, ah bm, am bh, ah bl, al bh, am bm) on v_mfma_f32_16x16x32_bf16 with float32 accumulation: per wave and tap
-// 96 instructions of 16 cycles where the float32 direct form issues 64 of 64 cycles (the 16x16x32 shape because the chip
-// holds a 12-15 % higher clock under it than under 32x32x16 at the same flops: a full launch is power-limited).  The dropped products are below
-// 2^-24 of |a b|: the result is not bit-identical to the float32 kernels but within a small multiple of their own
-// rounding error (tests/test_gpu_net.py states the gate).  conv_in, the biases, the residual adds, LeakyReLU and the
-// heads stay float32 VALU code exactly as in k_net_forward.
-//   LDS: [0, 64 KB) float32 activations at both ends of the trunk, the ring of staged weight halves in between;
+// 96 instructions of 16 cycles where the float32 direct form issues 64 of 64 cycles.  The dropped products are below
+// 2^-24 of |a b|: the result is not bit-identical to the float32 kernels but in their own error class
+// (tests/test_gpu_net.py states the gates).  conv_in, the biases, the residual adds, LeakyReLU and the heads stay float32
+// code exactly as in the float32 kernels.
+//   Why the 16x16x32 shape: a full launch of this kernel is POWER-limited -- with v_mfma_f32_32x32x16_bf16 the chip held
+//   1.8-1.95 GHz and every cycle saved came back as a lower clock; under 16x16x32 it holds 2.2-2.3 GHz at the same flops
+//   and LDS traffic (same box, same launch: 102 -> 92 us; NOTES.md, profiles/r06_x3_*).
+//   LDS: [0, 64 KB) float32 activations at both ends of the trunk; in between the ring of staged weight halves (60 KB),
+//        the five layers' biases and every thread's output row;
 //        [64 KB, 160 KB) the split activations [3 parts][8 granules of 8 channels][256 rows][8 bf16].
 //   The weights arrive pre-split from the host: per (layer, tap) [2 c][3 parts][4 kg][64 co][8 ci] bf16 (24 576 B),
 //   ci = 32 c + 8 kg + 0..7.  The MFMA takes the WEIGHTS as its first operand: a lane then owns 4 x 4 consecutive output
-//   channels of TWO rows, and the epilogue writes its residual in 8-byte pieces of those rows.
+//   channels of TWO rows, keeps their residual stream in float32 registers across the layers, and the epilogue writes
+//   the split image of the new activations in 8-byte pieces of those rows.
+//   -DCARO_X3_TIMERS=1: a diagnostic build whose stamped launches (caro_net_forward_stamped) also report the cycles a
+//   wave spends in each phase of a tap (tools/probe_clock.py); no stamp executes in the product build's launches.
 #ifndef CARO_X3_TIMERS
 #define CARO_X3_TIMERS 0
 #endif
@@ -757,7 +763,6 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
   const int R = nb * HW;  // real rows
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int i = lane & 31, h = lane >> 5;
 
   for (int k = tid; k < ACT / 4; k += NT) reinterpret_cast<float4*>(lds)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int k = tid; k < 9 * 2 * NF; k += NT) wbuf[k] = p.w_in[k];
@@ -773,7 +778,6 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
   // 32 c + 8 kg + 0..7 of output channel 16 cb + r16 (weights) and of the neighbours of rows wave * 32 + 16 rb + r16
   // (activations), and receives output channels 16 cb + 4 kg + 0..3 of those two rows.
   const int r16 = lane & 15, kg = lane >> 4;
-  (void)i; (void)h;
   const int myrow0 = wave * 32 + r16, myrow1 = myrow0 + 16;
   const bool rvalid0 = myrow0 < R, rvalid1 = myrow1 < R;
   // The residual stream of this lane's 32 outputs stays in float32 registers across the layers: the epilogue adds to it

@@ -250,7 +250,7 @@ def _stats(steps, nodes, dr, t_call, t_ready, t_played, reused, passes):
 
 
 def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0,
-                     searches=cfg.MCTS_SEARCHES, batch=cfg.MCTS_BATCH_SIZE, concurrent=None, node_cap=None):
+                     searches=cfg.MCTS_SEARCHES, batch=cfg.MCTS_BATCH_SIZE, concurrent=None, node_cap=None, net_mode="f32w"):
     """self_play as a STREAM: the engine is never stopped between calls.  Every slot restarts the moment its game ends
     (uid += stride, in the tree kernel) and a call returns as soon as n_games games have FINISHED since the previous
     call; the games then in flight are not thrown away -- they finish inside the next call and reach the replay buffer
@@ -270,7 +270,7 @@ def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0,
         raise _lib.CaroError("self_play_stream needs whole wavefronts per game (batch x lanes per descent a multiple of 64)")
     G = max(1, int(concurrent or n_games))
     stride = world * G
-    hip = net_hip.hipnet_for(net, device)
+    hip = net_hip.hipnet_for(net, device, mode=net_mode)
     hw = game.obs_shape[1] * game.obs_shape[2]
     from caro_ai_amd.engine import SelfPlayEngine
     cap = int(node_cap) if node_cap else SelfPlayEngine.default_node_cap(searches, batch, hw)
@@ -332,7 +332,7 @@ def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0,
 
 
 def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0, searches=cfg.MCTS_SEARCHES,
-              batch=cfg.MCTS_BATCH_SIZE, concurrent=None, stagger=False, reuse=True, node_cap=None, pool=True):
+              batch=cfg.MCTS_BATCH_SIZE, concurrent=None, stagger=False, reuse=True, node_cap=None, pool=True, net_mode="f32w"):
     """Play n_games (per rank) with the (best) net against itself, tuples appended on the device.
     Returns speed_steps, speed_nodes, steps, nodes (train.py:49-58) on the wall clock of the WHOLE call -- engine
     construction or restart, weight upload, the games, the tuple exchange --, plus where the time went.
@@ -350,6 +350,9 @@ def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_ba
     shape and restarted in place; a reused engine plays the games of a fresh one bit for bit
     (tests/test_gpu_stagger.py::test_reused_self_play_engine_plays_the_fresh_engines_games).
     node_cap: nodes per tree (default: searches x batch x cells, which cannot overflow).
+    net_mode: the HipNet arithmetic mode (net_hip.HipNet): "f32w" (default, float32) or the opt-in "bf16x3" (split
+    bfloat16 operands, float32 accumulate: 1.3 x the leaves/s, outputs within the float32 kernels' own tolerance, not
+    bit-identical to them).
     Raises CaroError if a tree overflowed its node pool (the games would no longer be the reference's)."""
     from caro_ai_amd import net_hip
     t_call = time.time()
@@ -363,7 +366,7 @@ def self_play(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_ba
     # the call ended with the longest chain of a slot's games: 111-115 passes for 4 096 games on 1 024 slots against 92-94)
     run = dict(seed=seed, uid_base=base, uid_stride=stride, games_limit=n_games,
                stagger_recycle=(2 if (stagger and pool) else 1) if restarts else 0, steps_before_tau_0=cfg.STEPS_BEFORE_TAU_0)
-    hip = net_hip.hipnet_for(net, device)
+    hip = net_hip.hipnet_for(net, device, mode=net_mode)
     eng, reused = _engine_for(game, G, batch, searches, device, stagger, run, hip, reuse, node_cap)
     t_ready = time.time()
     dr = _Drains()  # (every drained game is a wanted one: games_limit)
@@ -495,6 +498,10 @@ def parse_args(argv=None):
     p.add_argument("--sharded-evaluate", action="store_true",
                    help="arena gate as independent rounds with fresh trees, concurrent and sharded over the ranks (the "
                         "default under several ranks; a declared deviation from the reference's evaluate)")
+    p.add_argument("--net-mode", default="f32w", choices=["f32w", "bf16x3"],
+                   help="arithmetic of the self-play net kernel: f32w = float32 (default); bf16x3 = every float32 operand of "
+                        "the residual trunk as three bfloat16 parts, float32 accumulate -- 1.3 x the leaves/s, outputs within "
+                        "the float32 kernels' own tolerance but not bit-identical to them (the arena gate stays float32)")
     p.add_argument("--ddp", action="store_true",
                    help="several ranks: every rank trains on its share of each batch, gradients all-reduced "
                         "(default: rank 0 trains, the weights are broadcast)")
@@ -502,7 +509,7 @@ def parse_args(argv=None):
 
 
 def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, reference_evaluate=None, ddp=False,
-        sample_seed=None, stop=None, log=print, concurrent=None, stream=False):
+        sample_seed=None, stop=None, log=print, concurrent=None, stream=False, net_mode="f32w"):
     """The reference's training loop (train.py:165-217): self-play with the best net -> replay buffer -> TRAIN_ROUNDS SGD
     steps -> every EVALUATE_EVERY_STEP iterations the arena gate (challenger = the net being trained against the best
     net; promoted when its win ratio exceeds BEST_NET_WIN_RATIO: `NetWrapper.sync`, `best_%03d_%05d.dat`).
@@ -516,7 +523,8 @@ def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, re
     ends the loop early (several ranks: rank 0 decides, the others follow).  `concurrent`: game slots per rank (default:
     one per game).  stream=True: self-play as a stream (`self_play_stream`: slots restart at once, an iteration takes
     the first `games` games that finish, games in flight carry over to the next iteration -- no sparse tail; where the
-    geometry has no staggered mode the exact form is used).  Returns the history: per trained iteration the three losses, per evaluation (iteration, win
+    geometry has no staggered mode the exact form is used).  net_mode: the self-play net kernel's arithmetic (`self_play`;
+    the arena gate always runs float32).  Returns the history: per trained iteration the three losses, per evaluation (iteration, win
     ratio, promoted), the number of promotions, the best net wrapper, and per iteration the seconds each phase took
     (`phases`: self_play -- with its own setup / play / gather split --, train, broadcast, evaluate)."""
     rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
@@ -539,10 +547,10 @@ def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, re
         t0 = clock()
         if stream and staggered_ok(game, cfg.MCTS_BATCH_SIZE):
             sp = self_play_stream(game, replay_buffer, best_net.target_model, games, device=device, seed=0,
-                                  uid_base=step_idx * games * world, concurrent=concurrent)
+                                  uid_base=step_idx * games * world, concurrent=concurrent, net_mode=net_mode)
         else:
             sp = self_play(game, replay_buffer, best_net.target_model, games, device=device, seed=step_idx,
-                           uid_base=step_idx * games * world, stagger=True, concurrent=concurrent)
+                           uid_base=step_idx * games * world, stagger=True, concurrent=concurrent, net_mode=net_mode)
         ph = {"self_play": clock() - t0, "self_play_setup": sp["seconds_setup"], "self_play_play": sp["seconds_play"],
               "self_play_gather": sp["seconds_gather"], "engine_reused": sp["engine_reused"], "nodes": sp["nodes"],
               "train": 0.0, "broadcast": 0.0, "evaluate": 0.0}
@@ -617,7 +625,7 @@ def main(argv=None):
     fit(game, net, device, args.games, iterations=args.iterations, saves_path=saves_path, writer=writer,
         reference_evaluate=True if args.reference_evaluate else False if args.sharded_evaluate else None, ddp=args.ddp,
         log=lambda m: print(m, flush=True),
-        concurrent=args.concurrent or min(args.games, 1024), stream=not args.exact_self_play)
+        concurrent=args.concurrent or min(args.games, 1024), stream=not args.exact_self_play, net_mode=args.net_mode)
     writer.close()
     release_engines()  # (the self-play engines are kept between iterations: gigabytes of tree tables)
 

@@ -521,3 +521,27 @@ def test_self_play_pool_plays_the_same_games():
     # (the passes: with many short games per slot the pool form ends sooner -- bench.py's train_loop: 95 against 113 for
     # 4 096 games on 1 024 slots --; with 8 long games per slot, as here, the two are about even)
     assert out[True][2] <= out[False][2] * 1.1
+
+
+def test_self_play_with_the_split_bf16_net_mode():
+    """train.self_play / self_play_stream with net_mode="bf16x3" (the opt-in arithmetic of k_net_forward_x3): complete
+    games of the wanted uids, no overflow, tuples of the usual shape; and the cached HipNet of the default mode is a
+    different object (a mode change never reuses the other mode's weights image)."""
+    import torch
+    from caro_ai_amd import net_hip, train
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    from caro_ai_amd.train import DeviceReplayBuffer
+    g = ConnectFour()
+    net = Net(g.obs_shape, g.action_space)
+    net.load_state_dict(torch.load(os.path.join(WEIGHTS, "best_026_12000.dat"), map_location="cpu"))
+    net = net.to("cuda:0").eval()
+    assert net_hip.hipnet_for(net, "cuda:0", mode="bf16x3") is not net_hip.hipnet_for(net, "cuda:0")
+    assert net_hip.hipnet_for(net, "cuda:0", mode="bf16x3").mode == "bf16x3"
+    rb = DeviceReplayBuffer(g, 20000, "cuda:0")
+    sp = train.self_play(g, rb, net, 48, seed=3, searches=5, batch=8, concurrent=16, stagger=True, net_mode="bf16x3")
+    assert sp["games"] == 48 and sp["nodes"] > 0 and len(rb) == sp["steps"] >= 48 * 7
+    st = train.self_play_stream(g, rb, net, 32, seed=3, searches=5, batch=8, concurrent=16, net_mode="bf16x3")
+    assert st["games"] >= 32 and st["nodes"] > 0
+    train.release_engines()
+    net_hip.release_hipnets()

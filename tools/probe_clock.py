@@ -42,7 +42,7 @@ for rows in (1434, 600) + ((1700, 2300) if mode == "f32w" else ()):
         mfma_cycles, 100 * mfma_cycles / np.median(cyc)))
     if mode == "bf16x3" and os.environ.get("CARO_X3_TIMERS"):  # diagnostic build -DCARO_X3_TIMERS=1: per-phase cycles of wave 0, summed over the 45 taps
         t = stamps.cpu().numpy()[4 * 512:4 * 512 + 8 * grid].reshape(-1, 8).astype(np.float64)
-        names = ["top: staging loads", "LOAD(y,c1) + MFMA(x,c0)", "LOAD(x,c2) + MFMA(y,c1)", "LOAD(y,c3) + MFMA(x,c2)",
-                 "staged writes + prefetch + MFMA(y,c3)", "closing barrier"]
+        names = ["top: staging loads issued", "segment (c0, blocks 0-1) + reads of (c0, 2-3)", "segment (c0, 2-3) + reads of c1",
+                 "segment (c1, 0-1) + reads of (c1, 2-3)", "segment (c1, 2-3) + staged writes + next tap's first sets", "closing barrier"]
         for q, nm in enumerate(names):
             print("      %-52s %8.0f cycles (median), %6.0f per tap" % (nm, np.median(t[:, q]), np.median(t[:, q]) / 45))
