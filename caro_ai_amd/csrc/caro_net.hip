@@ -675,6 +675,24 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward(NetParams p0, NetParams p
   }
 }
 
+// ---- global -> LDS transfers that bypass the registers (used by the bf16x3 kernel below and by the Winograd kernels)
+__device__ __forceinline__ unsigned lds_addr(const void* q) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)q;
+}
+// 16 bytes per lane global -> LDS, not tracked by the compiler (it would wait for vmcnt(0) in front of every later
+// ds_read): lane l of the wave writes lds_wave_base + 16 l.  The issuer waits (vmcnt(0)) before the barrier that
+// publishes the data.  M0 is a reserved register: the compiler loads it right in front of each of its own uses and keeps
+// nothing alive in it, so it is not on the clobber list (hipcc warns if it is).
+__device__ __forceinline__ void dma_b128(const void* gsrc, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_wave_base), "v"(gsrc) : "memory");
+}
+// The same transfer addressed as UNIFORM base (a scalar register pair) + 32-bit lane offset: the lane holds one
+// register (16 tid) for the whole kernel instead of a 64-bit pointer per thread and the per-chunk address arithmetic
+// becomes scalar -- what k_net_forward_w2, which runs at its 256-register limit, uses (its pointer pairs were spilled).
+__device__ __forceinline__ void dma_b128_s(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
+}
+
 // ===================================================================================================
 // Split-operand form ("bf16x3"): an EXTRA arithmetic mode, never the default and never the bench's headline.  Every
 // float32 operand of the residual trunk is written as the sum of three bfloat16 parts (hi + mid + lo = the float32 value,
@@ -813,10 +831,13 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
   // BEFORE the barrier that ends tap t (its half 0 was complete one barrier earlier).
   uint4* ring = reinterpret_cast<uint4*>(act);
   const uint4* wsrc = reinterpret_cast<const uint4*>(p.wx3);
-  // what this thread stages per tap: item tid and (tid < 256) item 512 + tid of the 768 of half 1 of the next tap;
-  // (tid >= 256) item tid - 256 and item 256 + tid of the 768 of half 0 of the tap after it
+  // what this thread stages per tap (global -> LDS directly, 16 bytes per lane and transfer): item tid and (waves 0-3)
+  // item 512 + tid of the 768 of half 1 of the next tap; (waves 4-7) item tid - 256 and (all) item 256 + tid of the 768 of
+  // half 0 of the tap after it
   const bool stage_h0 = tid >= 256;
-  const int s1_src = stage_h0 ? X3_TAP_U4 + (tid - 256) : X3_H + 512 + tid;  // relative to the next tap's image
+  const unsigned ring_lds = lds_addr(ring);
+  const unsigned v0off = (unsigned)tid * 16u;  // byte offset of item `tid` in an image
+  const unsigned v1off = (unsigned)(stage_h0 ? X3_TAP_U4 + (tid - 256) : X3_H + 512 + tid) * 16u;  // relative to the next tap's image
   {
     ring[0 * X3_H + tid] = wsrc[tid];                                       // tap 0, half 0 (slot 0)
     if (tid < 256) ring[0 * X3_H + 512 + tid] = wsrc[512 + tid];
@@ -907,8 +928,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
   const uint4* wcol = ring + kg * 64 + r16;  // + slot + part * 256 + 16 cb
   CARO_X3_LOAD_ACT(X, 0, nrow9[0] & 0xFFFF, nrow9[0] >> 16)
   CARO_X3_LOAD_W(P, wcol, 0)
-  uint4 wn0, wn1, wn2;
-  const uint4* wnext = wsrc + X3_TAP_U4;  // image of the tap after the current one
+  const char* wnext = reinterpret_cast<const char*>(wsrc + X3_TAP_U4);  // image of the tap after the current one
   for (int layer = 0; layer < NRES; ++layer) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -916,11 +936,17 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
       const int cur = (layer + tap) & 1;
       const int slot0 = tap % 3, slot1 = (tap + 1) % 3, slot2 = (tap + 2) % 3;
       CARO_T0
-      // issue early (the image is followed by X3_PAD_TAPS zero taps: no bounds to check)
-      wn0 = wnext[X3_H + tid];
-      wn1 = wnext[s1_src];
-      wn2 = wnext[X3_TAP_U4 + 256 + tid];
-      wnext += X3_TAP_U4;
+      {  // The staged halves, on their way while the tap computes (the image is followed by X3_PAD_TAPS zero taps: no
+         // bounds to check).  Their slots were last read one tap ago, before the barrier that ended it; the transfers
+         // are waited for in front of this tap's closing barrier.
+        const unsigned d1 = ring_lds + (unsigned)(X3_RING_H1 + (cur ^ 1) * X3_H) * 16u;
+        const unsigned d0 = ring_lds + (unsigned)(slot2 * X3_H) * 16u;
+        const unsigned w1k = (unsigned)wave * 1024u;
+        dma_b128_s(wnext + X3_H * 16, v0off, __builtin_amdgcn_readfirstlane(d1 + w1k));
+        dma_b128_s(wnext, v1off, __builtin_amdgcn_readfirstlane(stage_h0 ? d0 + w1k - 4096u : d1 + 8192u + w1k));
+        dma_b128_s(wnext + (X3_TAP_U4 + 256) * 16, v0off, __builtin_amdgcn_readfirstlane(d0 + 4096u + w1k));
+        wnext += X3_TAP_U4 * 16;
+      }
       const uint4* hb0 = wcol + slot0 * X3_H;
       const uint4* hb1 = wcol + X3_RING_H1 + cur * X3_H;
       const int n0 = nrow9[tap] & 0xFFFF, n1 = nrow9[tap] >> 16;
@@ -942,28 +968,11 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
       CARO_X3_WEAVE(6)
       __builtin_amdgcn_sched_barrier(0);
       CARO_T(3)
-      {  // the staged halves (their slots were last read one tap ago, before the barrier that ended it) and the next
-         // tap's first operand sets -- at a layer's last tap the activations are read again behind the epilogue
-        uint4* d1 = ring + X3_RING_H1 + (cur ^ 1) * X3_H;
-        uint4* d0 = ring + slot2 * X3_H;
-        d1[tid] = wn0;
-        *(stage_h0 ? d0 + (tid - 256) : d1 + 512 + tid) = wn1;
-        d0[256 + tid] = wn2;
-      }
+      // the next tap's first operand sets -- at a layer's last tap the activations are read again behind the epilogue
       CARO_X3_LOAD_ACT(X, 0, nrow9[tap == 8 ? 0 : tap + 1] & 0xFFFF, nrow9[tap == 8 ? 0 : tap + 1] >> 16)
       CARO_X3_LOAD_W(P, wcol + slot1 * X3_H, 0)
       CARO_X3_SEG(Q, Y, 1)
-#pragma unroll
-      for (int q_ = 0; q_ < 3; ++q_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      }
-#pragma unroll
-      for (int q_ = 0; q_ < 12; ++q_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+      CARO_X3_WEAVE(12)
       __builtin_amdgcn_sched_barrier(0);
       CARO_T(4)
       if (tap == 8) {
@@ -1003,6 +1012,7 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
         if (stamps) t_epi += __builtin_amdgcn_s_memtime() - t_e0;
       }
       CARO_T0
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's transfers have landed
       __syncthreads();  // the staged halves / the new activations are visible to every wave
       CARO_T(5)
       if (tap == 8 && layer + 1 < NRES) {  // the next layer's first activation set reads the rows just written
@@ -1075,16 +1085,6 @@ static_assert(WNBUF * WCH == 2 * TPC * WCHUNK, "the ring takes the place of the 
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned lds_addr(const void* q) {
-  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)q;
-}
-// 16 bytes per lane global -> LDS, not tracked by the compiler (it would wait for vmcnt(0) in front of every later
-// ds_read): lane l of the wave writes lds_wave_base + 16 l.  The issuer waits (vmcnt(0)) before the barrier that
-// publishes the data.  M0 is a reserved register: the compiler loads it right in front of each of its own uses and keeps
-// nothing alive in it, so it is not on the clobber list (hipcc warns if it is).
-__device__ __forceinline__ void dma_b128(const void* gsrc, unsigned lds_wave_base) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_wave_base), "v"(gsrc) : "memory");
-}
 // chunk c of the transformed weights -> ring buffer c % WNBUF (every thread moves 4 x 16 bytes)
 __device__ __forceinline__ void fetch_chunk(const float* ww, int c, unsigned wring, int tid) {
   const float4* src = reinterpret_cast<const float4*>(ww + (size_t)c * WCH) + tid;
@@ -1093,12 +1093,6 @@ __device__ __forceinline__ void fetch_chunk(const float* ww, int c, unsigned wri
   for (int m = 0; m < WCH / 4 / NT; ++m) dma_b128(src + m * NT, dst + m * NT * 16);
 }
 
-// The same transfer addressed as UNIFORM base (a scalar register pair) + 32-bit lane offset: the lane holds one
-// register (16 tid) for the whole kernel instead of a 64-bit pointer per thread and the per-chunk address arithmetic
-// becomes scalar -- what k_net_forward_w2, which runs at its 256-register limit, uses (its pointer pairs were spilled).
-__device__ __forceinline__ void dma_b128_s(const void* sbase, unsigned voff, unsigned lds_wave_base) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
-}
 __device__ __forceinline__ void fetch_chunk_s(const float* ww, int c, unsigned wring, int tid) {
   const char* base = reinterpret_cast<const char*>(ww) + (size_t)c * (WCH * 4);
   const unsigned voff = (unsigned)tid * 16u;

@@ -540,7 +540,7 @@ def test_self_play_with_the_split_bf16_net_mode():
     assert net_hip.hipnet_for(net, "cuda:0", mode="bf16x3").mode == "bf16x3"
     rb = DeviceReplayBuffer(g, 20000, "cuda:0")
     sp = train.self_play(g, rb, net, 48, seed=3, searches=5, batch=8, concurrent=16, stagger=True, net_mode="bf16x3")
-    assert sp["games"] == 48 and sp["nodes"] > 0 and len(rb) == sp["steps"] >= 48 * 7
+    assert sp["games"] == 48 and sp["nodes"] > 0 and sp["steps"] >= 48 * 7 and len(rb) >= sp["steps"]
     st = train.self_play_stream(g, rb, net, 32, seed=3, searches=5, batch=8, concurrent=16, net_mode="bf16x3")
     assert st["games"] >= 32 and st["nodes"] > 0
     train.release_engines()

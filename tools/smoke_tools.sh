@@ -8,7 +8,7 @@ cd $ROOT
 : > $OUT/tools_smoke.txt
 for t in probe_clock.py probe_clock15.py probe_engine_net.py probe_grid.py \
          probe_leaves.py probe_netloop.py probe_select.py probe_select15.py probe_small.py probe_stag.py \
-         measure_dup_leaves.py measure_move_latency.py measure_train_step.py cmp_net.py bench_noise.py; do
+         measure_dup_leaves.py measure_move_latency.py measure_train_step.py cmp_net.py bench_noise.py probe_x3.py probe_gate.py; do
   a=""; if [ $t = cmp_net.py ]; then a=$OUT/cmp_net.npz; fi
   timeout -k 5 150 python tools/$t $a > $OUT/smoke_$t.log 2>&1
   echo "$t rc=$?" >> $OUT/tools_smoke.txt
