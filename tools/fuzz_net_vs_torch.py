@@ -31,7 +31,7 @@ def main():
     for shape in [(2, 6, 7)] + [(2, n, n) for n in range(3, 16)]:
         A = 7 if shape == (2, 6, 7) else shape[1] * shape[2]
         net = _net(shape, A, None, seed=int(rng.integers(1 << 20)))
-        modes = ["f32", "f32w", "f32w1"] + (["f32w2"] if L_.caro_net_winograd2d_supported(shape[1], shape[2]) else [])
+        modes = ["f32", "f32w", "f32w1", "bf16x3"] + (["f32w2"] if L_.caro_net_winograd2d_supported(shape[1], shape[2]) else [])
         hn = {m: HipNet(net, "cuda:0", mode=m) for m in modes}
         tb = {m: int(L_.caro_net_boards_per_workgroup(hn[m].h)) for m in modes}
         sizes = {1, 2, int(rng.integers(3, 40))}
