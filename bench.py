@@ -825,6 +825,15 @@ def main():
                                   "note": "the same 1024 games as two engines of 512 on two HIP streams, in this run: one "
                                           "half's tree kernels run in the partly filled last round of the other half's net "
                                           "launch; bit-identical per game"}
+            if args.net == "hipw":
+                # config 4 with the opt-in bf16x3 kernel (k_net_forward_x3 + k_net_heads): labelled, beside the leg's value
+                x4 = side_leg("config4-bf16x3", dict(c4, net="hipx3"), args.config4_steps, args.config4_warmup, False)
+                one["net_bf16x3"] = {"value": x4["value"], "unit": x4["unit"], "ms_per_step": x4["ms_per_step"],
+                                     "vs_config4": x4["value"] / one["value"], "games_finished": x4["games_finished"],
+                                     "overflows": x4["overflows"],
+                                     "note": "extra, not this leg's value: the same configuration with lib/model.py Net in "
+                                             "bf16x3 split-operand arithmetic, fp32 accumulate (direct 3x3 form, "
+                                             "k_net_forward_x3 + k_net_heads); not bit-identical to the fp32 kernels"}
             extras["config4"] = one
         except Exception as e:
             import traceback

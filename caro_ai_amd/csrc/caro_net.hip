@@ -749,7 +749,8 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
                                                             const int32_t* __restrict__ counts, int which, int row1,
                                                             float* __restrict__ probs, float* __restrict__ values,
                                                             unsigned long long* __restrict__ stamps,
-                                                            const int32_t* __restrict__ gpack, int gG, int gB) {
+                                                            const int32_t* __restrict__ gpack, int gG, int gB,
+                                                            float* __restrict__ featbuf, int32_t* __restrict__ rowlist) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* act = lds;
   float* wbuf = lds + ACT;
@@ -1040,7 +1041,9 @@ __global__ __launch_bounds__(NT, 2) void k_net_forward_x3(NetParams p0, NetParam
   __syncthreads();
   unsigned long long t_trunk1 = 0;
   if (stamps) t_trunk1 = __builtin_amdgcn_s_memtime();
-  heads_f32<false>(p, act, wbuf, probs, values, slot_v, nb, R, tid);
+  // featbuf != null (one board per workgroup): only the 1x1 convolutions here, the FC heads of the whole launch follow in
+  // k_net_heads (row0 + board0 = this board's dense index)
+  heads_f32<false>(p, act, wbuf, probs, values, slot_v, nb, R, tid, featbuf, rowlist, row0 + board0);
   if (stamps && tid == 0) {
     stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_c0;
     stamps[4 * blockIdx.x + 1] = ((__builtin_amdgcn_s_memrealtime() - t_r0) & 0xFFFFFull) | (t_epi << 20);  // + the five epilogues
@@ -2569,6 +2572,45 @@ int caro_net_create_hash(int H, int W, int A, uint64_t salt, int device_id, caro
   return 0;
 }
 
+// The feature rows of a launch whose FC heads follow in k_net_heads, per (net handle, stream): the table slot of `stream`
+// (least recently used one re-keyed when the table is full), grown to `need` rows.
+static int head_rows_for(caro_net* n0, void* stream, int64_t need, caro_net::HeadRows** out) {
+  caro_net::HeadRows* hr = nullptr;
+  for (int k = 0; k < n0->n_hrows; ++k)
+    if (n0->hrows[k].stream == stream) hr = &n0->hrows[k];
+  if (!hr) {
+    if (n0->n_hrows == 8) {
+      // table full (a long-lived net launched on transient streams: engines recreated per iteration): the least
+      // recently used slot goes.
+      hr = &n0->hrows[0];
+      for (int k = 1; k < 8; ++k)
+        if (n0->hrows[k].used < hr->used) hr = &n0->hrows[k];
+      // The slot's buffers are KEPT and only re-keyed (they are re-allocated below if the new stream needs more
+      // rows): one device synchronisation -- launches of the old stream may still read them -- instead of a
+      // synchronising hipFree pair + two hipMallocs.  A net used round-robin on more than 8 streams pays this on
+      // every launch: caro_net_stream_evictions() counts them.
+      if (hipDeviceSynchronize() != hipSuccess) return nfail(CARO_E_HIP, "hipDeviceSynchronize failed");
+      n0->hrows_evictions += 1;
+      hr->stream = stream;
+    } else {
+      hr = &n0->hrows[n0->n_hrows++];
+      hr->stream = stream; hr->feat = nullptr; hr->rowl = nullptr; hr->rows = 0;
+    }
+  }
+  hr->used = ++n0->hrows_clock;
+  if (hr->rows < need) {
+    if (hr->feat) (void)hipFree(hr->feat);
+    if (hr->rowl) (void)hipFree(hr->rowl);
+    hr->feat = nullptr; hr->rowl = nullptr; hr->rows = 0;
+    if (hipMalloc((void**)&hr->feat, (size_t)need * 3 * n0->p.HW * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&hr->rowl, (size_t)need * sizeof(int32_t)) != hipSuccess)
+      return nfail(CARO_E_NOMEM, "hipMalloc of the head feature rows failed");
+    hr->rows = need;
+  }
+  *out = hr;
+  return 0;
+}
+
 // one launch of whichever kernel serves this pair of nets.  which 0 / 1: net n0 on its class' rows; 2: both.
 // gpack != null: slot rows (caro_net_forward_slots), otherwise dense rows.
 static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const int32_t* counts_dev, int which,
@@ -2586,39 +2628,8 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
     if (n0->p.ww2) {
       // the trunk launch leaves every board's three feature planes in n0's feature buffer; the FC heads of the whole
       // launch follow, 32 boards per workgroup (k_net_heads).  The buffer grows to the largest launch seen (first call).
-      const int64_t need = max_rows + (row1 > 0 ? row1 : 0) + 64;
       caro_net::HeadRows* hr = nullptr;
-      for (int k = 0; k < n0->n_hrows; ++k)
-        if (n0->hrows[k].stream == stream) hr = &n0->hrows[k];
-      if (!hr) {
-        if (n0->n_hrows == 8) {
-          // table full (a long-lived net launched on transient streams: engines recreated per iteration): the least
-          // recently used slot goes.  hipFree waits for the device, so nothing in flight still reads its rows.
-          hr = &n0->hrows[0];
-          for (int k = 1; k < 8; ++k)
-            if (n0->hrows[k].used < hr->used) hr = &n0->hrows[k];
-          // The slot's buffers are KEPT and only re-keyed (they are re-allocated below if the new stream needs more
-          // rows): one device synchronisation -- launches of the old stream may still read them -- instead of a
-          // synchronising hipFree pair + two hipMallocs.  A net used round-robin on more than 8 streams pays this on
-          // every launch: caro_net_stream_evictions() counts them.
-          if (hipDeviceSynchronize() != hipSuccess) return nfail(CARO_E_HIP, "hipDeviceSynchronize failed");
-          n0->hrows_evictions += 1;
-          hr->stream = stream;
-        } else {
-          hr = &n0->hrows[n0->n_hrows++];
-          hr->stream = stream; hr->feat = nullptr; hr->rowl = nullptr; hr->rows = 0;
-        }
-      }
-      hr->used = ++n0->hrows_clock;
-      if (hr->rows < need) {
-        if (hr->feat) (void)hipFree(hr->feat);
-        if (hr->rowl) (void)hipFree(hr->rowl);
-        hr->feat = nullptr; hr->rowl = nullptr; hr->rows = 0;
-        if (hipMalloc((void**)&hr->feat, (size_t)need * 3 * n0->p.HW * sizeof(float)) != hipSuccess ||
-            hipMalloc((void**)&hr->rowl, (size_t)need * sizeof(int32_t)) != hipSuccess)
-          return nfail(CARO_E_NOMEM, "hipMalloc of the head feature rows failed");
-        hr->rows = need;
-      }
+      if (int rc = head_rows_for(n0, stream, max_rows + (row1 > 0 ? row1 : 0) + 64, &hr)) return rc;
       hipLaunchKernelGGL(cnet::k_net_forward_w2, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B,
                          hr->feat, hr->rowl, slist);
@@ -2630,9 +2641,23 @@ static int net_launch(caro_net* n0, caro_net* n1, const float* planes_dev, const
     else if (n0->p.ww)
       hipLaunchKernelGGL(cnet::k_net_forward_w, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, stamps ? stamps : n0->dbg_stamps, gpack, G, B);
-    else if (n0->p.wx3)
+    else if (n0->p.wx3) {
+      // one board per workgroup (12x12 .. 15x15) and the transposed policy matrix at hand: the FC heads of the whole
+      // launch follow in k_net_heads, as for the 2-D Winograd form
+      const bool batched = n0->p.TB == 1 && n0->p.w_pT && n0->p.HW <= cnet::HEADS_MAX_CELLS;
+      caro_net::HeadRows* hr = nullptr;
+      if (batched)
+        if (int rc = head_rows_for(n0, stream, max_rows + (row1 > 0 ? row1 : 0) + 64, &hr)) return rc;
       hipLaunchKernelGGL(cnet::k_net_forward_x3, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
-                         counts_dev, which, row1, probs_dev, values_dev, stamps, gpack, G, B);
+                         counts_dev, which, row1, probs_dev, values_dev, stamps, gpack, G, B, hr ? hr->feat : nullptr,
+                         hr ? hr->rowl : nullptr);
+      if (hr) {
+        if (hipGetLastError() != hipSuccess) return nfail(CARO_E_HIP, "net kernel launch failed");
+        const unsigned hgrid = (unsigned)((max_rows + cnet::HB - 1) / cnet::HB) + (which == 2 ? 1u : 0u);
+        hipLaunchKernelGGL(cnet::k_net_heads, dim3(hgrid), dim3(cnet::NT), 0, st, n0->p, n1->p, counts_dev, which, row1,
+                           hr->feat, hr->rowl, probs_dev, values_dev);
+      }
+    }
     else
       hipLaunchKernelGGL(cnet::k_net_forward, dim3(grid), dim3(cnet::NT), 0, st, n0->p, n1->p, planes_dev,
                          counts_dev, which, row1, probs_dev, values_dev, stamps, gpack, G, B);

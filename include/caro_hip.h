@@ -287,7 +287,9 @@ int caro_net_enable_winograd2d(caro_net* n, const float* ww2_host, int64_t n_flo
  * adds, LeakyReLU and the heads in float32 as in the default kernel.  NOT bit-identical to the float32 modes: within
  * the tolerance tests/test_gpu_net.py states for it.  parts_host: caro_net_split_bf16_size() uint16 =
  * [45 (layer, tap)][2 c][3 parts][4 kg][64 co][8 ci] bfloat16 bit patterns, ci = 32 c + 8 kg + 0..7
- * (caro_ai_amd/net_hip.py:pack_net_x3).  Mutually exclusive with the other arithmetic modes of a net. */
+ * (caro_ai_amd/net_hip.py:pack_net_x3).  Mutually exclusive with the other arithmetic modes of a net.  On boards served one
+ * per workgroup (12x12 .. 15x15) a forward call is two launches, as in f32w2 mode: the trunk, then the FC heads + softmax of
+ * the whole call 32 boards per workgroup, with the feature rows kept per (net handle, stream) as described below. */
 int64_t caro_net_split_bf16_size(void);
 int caro_net_enable_split_bf16(caro_net* n, const uint16_t* parts_host, int64_t n_u16);
 /* how often a slot of that (handle, stream) table had to change its stream: 0 while a handle serves at most 8 streams;

@@ -414,3 +414,46 @@ def test_split_bf16_parts_are_an_exact_decomposition_and_the_c_abi_refuses_misus
     ww = np.zeros(60 * 4096, np.float32)
     assert L.caro_net_enable_winograd(hf.h, ww.ctypes.data, ww.size) == -71
     hf.close()
+
+
+def test_split_bf16_net_on_large_boards_uses_the_batched_heads():
+    """bf16x3 on boards of one per workgroup (12x12 .. 15x15): the trunk launch is followed by k_net_heads (the FC heads of
+    the whole launch, 32 boards per workgroup) exactly as in f32w2 mode -- same gates; 11x11 (two boards per workgroup)
+    keeps the heads inside the kernel; two nets in one launch (an arena) agree with two single launches bit for bit."""
+    import ctypes as C
+    from caro_ai_amd import _lib
+    from caro_ai_amd.net_hip import HipNet
+    for n, L in ((15, 70), (12, 33), (11, 40)):
+        shape = (2, n, n)
+        net = _net(shape, n * n, None, seed=n)
+        x = _boards(L, shape, 3 * n)
+        with torch.no_grad():
+            lg, vl = net(x)
+            p_ref = torch.softmax(lg, dim=1)
+            lg64, _ = net.double()(x.double())
+            p64 = torch.softmax(lg64, dim=1)
+        net.float()
+        hn = HipNet(net, "cuda:0", mode="bf16x3")
+        assert hn.L.caro_net_boards_per_workgroup(hn.h) == (1 if n >= 12 else 2)
+        p, v = hn(x.to("cuda:0"))
+        torch.cuda.synchronize()
+        assert (p.cpu() - p_ref).abs().max().item() < 1e-4 and (v.cpu() - vl[:, 0]).abs().max().item() < 1e-4
+        e_hip, e_ref = (p.cpu().double() - p64).abs().max().item(), (p_ref.double() - p64).abs().max().item()
+        assert e_hip < max(4 * e_ref, 1e-6), (n, e_hip, e_ref)
+        if n == 15:  # pair launch: rows [0, 40) through net a, [40, 70) through net b
+            net_b = _net(shape, n * n, None, seed=99)
+            hb = HipNet(net_b, "cuda:0", mode="bf16x3")
+            xb = x.to("cuda:0")
+            pa, va = hn(xb[:40].contiguous())
+            pb, vb = hb(xb[40:].contiguous())
+            counts = torch.tensor([40, 30], dtype=torch.int32, device="cuda:0")
+            probs = torch.empty((L, n * n), dtype=torch.float32, device="cuda:0")
+            values = torch.empty(L, dtype=torch.float32, device="cuda:0")
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(hn.L.caro_net_forward_pair(hn.h, hb.h, xb.data_ptr(), counts.data_ptr(), L, probs.data_ptr(),
+                                                  values.data_ptr(), st))
+            torch.cuda.synchronize()
+            assert torch.equal(probs[:40], pa) and torch.equal(probs[40:], pb)
+            assert torch.equal(values[:40], va) and torch.equal(values[40:], vb)
+            hb.close()
+        hn.close()

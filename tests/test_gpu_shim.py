@@ -535,7 +535,7 @@ def test_config4_conv_net_exact_with_reference_net_arithmetic():
         eng.close()
 
 
-@pytest.mark.parametrize("inference", ["hipw", "hipw1", "hip"])
+@pytest.mark.parametrize("inference", ["hipw", "hipw1", "hip", "hipx3"])  # hipx3: the opt-in bf16x3 form (+ k_net_heads here)
 def test_config4_conv_net_on_gpu_vs_reference_games(inference):
     """The same recorded games against the engine with the net ON THE GPU (fused HIP kernel: hipw = the 2-D Winograd
     form F(2x2,3x3) that config 4 runs from round 4 on, hipw1 = the row form, hip = direct convolutions),
