@@ -503,7 +503,10 @@ class Leg:
                         # the direct-convolution count is kept beside it as algorithmic_*
                         "achieved": ex, "peak": peak, "unit": "TFLOP/s", "frac": ex / peak,
                         "algorithmic_achieved": achieved, "algorithmic_frac": achieved / peak,
-                        "note": "achieved = flops the matrix pipe executes per launch (Winograd form: fewer multiplies "
+                        "note": ("bf16x3 leg: flops = the six bf16 part products per multiply the pipe executes, peak = "
+                                 "the bf16 MFMA peak; a utilisation figure of the pipe, not comparable with the fp32 legs' "
+                                 "-- compare avg_launch_us.  " if self.net == "hipx3" else "") +
+                                "achieved = flops the matrix pipe executes per launch (Winograd form: fewer multiplies "
                                 "than the direct convolution; tile padding included) / launch time measured with HIP "
                                 "events in this run; algorithmic_* prices SURVEY 8(d)'s direct-convolution flops per "
                                 "leaf over the same time and can exceed 1 for a Winograd kernel; mfma_busy_pmc is the "
@@ -517,7 +520,8 @@ class Leg:
                                            "every XCD's L2 reads the weight taps itself -- harmless for a kernel bound "
                                            "by the matrix pipe"
                                            % ((leaves_per_launch * (8 * HW + 4 * A + 4)
-                                               + 4.0 * (60 * 4096 + 18 * 64 + 64 + 5 * 64 + 3 * 64 + 3 + 20 * HW + 41
+                                               + 4.0 * ((45 * 6144 if self.net == "hipx3" else 60 * 4096)  # residual weights: 45 taps x 24 576 B of bf16 parts | 60 transformed taps of 4096 floats
+                                                        + 18 * 64 + 64 + 5 * 64 + 3 * 64 + 3 + 20 * HW + 41
                                                         + A * 2 * HW + A)) / 1e6))
                         if pmc.get(kname) else None,
                         "mfma_busy_pmc": pmc.get(kname, {}).get("mfma_busy"),
