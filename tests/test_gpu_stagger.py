@@ -164,7 +164,8 @@ def test_train_self_play_staggered_fills_the_replay_buffer():
     assert sp3["games"] >= 32 and len(rb3) == sp3["steps"] + sp3["games"]
 
 
-def test_staggered_real_weights_vs_reference_recorded_games():
+@pytest.mark.parametrize("inference", ["hipw", "hipx3"])  # hipx3: the opt-in bf16x3 net kernel (bench.py's labelled extra leg)
+def test_staggered_real_weights_vs_reference_recorded_games(inference):
     """The staggered path with the real net on the GPU (what bench.py runs) against the 32 self-play games RECORDED
     FROM THE REFERENCE at config 2's per-game settings (tests/golden/real_c4_x32.json.gz: shipped best_026_12000.dat,
     25 x 8 sims/move, tau = 1 for 10 plies).  A staggered engine cannot be stopped after every ply to read root N, but
@@ -186,7 +187,7 @@ def test_staggered_real_weights_vs_reference_recorded_games():
     net = net.to(DEV).eval()
     eng = SelfPlayEngine(game, 32, net1=net, max_batch=g0["batch"], seed=g0["seed"], uid_base=g0["uid"], device=DEV,
                          steps_before_tau_0=g0["steps_before_tau_0"], searches_hint=g0["searches"], stagger=True,
-                         stagger_recycle=False)
+                         stagger_recycle=False, inference=inference)
     tuples, recs = eng.play_until(g0["searches"], g0["batch"], recycle=False)
     assert eng.live_games() == 0 and eng.counters()["overflows"] == 0
     eng.close()
@@ -214,7 +215,7 @@ def test_staggered_real_weights_vs_reference_recorded_games():
             if ok and len(states) == gm["plies"]:
                 assert (result, steps) == (gm["result"], gm["steps"]), gm["uid"]
                 whole += 1
-    print("staggered vs reference-recorded games: identical pi on %d / %d plies, %d / 32 whole games" % (same, total, whole))
+    print("staggered (%s) vs reference-recorded games: identical pi on %d / %d plies, %d / 32 whole games" % (inference, same, total, whole))
     assert total >= 400 and same / total >= 0.99 and whole >= 24
 
 
