@@ -185,11 +185,12 @@ def test_winograd_net_tile_size_boundaries(L):
     hn.close()
 
 
-def test_hip_net_device_count_and_second_net_offset():
+@pytest.mark.parametrize("mode", ["f32w", "bf16x3"])
+def test_hip_net_device_count_and_second_net_offset(mode):
     """rows come from counts on the device: which = 1 starts at counts[0]."""
     from caro_ai_amd.net_hip import HipNet
     net = _net((2, 6, 7), 7, "best_026_12000.dat")
-    hn = HipNet(net, "cuda:0")
+    hn = HipNet(net, "cuda:0", mode=mode)
     x = _boards(50, (2, 6, 7), 3).to("cuda:0")
     counts = torch.tensor([20, 30], dtype=torch.int32, device="cuda:0")
     probs = torch.full((64, 7), -1.0, device="cuda:0")
