@@ -853,6 +853,13 @@ def main():
                 x3 = side_leg("net_bf16x3", dict(game_name="c4", G=args.games, S=args.searches, B=args.batch, arena=False,
                                                  net="hipx3"), 10, 5, not args.no_profile)
                 x3["vs_headline"] = x3["value"] / res["value"]
+                # the same leg as two engines of half the games on two HIP streams (no CU mask): with this kernel a
+                # half's tree kernels overlap the other half's net launch to a gain (the fp32 kernel loses that way)
+                x3b = side_leg("net_bf16x3-2streams", dict(game_name="c4", G=args.games, S=args.searches, B=args.batch,
+                                                           arena=False, net="hipx3", streams=2, stream_mask=0), 10, 5, False)
+                x3["two_streams"] = {"value": x3b["value"], "unit": x3b["unit"], "ms_per_step": x3b["ms_per_step"],
+                                     "vs_headline": x3b["value"] / res["value"], "streams_per_gpu": 2,
+                                     "overflows": x3b["overflows"]}
                 x3["note"] = ("extra leg, not the headline: lib/model.py Net with bf16x3 split operands, fp32 accumulate "
                               "(k_net_forward_x3); 10 moves after 5 of warm-up, the headline's games and seeds")
                 extras["net_bf16x3"] = x3
