@@ -74,6 +74,7 @@ def main():
 
     stats("stats", tag)
     stats("stats_config4", tag + "_config4")
+    stats("stats_x3", tag + "_x3")  # the labelled extra leg (--net hipx3)
     # ---- counters
     pmc_name = sys.argv[3] if len(sys.argv) > 3 else "pmc_r02.json"
 

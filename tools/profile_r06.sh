@@ -6,7 +6,7 @@
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/${1:-prof_r06}
-WHAT=${2:-all}   # "stats": the kernel-trace pass of the headline only
+WHAT=${2:-all}   # "stats": the kernel-trace pass of the headline only; "x3stats": that of the --net hipx3 leg only
 mkdir -p $OUT
 # what is profiled: bench.py quotes the counters of pmc_r06.json only while the kernel sources still hash to this
 python3 $ROOT/tools/source_sha.py > $OUT/source_sha256.json
@@ -15,6 +15,12 @@ B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra-configs --sustained-moves
 H="--steps 20 --warmup 5"
 C5="--arena --games 512 --searches 100 --steps 3 --warmup 2"
 C4="--game gomoku15 --searches 50 --steps 2 --warmup 1"
+x3_stats() {  # kernel-trace pass of the labelled extra leg's configuration (--net hipx3)
+  echo "rocprofv3 --kernel-trace --stats -- $B $H --net hipx3" | sed "s#$ROOT/##g" > $OUT/stats_x3.cmd
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_x3 -- $B $H --net hipx3 > $OUT/stats_x3.json 2> $OUT/stats_x3.err
+  echo x3 stats done
+}
+if [ "$WHAT" = "x3stats" ]; then x3_stats; exit 0; fi
 echo "rocprofv3 --kernel-trace --stats -- $B $H" | sed "s#$ROOT/##g" > $OUT/stats.cmd  # (what the summary's header quotes)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B $H > $OUT/stats.json 2> $OUT/stats.err
 echo stats done
@@ -35,5 +41,6 @@ run_pmc x3 $H --net hipx3   # the labelled extra leg: bf16x3 split operands (k_n
 echo "rocprofv3 --kernel-trace --stats -- $B $C4" | sed "s#$ROOT/##g" > $OUT/stats_config4.cmd
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_config4 -- $B $C4 > $OUT/stats_config4.json 2> $OUT/stats_config4.err
 echo config4 stats done
+x3_stats
 find $OUT -name "*_agent_info.csv" -delete
 du -sh $OUT
