@@ -290,7 +290,7 @@ class Leg:
     """One BASELINE.json configuration: engine + nets + the move loop."""
 
     def __init__(self, args, game_name, G, S, B, arena, rank, world, device, evict=None, node_cap=0, streams=None,
-                 stream_mask=None, net=None):
+                 stream_mask=None, net=None, split_tiles=True):
         from caro_ai_amd import parallel
         from caro_ai_amd.engine import SelfPlayEngine, StreamedSelfPlay, torch_evaluator
         from caro_ai_amd.lib.game.connect_four import ConnectFour
@@ -322,8 +322,8 @@ class Leg:
         if self.is_hip:
             from caro_ai_amd.net_hip import HipNet
             mode = {"hip": "f32", "hipw": "f32w", "hipx3": "bf16x3"}[self.net]
-            self.hipnet = HipNet(net, str(device), mode=mode)
-            hipnets = [self.hipnet] + ([HipNet(net2, str(device), mode=mode)] if arena else [])
+            self.hipnet = HipNet(net, str(device), mode=mode, split_tiles=split_tiles)
+            hipnets = [self.hipnet] + ([HipNet(net2, str(device), mode=mode, split_tiles=split_tiles)] if arena else [])
             make_evaluators = lambda: list(hipnets)
         else:
             fnet = GemmNet(net).to(device).eval()
@@ -775,6 +775,33 @@ def main():
     torch.cuda.empty_cache()
 
     extras, extras_rc = {}, 0
+    two_streams = None
+    if world == 1 and headline and args.net == "hipw" and args.streams == 1 and args.stagger and args.games % 2 == 0:
+        # The same games as two engines of half the games on two HIP streams, the net kernel with FULL tiles only (no
+        # K-split tiles: a half's launch then takes half the compute units and the two halves' launches run side by
+        # side, each half's tree kernels beside the other half's net launch).  A SCHEDULING variant reported beside
+        # `value`, which stays the one-engine figure every round has reported and the one the kernels' launch times and
+        # rooflines of this line belong to.  With K-split tiles two streams lose (each half's launch fills the chip).
+        try:
+            x = Leg(args, game_name="c4", G=args.games, S=args.searches, B=args.batch, arena=False, rank=rank, world=world,
+                    device=device, streams=2, stream_mask=0, split_tiles=False)
+            r2 = x.run(args.steps, args.warmup, profile=False, label="two_streams")
+            x.close()
+            del x
+            torch.cuda.empty_cache()
+            if r2["overflows"]:
+                raise RuntimeError("two_streams: %d minibatches overflowed the node pool" % r2["overflows"])
+            two_streams = {"value": r2["value"], "unit": r2["unit"], "ms_per_step": r2["ms_per_step"],
+                           "vs_value": r2["value"] / res["value"], "streams_per_gpu": 2, "overflows": r2["overflows"],
+                           "games_finished": r2["games_finished"],
+                           "note": "the headline's games as two engines of half the games on two HIP streams (no CU "
+                                   "mask), k_net_forward_w with full tiles only (HipNet(split_tiles=False)); a scheduling "
+                                   "variant, not a kernel speed-up: `value` and the rooflines of this line are one engine's"}
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            two_streams = {"error": repr(e)}
+            extras_rc = 1
     train_loop = None
     if world == 1 and headline and args.train_loop_games > 0 and args.net == "hipw" and args.stagger:
         try:
@@ -880,6 +907,7 @@ def main():
         out["dist"] = dist_rec
         out["selfcheck"] = selfcheck
         out["sustained"] = sustained
+        out["two_streams"] = two_streams
         out["train_loop"] = train_loop
         out["cpu_baseline"] = cpu_line
         out.update(extras)

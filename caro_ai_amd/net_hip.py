@@ -167,7 +167,7 @@ class HipNet:
     """Device-resident packed weights + the forward launch.
     mode "f32w" (default): float32 on v_mfma_f32_32x32x2_f32, the 3x3 convolutions in Winograd form -- the row form
                  F(2,3) ("f32w1"), or on large boards (13x13 up, one board per workgroup) the 2-D form F(2x2,3x3) ("f32w2").
-    mode "f32w1" / "f32w2": that form, forced.
+    mode "f32w1" / "f32w2": that form, forced.  split_tiles=False (row form): full tiles only, see __init__.
     mode "f32": the same with direct 3x3 convolutions (a plain fma chain in k order): the A/B baseline.
     mode "bf16x3": an EXTRA mode, never a default: the direct form with every float32 trunk operand split into three
                  bfloat16 parts, six part products per multiply on v_mfma_f32_16x16x32_bf16, float32 accumulation (k_net_forward_x3);
@@ -175,7 +175,7 @@ class HipNet:
 
     device_counts = True  # the engine may call forward_dev without knowing L on the host
 
-    def __init__(self, net: Net, device="cuda:0", negative_slope=0.01, mode="f32w"):
+    def __init__(self, net: Net, device="cuda:0", negative_slope=0.01, mode="f32w", split_tiles=True):
         self.L = _lib.load()
         self.device = torch.device(device)
         self.H, self.W = net.input_shape[1], net.input_shape[2]
@@ -195,7 +195,21 @@ class HipNet:
             _lib.check(self.L.caro_net_enable_winograd2d(self.h, w2.ctypes.data, w2.size))
         elif mode == "f32w1":
             ww = pack_net_w(net)
-            _lib.check(self.L.caro_net_enable_winograd(self.h, ww.ctypes.data, ww.size))
+            # split_tiles=False: full tiles only -- no 2- / 4-way K-split tiles for small launches (the library reads
+            # CARO_NO_SPLIT_TILES when the mode is enabled).  A half-size launch then occupies half the compute units
+            # instead of all of them: what two engines on two streams want (bench.py `two_streams`).
+            import os
+            old = os.environ.get("CARO_NO_SPLIT_TILES")
+            if not split_tiles:
+                os.environ["CARO_NO_SPLIT_TILES"] = "1"
+            try:
+                _lib.check(self.L.caro_net_enable_winograd(self.h, ww.ctypes.data, ww.size))
+            finally:
+                if not split_tiles:
+                    if old is None:
+                        del os.environ["CARO_NO_SPLIT_TILES"]
+                    else:
+                        os.environ["CARO_NO_SPLIT_TILES"] = old
         elif mode == "bf16x3":
             wx = pack_net_x3(net)
             assert wx.size == self.L.caro_net_split_bf16_size()

@@ -458,3 +458,26 @@ def test_split_bf16_net_on_large_boards_uses_the_batched_heads():
             assert torch.equal(values[:40], va) and torch.equal(values[40:], vb)
             hb.close()
         hn.close()
+
+
+def test_full_tiles_only_option_of_the_row_winograd_form(monkeypatch):
+    """HipNet(split_tiles=False): the row-Winograd kernel with full tiles only (what bench.py's `two_streams` record runs: a
+    half-size launch then takes half the compute units) == the library's CARO_NO_SPLIT_TILES=1 form bit for bit, within the
+    usual gates of the default form, and the process environment is left as it was."""
+    import os
+    from caro_ai_amd.net_hip import HipNet
+    net = _net((2, 6, 7), 7, "best_026_12000.dat")
+    x = _boards(600, (2, 6, 7), 11).to("cuda:0")  # a launch the default form serves with 2-way K-split tiles
+    monkeypatch.delenv("CARO_NO_SPLIT_TILES", raising=False)
+    h_opt = HipNet(net, "cuda:0", mode="f32w", split_tiles=False)
+    assert "CARO_NO_SPLIT_TILES" not in os.environ
+    h_def = HipNet(net, "cuda:0", mode="f32w")
+    monkeypatch.setenv("CARO_NO_SPLIT_TILES", "1")
+    h_env = HipNet(net, "cuda:0", mode="f32w")
+    monkeypatch.delenv("CARO_NO_SPLIT_TILES")
+    (p_opt, v_opt), (p_def, v_def), (p_env, v_env) = h_opt(x), h_def(x), h_env(x)
+    torch.cuda.synchronize()
+    assert torch.equal(p_opt, p_env) and torch.equal(v_opt, v_env)
+    assert (p_opt - p_def).abs().max().item() < 1e-4 and (v_opt - v_def).abs().max().item() < 1e-4
+    for h in (h_opt, h_def, h_env):
+        h.close()
