@@ -655,6 +655,19 @@ def train_loop_record(args, device, headline, games=4096, concurrent=1024):
         sp["speed_nodes_wall"] = sp["nodes"] / sp["seconds_wall"]
         stream.append(sp)
     train.release_engines()
+    # ... and the stream on two half-engines (train.self_play_stream(streams=2), `python -m caro_ai_amd.train --streams 2`):
+    # the product form of this line's `two_streams` record
+    stream2 = []
+    for i in range(3):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        sp = train.self_play_stream(game, rb, net, games, device=str(device), searches=args.searches, batch=args.batch,
+                                    concurrent=concurrent, uid_base=(6 + i) * games, streams=2)
+        torch.cuda.synchronize(device)
+        sp["seconds_wall"] = time.perf_counter() - t0
+        sp["speed_nodes_wall"] = sp["nodes"] / sp["seconds_wall"]
+        stream2.append(sp)
+    train.release_engines()
     torch.cuda.empty_cache()
     keep = ("speed_nodes_wall", "speed_nodes_play", "nodes", "steps", "games", "rows", "seconds_wall", "seconds_setup",
             "seconds_play", "seconds_gather", "engine_reused", "passes")
@@ -672,6 +685,11 @@ def train_loop_record(args, device, headline, games=4096, concurrent=1024):
                        "calls": [{k: c[k] for k in keep} for c in stream],
                        "what": "train.self_play_stream, three consecutive calls of %d games (the first starts the stream): "
                                "no call plays a sparse tail, the games in flight at its end finish in the next call" % games},
+            "stream_two_engines": {"speed_nodes": stream2[-1]["speed_nodes_wall"],
+                                   "frac_of_headline": stream2[-1]["speed_nodes_wall"] / headline,
+                                   "calls": [{k: c[k] for k in keep} for c in stream2],
+                                   "what": "the same with streams=2 (`train.py --streams 2`, opt-in): the slots as two engines "
+                                           "of half the slots on two HIP streams, full net tiles only"},
             "tail_note": "exact form: the wanted games are played to the end and nothing beyond them is started, so the "
                          "last passes of a call carry few live games (`passes` against games x mean plies / slots) and "
                          "each of those passes costs its 25 launch pairs at their small-launch floor; the stream form "

@@ -530,6 +530,29 @@ class StreamedSelfPlay:
     def _each(self):
         return zip(self.parts, self.streams)
 
+    # what train.self_play_stream asks of an engine
+    @property
+    def h(self):
+        return all(e.h for e in self.parts)
+
+    @property
+    def cfg(self):
+        return self.parts[0].cfg
+
+    _drain_open = False  # (this class's move() drains synchronously per part: nothing stays open between calls)
+
+    def restart(self, evaluators=None, searches=None, **run):
+        """SelfPlayEngine.restart on every part; `uid_base` is the whole engine's (part k starts k * G / n further)"""
+        per = self.G // len(self.parts)
+        for k, (e, st) in enumerate(self._each()):
+            with torch.cuda.stream(st):
+                r = dict(run)
+                if "uid_base" in r:
+                    r["uid_base"] = r["uid_base"] + k * per
+                e.restart(evaluators=evaluators, searches=searches, **r)
+                e._primed = False
+        torch.cuda.synchronize(self.device)
+
     def search(self, searches, batch):
         for e, st in self._each():
             with torch.cuda.stream(st):

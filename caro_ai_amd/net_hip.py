@@ -264,16 +264,16 @@ _HIPNETS = {}  # (id(net), device, mode) -> (weights version, HipNet), most rece
 HIPNET_CACHE = 4
 
 
-def hipnet_for(net: Net, device="cuda:0", mode="f32w") -> HipNet:
+def hipnet_for(net: Net, device="cuda:0", mode="f32w", split_tiles=True) -> HipNet:
     """The `HipNet` of `net` as its weights are NOW, built once per weight version: callers that run the same net
     again and again (train.self_play with the best net between two promotions, train.py:185-217) do not pack and
     upload it again.  The cache only drops its reference when an entry goes stale or falls out; an engine that
     still launches on a HipNet keeps it alive."""
-    key = (id(net), str(torch.device(device)), mode)
+    key = (id(net), str(torch.device(device)), mode, bool(split_tiles))
     ver = weights_version(net)
     hit = _HIPNETS.pop(key, None)
     if hit is None or hit[0] != ver:
-        hit = (ver, HipNet(net, device, mode=mode))
+        hit = (ver, HipNet(net, device, mode=mode, split_tiles=split_tiles))
     _HIPNETS[key] = hit
     while len(_HIPNETS) > HIPNET_CACHE:
         _HIPNETS.pop(next(iter(_HIPNETS)))

@@ -250,7 +250,8 @@ def _stats(steps, nodes, dr, t_call, t_ready, t_played, reused, passes):
 
 
 def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0, uid_base=0,
-                     searches=cfg.MCTS_SEARCHES, batch=cfg.MCTS_BATCH_SIZE, concurrent=None, node_cap=None, net_mode="f32w"):
+                     searches=cfg.MCTS_SEARCHES, batch=cfg.MCTS_BATCH_SIZE, concurrent=None, node_cap=None, net_mode="f32w",
+                     streams=1):
     """self_play as a STREAM: the engine is never stopped between calls.  Every slot restarts the moment its game ends
     (uid += stride, in the tree kernel) and a call returns as soon as n_games games have FINISHED since the previous
     call; the games then in flight are not thrown away -- they finish inside the next call and reach the replay buffer
@@ -261,6 +262,10 @@ def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0,
     What changes against `self_play`: WHEN a game's tuples arrive (a long game may land one iteration later), not
     which games are played or how.  When the net's weights have changed since the stream was started (a promotion),
     the games in flight belong to the old net: the stream is restarted (they are dropped, at most one game per slot).
+    streams=2 (opt-in): the slots as two engines of half the slots on two HIP streams, the float32 net kernel with full
+    tiles only -- a half's net launch then takes half the compute units, the halves' launches run side by side and each
+    half's tree kernels beside the other half's net launch (bench.py `two_streams`: +3 %, with the bf16x3 kernel +7 %);
+    the same uids as one engine.
     Needs the staggered geometry (whole wavefronts per game: `staggered_ok`).  Returns what self_play returns; `nodes` / `speed_nodes`
     count the node-expansions of this call's launches (incl. the part of the in-flight games played in it)."""
     from caro_ai_amd import net_hip
@@ -270,11 +275,14 @@ def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0,
         raise _lib.CaroError("self_play_stream needs whole wavefronts per game (batch x lanes per descent a multiple of 64)")
     G = max(1, int(concurrent or n_games))
     stride = world * G
-    hip = net_hip.hipnet_for(net, device, mode=net_mode)
+    streams = max(1, int(streams))
+    if G % streams:
+        raise _lib.CaroError("self_play_stream: %d slots do not split over %d streams" % (G, streams))
+    hip = net_hip.hipnet_for(net, device, mode=net_mode, split_tiles=streams == 1)
     hw = game.obs_shape[1] * game.obs_shape[2]
-    from caro_ai_amd.engine import SelfPlayEngine
+    from caro_ai_amd.engine import SelfPlayEngine, StreamedSelfPlay
     cap = int(node_cap) if node_cap else SelfPlayEngine.default_node_cap(searches, batch, hw)
-    key = ("stream", type(game).__name__, game.kind, game.n, game.k, G, batch, cap, str(torch.device(device)))
+    key = ("stream", type(game).__name__, game.kind, game.n, game.k, G, batch, cap, str(torch.device(device)), streams)
     eng = _ENGINES.pop(key, None)
     ss = getattr(eng, "_stream_state", None) if eng is not None and eng.h else None
     reused = ss is not None and ss["hip"] is hip and ss["searches"] == searches
@@ -287,6 +295,9 @@ def self_play_stream(game, replay_buffer, net, n_games, device="cuda:0", seed=0,
         if eng is not None and eng.h:
             eng._drain_open and eng.flush()
             eng.restart(evaluators=[hip], searches=searches, **run)
+        elif streams > 1:
+            eng = StreamedSelfPlay(game, G, lambda: [hip], n_streams=streams, device=device, partition_cus=False,
+                                   max_batch=batch, node_cap=cap, searches_hint=searches, stagger=True, **run)
         else:
             eng = SelfPlayEngine(game, G, evaluators=[hip], max_batch=batch, node_cap=cap, device=device,
                                  searches_hint=searches, stagger=True, **run)
@@ -502,6 +513,9 @@ def parse_args(argv=None):
                    help="arithmetic of the self-play net kernel: f32w = float32 (default); bf16x3 = every float32 operand of "
                         "the residual trunk as three bfloat16 parts, float32 accumulate -- 1.3 x the leaves/s, outputs within "
                         "the float32 kernels' own tolerance but not bit-identical to them (the arena gate stays float32)")
+    p.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                   help="self-play (stream form) as this many engines on separate HIP streams, the float32 net kernel with "
+                        "full tiles only: 2 = +3 %% leaves/s (bench.py `two_streams`; +7 %% with --net-mode bf16x3)")
     p.add_argument("--ddp", action="store_true",
                    help="several ranks: every rank trains on its share of each batch, gradients all-reduced "
                         "(default: rank 0 trains, the weights are broadcast)")
@@ -509,7 +523,7 @@ def parse_args(argv=None):
 
 
 def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, reference_evaluate=None, ddp=False,
-        sample_seed=None, stop=None, log=print, concurrent=None, stream=False, net_mode="f32w"):
+        sample_seed=None, stop=None, log=print, concurrent=None, stream=False, net_mode="f32w", streams=1):
     """The reference's training loop (train.py:165-217): self-play with the best net -> replay buffer -> TRAIN_ROUNDS SGD
     steps -> every EVALUATE_EVERY_STEP iterations the arena gate (challenger = the net being trained against the best
     net; promoted when its win ratio exceeds BEST_NET_WIN_RATIO: `NetWrapper.sync`, `best_%03d_%05d.dat`).
@@ -524,7 +538,7 @@ def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, re
     one per game).  stream=True: self-play as a stream (`self_play_stream`: slots restart at once, an iteration takes
     the first `games` games that finish, games in flight carry over to the next iteration -- no sparse tail; where the
     geometry has no staggered mode the exact form is used).  net_mode: the self-play net kernel's arithmetic (`self_play`;
-    the arena gate always runs float32).  Returns the history: per trained iteration the three losses, per evaluation (iteration, win
+    the arena gate always runs float32); streams: the stream form on that many half-engines (`self_play_stream`).  Returns the history: per trained iteration the three losses, per evaluation (iteration, win
     ratio, promoted), the number of promotions, the best net wrapper, and per iteration the seconds each phase took
     (`phases`: self_play -- with its own setup / play / gather split --, train, broadcast, evaluate)."""
     rank, _, world = parallel.env_rank() if parallel.is_dist() else (0, 0, 1)
@@ -547,7 +561,8 @@ def fit(game, net, device, games, iterations=0, saves_path=None, writer=None, re
         t0 = clock()
         if stream and staggered_ok(game, cfg.MCTS_BATCH_SIZE):
             sp = self_play_stream(game, replay_buffer, best_net.target_model, games, device=device, seed=0,
-                                  uid_base=step_idx * games * world, concurrent=concurrent, net_mode=net_mode)
+                                  uid_base=step_idx * games * world, concurrent=concurrent, net_mode=net_mode,
+                                  streams=streams)
         else:
             sp = self_play(game, replay_buffer, best_net.target_model, games, device=device, seed=step_idx,
                            uid_base=step_idx * games * world, stagger=True, concurrent=concurrent, net_mode=net_mode)
@@ -625,7 +640,8 @@ def main(argv=None):
     fit(game, net, device, args.games, iterations=args.iterations, saves_path=saves_path, writer=writer,
         reference_evaluate=True if args.reference_evaluate else False if args.sharded_evaluate else None, ddp=args.ddp,
         log=lambda m: print(m, flush=True),
-        concurrent=args.concurrent or min(args.games, 1024), stream=not args.exact_self_play, net_mode=args.net_mode)
+        concurrent=args.concurrent or min(args.games, 1024), stream=not args.exact_self_play, net_mode=args.net_mode,
+        streams=args.streams)
     writer.close()
     release_engines()  # (the self-play engines are kept between iterations: gigabytes of tree tables)
 

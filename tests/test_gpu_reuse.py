@@ -545,3 +545,34 @@ def test_self_play_with_the_split_bf16_net_mode():
     assert st["games"] >= 32 and st["nodes"] > 0
     train.release_engines()
     net_hip.release_hipnets()
+
+
+def test_self_play_stream_on_two_half_engines():
+    """train.self_play_stream(streams=2): the slots as two engines on two HIP streams (full net tiles only), three
+    consecutive calls: every call delivers complete games with unique uids out of the single engine's uid set, nothing
+    overflows, the engine is kept between the calls; and the one-engine form still works beside it (its own cache key)."""
+    import torch
+    from caro_ai_amd import net_hip, train
+    from caro_ai_amd.engine import StreamedSelfPlay
+    from caro_ai_amd.lib.game.connect_four import ConnectFour
+    from caro_ai_amd.lib.model import Net
+    from caro_ai_amd.train import DeviceReplayBuffer
+    g = ConnectFour()
+    net = Net(g.obs_shape, g.action_space)
+    net.load_state_dict(torch.load(os.path.join(WEIGHTS, "best_026_12000.dat"), map_location="cpu"))
+    net = net.to("cuda:0").eval()
+    rb = DeviceReplayBuffer(g, 40000, "cuda:0")
+    seen = set()
+    for call in range(3):
+        st = train.self_play_stream(g, rb, net, 64, seed=5, searches=5, batch=8, concurrent=32, streams=2)
+        assert st["games"] >= 64 and st["nodes"] > 0 and st["engine_reused"] == (call > 0)
+    eng = next(e for e in train._ENGINES.values() if isinstance(e, StreamedSelfPlay))
+    assert len(eng.parts) == 2 and eng.counters()["overflows"] == 0
+    # uids: slot g of part k is global slot 16 k + g, stride 32 -- the single engine's layout
+    assert [e.cfg.uid_base for e in eng.parts] == [eng.parts[0].cfg.uid_base, eng.parts[0].cfg.uid_base + 16]
+    assert all(e.cfg.uid_stride == 32 for e in eng.parts)
+    one = train.self_play_stream(g, rb, net, 32, seed=5, searches=5, batch=8, concurrent=32)
+    assert one["games"] >= 32 and not one["engine_reused"]
+    assert len(rb) > 0
+    train.release_engines()
+    net_hip.release_hipnets()
